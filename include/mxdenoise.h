@@ -1,0 +1,190 @@
+/*
+ * mxdenoise -- MI355X (gfx950) native denoiser for the sduss/Mixfusion model slot.  C ABI.
+ *
+ * Plain pointers and sizes only (no torch types).  Every device pointer is a HIP device
+ * address owned by the caller; every entry point takes an explicit hipStream_t (as void*),
+ * launches asynchronously on it and never synchronises the device.  Return value: 0 on
+ * success, non-zero on error (mx_last_error() gives the message for the calling thread).
+ *
+ * Reference interfaces replaced (paths relative to the sduss tree):
+ *   inner boundary  esymred_mp.groupnorm / mock_groupnorm
+ *                   sduss/model_executor/modules/kernels/norm_silu_concat.cpp:66-101
+ *                   (called from modules/groupnorm.py:33,50,58)
+ *   outer boundary  PatchUNet.forward            sduss/model_executor/modules/unet.py:205-530
+ *                   (invoked once per step at
+ *                    diffusers/pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl_esymred.py:369-380)
+ *   step either side EulerDiscreteScheduler.batch_scale_model_input / batch_step
+ *                   diffusers/schedulers/scheduling_euler_discrete.py:161-274 and the CFG combine
+ *                   pipeline_stable_diffusion_xl_esymred.py:382-385
+ */
+#ifndef MXDENOISE_H
+#define MXDENOISE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of caller tensors */
+enum { MX_F32 = 0, MX_F16 = 1, MX_BF16 = 2 };
+
+const char* mx_last_error(void);
+int mx_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Inner boundary: drop-in for the reference's only native op (NCHW patch batches).
+ *
+ * mx_groupnorm_halo == esymred_mp.groupnorm (norm_silu_concat.cpp:75-101):
+ *   per-(patch,group) moments -> cross-patch merge per latent (mean of means, mean of biased
+ *   variances; norm_silu_concat.cu:361-386) -> y = x*(rstd*gamma) + (beta - rstd*gamma*mean)
+ *   (no SiLU, cu:157-163) -> if padding: result placed in the interior of a zero-filled
+ *   [N,C,H+2,W+2] tensor and each patch's edge rows/cols/corners scattered into its neighbours'
+ *   halo cells (cu:164-241).  `cpg` is what the reference calls `group` (channels per group).
+ *   x: [N,C,H,W] contiguous, y: [N,C,H+2p,W+2p] (p = padding?1:0), gamma/beta: [C] of `dtype`,
+ *   latent_offset: int32[n_latents+1], patch_map: int32[N] (1-based latent index),
+ *   padding_idx: int32[4N] = (top,left,bottom,right) neighbour patch index or -1.
+ *   workspace: >= mx_groupnorm_halo_workspace_bytes(N, C, cpg) bytes of device scratch.
+ *   Differences, on purpose: statistics are kept in fp32 (the reference rounds them to the
+ *   tensor dtype, cpp:84-85); the merge is out of place (the reference's in-place merge races);
+ *   no device synchronisation (reference: cudaDeviceSynchronize after every launch).
+ *
+ * mx_halo_only == esymred_mp.mock_groupnorm (cpp:66-74): the same scatter with identity values.
+ * ------------------------------------------------------------------------------------------ */
+size_t mx_groupnorm_halo_workspace_bytes(int N, int C, int cpg);
+int mx_groupnorm_halo(void* stream, const void* x, const void* gamma, const void* beta, void* y,
+                      int N, int C, int H, int W, int cpg, double eps, int padding,
+                      const int32_t* latent_offset, int n_latents, const int32_t* patch_map,
+                      const int32_t* padding_idx, int dtype, void* workspace);
+int mx_halo_only(void* stream, const void* x, void* y, int N, int C, int H, int W,
+                 const int32_t* padding_idx, int dtype);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks of the step plan (NHWC / token-major bf16, fp32 accumulate).  Exported so the
+ * parity tests can check each kernel against the oracle through the same ABI the plan uses.
+ * ------------------------------------------------------------------------------------------ */
+
+/* epilogue flags for mx_gemm / mx_conv3x3 */
+enum {
+  MX_EPI_SILU     = 1 << 0,  /* out = silu(v) */
+  MX_EPI_GEGLU    = 1 << 1,  /* weight rows interleaved [32 hidden | 32 gate]; out[M, N/2] = h * gelu(g) */
+  MX_EPI_OUT_F32  = 1 << 2,  /* C is fp32 instead of bf16 */
+  MX_EPI_QKV      = 1 << 3   /* column segments of width seg: segment s with (s % period) == period-1
+                                is written transposed into vt[b][vcol][key]; others row-major, compacted */
+};
+
+typedef struct mx_gemm_desc {
+  const void* a;        /* bf16 [M, K] row stride lda (elements); conv: NHWC input [B, Hin, Win, Cin] */
+  const void* w;        /* bf16 [N, K] row-major (K = 9*Cin tap-major for conv) */
+  void* c;              /* bf16 (or fp32) [M, ldc] */
+  const float* bias;    /* fp32 [N] or NULL */
+  const float* rowbias; /* fp32 [M / rows_per_batch, ldrb] or NULL (time-embedding add of resnet conv1) */
+  const void* residual; /* bf16 [M, ldr] or NULL, added before the activation */
+  void* vt;             /* MX_EPI_QKV: bf16 [batches][N/period][ldvt] */
+  int M, N, K;
+  int lda, ldc, ldr, ldrb;
+  int rows_per_batch;
+  int flags;
+  int seg, period, ldvt; /* MX_EPI_QKV */
+  /* conv geometry (ignored by mx_gemm) */
+  int B, Hin, Win, Cin;  /* stored input */
+  int Hout, Wout;        /* output grid; M = B*Hout*Wout */
+  int stride;            /* 1 or 2 */
+  int up;                /* 1: input is nearest-upsampled x2 on the fly (Hout = 2*Hin) */
+  int corner_patch;      /* >0: sliced-mode halo-corner rule with this patch edge (output-grid pixels
+                            for stride 1, input-grid pixels for stride 2); 0: plain zero padding */
+} mx_gemm_desc;
+
+int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
+int mx_conv3x3(void* stream, const mx_gemm_desc* d);   /* implicit GEMM, pad 1 */
+
+/* softmax(Q K^T * scale) V per (batch, head); head_dim 64.
+ * q: bf16 rows (b*Lq + i), head h at columns [64h, 64h+64), row stride ldq; k likewise (Lk, ldk);
+ * vt: bf16, V transposed: element (b, h, d, key) at vt[b*vt_batch_stride + (h*64 + d)*ldvt + key];
+ * o: bf16 [B*Lq, ldo]. */
+int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                 int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale);
+
+/* y = LayerNorm(x) * gamma + beta over the last dim C; x,y bf16 [M, C]; gamma/beta fp32 [C] */
+int mx_layernorm(void* stream, const void* x, void* y, const float* gamma, const float* beta,
+                 int M, int C, float eps);
+
+/* NHWC GroupNorm (+ optional SiLU): x,y bf16 [B, H, W, C]; gamma/beta fp32 [C].
+ * patch > 0 selects the reference's sliced statistics (average over patch x patch tiles of
+ * per-tile mean and biased variance, norm_silu_concat.cu:361-386); 0 = exact GroupNorm.
+ * workspace >= mx_groupnorm_nhwc_workspace_bytes(B, H, W, C). */
+size_t mx_groupnorm_nhwc_workspace_bytes(int B, int H, int W, int C);
+int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const float* gamma, const float* beta,
+                      int B, int H, int W, int C, int groups, float eps, int silu, int patch,
+                      void* workspace);
+
+/* ------------------------------------------------------------------------------------------
+ * Outer boundary: the SDXL UNet in the model slot.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mx_unet_config {
+  int in_channels, out_channels;
+  int n_levels;                    /* <= 4 */
+  int block_out_channels[4];
+  int layers_per_block;
+  int down_has_attn[4];
+  int transformer_layers[4];
+  int num_heads[4];                /* head_dim must be 64 */
+  int cross_attention_dim;
+  int addition_time_embed_dim;
+  int projection_class_embeddings_input_dim;
+  int norm_num_groups;
+  float norm_eps, transformer_norm_eps, layer_norm_eps;
+} mx_unet_config;
+
+typedef struct mx_weight_entry {
+  const char* name;   /* packed-tensor name, see sduss_amd/weights.py */
+  uint64_t offset;    /* byte offset into the blob */
+  uint64_t bytes;
+} mx_weight_entry;
+
+typedef struct mx_unet mx_unet;
+
+mx_unet* mx_unet_create(const mx_unet_config* cfg);
+void mx_unet_destroy(mx_unet* u);
+/* the blob (device memory, packed by sduss_amd/weights.py) stays owned by the caller and must
+ * outlive the handle; the table is copied */
+int mx_unet_set_weights(mx_unet* u, const void* blob, uint64_t blob_bytes,
+                        const mx_weight_entry* table, int n_entries);
+size_t mx_unet_workspace_bytes(const mx_unet* u, int batch, int H, int W, int ctx_len);
+/* host-only walk of the step plan that resolves every packed tensor by name and size (no launches, no GPU needed) */
+int mx_unet_validate(const mx_unet* u, int batch, int H, int W, int ctx_len);
+/* One UNet forward over `batch` whole latents of one resolution (CFG rows included by the caller).
+ *   latents  [batch, in_channels, H, W]  of `io_dtype` (NCHW, as the reference passes them)
+ *   timesteps fp32 [batch]; ehs bf16 [batch, ctx_len, cross_attention_dim];
+ *   text_embeds bf16 [batch, text_dim]; time_ids fp32 [batch, 6]
+ *   out      [batch, out_channels, H, W] of `io_dtype`
+ *   gn_patch 0 = is_sliced False (exact GroupNorm, zero-padded convs);
+ *            p>0 = is_sliced True with latent patch edge p: patch-averaged GroupNorm statistics and the
+ *            halo-corner rule, i.e. bit-for-bit the arithmetic of the reference's sliced path on whole images. */
+int mx_unet_forward(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
+                    const void* ehs, const void* text_embeds, const float* time_ids, void* out,
+                    int batch, int H, int W, int ctx_len, int gn_patch, void* workspace, size_t workspace_bytes);
+/* debugging / parity: copy of the NHWC bf16 activation after the named stage of the LAST forward
+ * is not kept; instead a forward can be asked to stop after `stage` and dump it (tests only). */
+int mx_unet_forward_trace(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
+                          const void* ehs, const void* text_embeds, const float* time_ids, void* out,
+                          int batch, int H, int W, int ctx_len, int gn_patch, void* workspace,
+                          size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * The element-wise steps either side of the model call.
+ * ------------------------------------------------------------------------------------------ */
+/* out[b] = x[b mod n_lat] / sqrt(sigma[b mod n_lat]^2 + 1) for b in [0, n_rows)   (batch_scale_model_input, CFG
+ * duplication of the latents fused: n_rows = 2*n_lat under CFG, pipeline_..._esymred.py:327) */
+int mx_euler_scale_input(void* stream, const void* latents, void* out, const float* sigma,
+                         int n_lat, int n_rows, int64_t elems_per_latent, int dtype);
+/* latents <- latents + ((u + g (t - u))) * (sigma_next - sigma), fp32 math, stored in `dtype`
+ * noise: [2*n_lat, elems] = [uncond..., cond...] (guidance > 0) ; epsilon-prediction Euler step */
+int mx_cfg_euler_step(void* stream, const void* noise, void* latents, const float* sigma, const float* sigma_next,
+                      float guidance_scale, int n_lat, int64_t elems_per_latent, int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXDENOISE_H */

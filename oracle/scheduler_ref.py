@@ -25,7 +25,7 @@ def sdxl_euler_tables(num_inference_steps: int, num_train_timesteps: int = 1000,
     step_ratio = num_train_timesteps // num_inference_steps
     timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.float32)
     timesteps += steps_offset
-    sig = np.array(((1 - alphas_cumprod) / alphas_cumprod) ** 0.5)
+    sig = (((1 - alphas_cumprod) / alphas_cumprod) ** 0.5).numpy()
     sigmas = np.interp(timesteps, np.arange(0, len(sig)), sig)
     sigmas = np.concatenate([sigmas, [0.0]]).astype(np.float32)
     init_noise_sigma = float((sigmas.max() ** 2 + 1) ** 0.5)  # 'leading' spacing

@@ -1,0 +1,68 @@
+// Shared helpers for the gfx950 kernels of mxdenoise.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace mx {
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+
+// round-to-nearest-even via the hardware convert (keeps NaN a NaN, MI355X_MICROARCH "Correctness boundaries")
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as diffusers' GEGLU uses F.gelu default
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host side ----
+void set_error(const std::string& msg);
+#define MX_CHECK(cond, msg)                   \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::mx::set_error(std::string(msg));      \
+      return 1;                               \
+    }                                         \
+  } while (0)
+#define MX_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::mx::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+      return 1;                                                                          \
+    }                                                                                    \
+  } while (0)
+#define MX_LAUNCH_CHECK() MX_HIP(hipGetLastError())
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace mx

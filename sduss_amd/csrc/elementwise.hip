@@ -1,0 +1,218 @@
+// Small HBM-bound glue kernels of the step plan (gfx950): layout conversion at the model boundary,
+// sinusoidal embeddings, channel concat, and the fused scheduler / CFG steps either side of the UNet.
+#include "common.h"
+#include "../../include/mxdenoise.h"
+
+namespace mx {
+
+template <typename T> __device__ __forceinline__ float load_as_f32(const T* p, long i);
+template <> __device__ __forceinline__ float load_as_f32<float>(const float* p, long i) { return p[i]; }
+template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t* p, long i) { return bf16_to_f32(p[i]); }
+template <> __device__ __forceinline__ float load_as_f32<_Float16>(const _Float16* p, long i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void store_from_f32(T* p, long i, float v);
+template <> __device__ __forceinline__ void store_from_f32<float>(float* p, long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void store_from_f32<bf16_t>(bf16_t* p, long i, float v) { p[i] = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void store_from_f32<_Float16>(_Float16* p, long i, float v) { p[i] = (_Float16)v; }
+
+// value after a round trip through T (emulates an op whose result tensor has dtype T)
+template <typename T> __device__ __forceinline__ float rnd(float v) {
+  T tmp;
+  store_from_f32<T>(&tmp, 0, v);
+  return load_as_f32<T>(&tmp, 0);
+}
+
+// NCHW latents of any io dtype -> NHWC bf16 with the channel dim zero-padded to CP (=64), so conv_in
+// runs on the same implicit-GEMM kernel as every other conv (unet.py:344).
+template <typename T>
+__global__ void prep_latent_kernel(const T* __restrict__ in, bf16_t* __restrict__ out, int B, int Cin, int HW, int CP) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, 8-channel chunk)
+  const int chunks = CP / 8;
+  const long total = (long)B * HW * chunks;
+  if (idx >= total) return;
+  const int ch = (int)(idx % chunks);
+  const long pix = idx / chunks;
+  const int b = (int)(pix / HW);
+  const int p = (int)(pix - (long)b * HW);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = ch * 8 + e;
+    v[e] = (c < Cin) ? load_as_f32<T>(in, ((long)b * Cin + c) * HW + p) : 0.f;
+  }
+  u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  *reinterpret_cast<u32x4*>(out + idx * 8) = o;
+}
+
+// NHWC bf16 [B*HW, ld] (first C columns) -> NCHW io dtype
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ in, T* __restrict__ out, int B, int C, int HW, int ld) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW, p fastest
+  const long total = (long)B * C * HW;
+  if (idx >= total) return;
+  const int p = (int)(idx % HW);
+  const long bc = idx / HW;
+  const int c = (int)(bc % C);
+  const int b = (int)(bc / C);
+  store_from_f32<T>(out, idx, bf16_to_f32(in[((long)b * HW + p) * ld + c]));
+}
+
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin], bf16 out.
+// tsin [B, d0] from timesteps; addin [B, text_dim + 6*da] = [text_embeds | sinusoid(time_ids)] (unet.py:314-334).
+__global__ void time_embed_kernel(const float* __restrict__ timesteps, const bf16_t* __restrict__ text_embeds,
+                                  const float* __restrict__ time_ids, bf16_t* __restrict__ tsin,
+                                  bf16_t* __restrict__ addin, int B, int d0, int text_dim, int da) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int addw = text_dim + 6 * da;
+  if (i < d0) {
+    const int half = d0 / 2;
+    const int j = (i < half) ? i : i - half;
+    const float freq = __expf(-9.210340371976184f * (float)j / (float)half);
+    const float ang = timesteps[b] * freq;
+    tsin[(long)b * d0 + i] = f32_to_bf16((i < half) ? cosf(ang) : sinf(ang));
+  }
+  if (i < addw) {
+    bf16_t o;
+    if (i < text_dim) {
+      o = text_embeds[(long)b * text_dim + i];
+    } else {
+      const int k = i - text_dim;
+      const int which = k / da;
+      const int e = k - which * da;
+      const int half = da / 2;
+      const int j = (e < half) ? e : e - half;
+      const float freq = __expf(-9.210340371976184f * (float)j / (float)half);
+      const float ang = time_ids[b * 6 + which] * freq;
+      o = f32_to_bf16((e < half) ? cosf(ang) : sinf(ang));
+    }
+    addin[(long)b * addw + i] = o;
+  }
+}
+
+// out[m, 0:C1] = a[m, :], out[m, C1:C1+C2] = b[m, :]   (torch.cat([hidden, skip], dim=1) in NHWC)
+__global__ void concat_channels_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                       bf16_t* __restrict__ out, long M, int C1, int C2) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunks = (C1 + C2) / 8;
+  if (idx >= M * chunks) return;
+  const long m = idx / chunks;
+  const int ch = (int)(idx - m * chunks);
+  const int c1 = C1 / 8;
+  const u32x4 v = (ch < c1) ? *reinterpret_cast<const u32x4*>(a + m * C1 + ch * 8)
+                            : *reinterpret_cast<const u32x4*>(b + m * C2 + (ch - c1) * 8);
+  *reinterpret_cast<u32x4*>(out + idx * 8) = v;
+}
+
+// batch_scale_model_input with the CFG duplication fused (scheduling_euler_discrete.py:161-184)
+template <typename T>
+__global__ void euler_scale_input_kernel(const T* __restrict__ lat, T* __restrict__ out, const float* __restrict__ sigma,
+                                         int n_lat, int n_rows, long elems) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_rows * elems) return;
+  const int row = (int)(idx / elems);
+  const long e = idx - (long)row * elems;
+  const int src = row % n_lat;
+  // the reference evaluates samples / ((sigmas ** 2 + 1) ** 0.5) with sigmas cast to the tensor dtype
+  // (scheduling_euler_discrete.py:175-182): one rounding to T per op
+  const float s = rnd<T>(sigma[src]);
+  const float denom = rnd<T>(__fsqrt_rn(rnd<T>(__fadd_rn(rnd<T>(__fmul_rn(s, s)), 1.0f))));
+  store_from_f32<T>(out, idx, __fdiv_rn(load_as_f32<T>(lat, (long)src * elems + e), denom));
+}
+
+// CFG combine + epsilon Euler step, fp32 math (pipeline_..._esymred.py:382-385; scheduling_euler_discrete.py:210-268)
+template <typename T>
+__global__ void cfg_euler_step_kernel(const T* __restrict__ noise, T* __restrict__ lat, const float* __restrict__ sigma,
+                                      const float* __restrict__ sigma_next, float g, int n_lat, long elems) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_lat * elems) return;
+  const int row = (int)(idx / elems);
+  float eps;
+  if (g > 0.f) {
+    const float u = load_as_f32<T>(noise, idx);
+    const float t = load_as_f32<T>(noise, (long)n_lat * elems + idx);
+    // the combine runs in the model dtype (pipeline_..._esymred.py:383-385): one rounding per op
+    eps = rnd<T>(__fadd_rn(u, rnd<T>(__fmul_rn(g, rnd<T>(__fsub_rn(t, u))))));
+  } else {
+    eps = load_as_f32<T>(noise, idx);
+  }
+  const float x = load_as_f32<T>(lat, idx);
+  const float s = sigma[row], sn = sigma_next[row];
+  // separate IEEE ops (no fma contraction) so the fp32 chain matches torch's op-by-op evaluation
+  const float pred_x0 = __fsub_rn(x, __fmul_rn(s, eps));
+  const float d = __fdiv_rn(__fsub_rn(x, pred_x0), s);
+  store_from_f32<T>(lat, idx, __fadd_rn(x, __fmul_rn(d, __fsub_rn(sn, s))));
+}
+
+}  // namespace mx
+
+using namespace mx;
+
+// ---- internal launchers used by the step plan (C++ linkage inside the library) ----
+namespace mx {
+int launch_prep_latent(hipStream_t s, const void* in, int dtype, void* out, int B, int Cin, int HW, int CP) {
+  MX_CHECK(CP % 8 == 0 && Cin <= CP, "prep_latent: bad channel padding");
+  const long total = (long)B * HW * (CP / 8);
+  dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+  if (dtype == MX_F32) hipLaunchKernelGGL((prep_latent_kernel<float>), grid, block, 0, s, (const float*)in, (bf16_t*)out, B, Cin, HW, CP);
+  else if (dtype == MX_F16) hipLaunchKernelGGL((prep_latent_kernel<_Float16>), grid, block, 0, s, (const _Float16*)in, (bf16_t*)out, B, Cin, HW, CP);
+  else if (dtype == MX_BF16) hipLaunchKernelGGL((prep_latent_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)in, (bf16_t*)out, B, Cin, HW, CP);
+  else MX_CHECK(false, "prep_latent: bad dtype");
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_nhwc_to_nchw(hipStream_t s, const void* in, void* out, int dtype, int B, int C, int HW, int ld) {
+  const long total = (long)B * C * HW;
+  dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+  if (dtype == MX_F32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), grid, block, 0, s, (const bf16_t*)in, (float*)out, B, C, HW, ld);
+  else if (dtype == MX_F16) hipLaunchKernelGGL((nhwc_to_nchw_kernel<_Float16>), grid, block, 0, s, (const bf16_t*)in, (_Float16*)out, B, C, HW, ld);
+  else if (dtype == MX_BF16) hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)in, (bf16_t*)out, B, C, HW, ld);
+  else MX_CHECK(false, "nhwc_to_nchw: bad dtype");
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_time_embed(hipStream_t s, const float* timesteps, const void* text_embeds, const float* time_ids,
+                      void* tsin, void* addin, int B, int d0, int text_dim, int da) {
+  const int w = (d0 > text_dim + 6 * da) ? d0 : text_dim + 6 * da;
+  dim3 grid(cdiv(w, 256), B), block(256);
+  hipLaunchKernelGGL(time_embed_kernel, grid, block, 0, s, timesteps, (const bf16_t*)text_embeds, time_ids,
+                     (bf16_t*)tsin, (bf16_t*)addin, B, d0, text_dim, da);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_concat(hipStream_t s, const void* a, const void* b, void* out, long M, int C1, int C2) {
+  MX_CHECK(C1 % 8 == 0 && C2 % 8 == 0, "concat: channels must be multiples of 8");
+  const long total = M * ((C1 + C2) / 8);
+  dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+  hipLaunchKernelGGL(concat_channels_kernel, grid, block, 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, M, C1, C2);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mx
+
+extern "C" int mx_euler_scale_input(void* stream, const void* latents, void* out, const float* sigma,
+                                    int n_lat, int n_rows, int64_t elems, int dtype) {
+  MX_CHECK(latents && out && sigma && n_lat > 0 && n_rows >= n_lat && elems > 0, "euler_scale_input: bad arguments");
+  const long total = (long)n_rows * elems;
+  dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MX_F32) hipLaunchKernelGGL((euler_scale_input_kernel<float>), grid, block, 0, s, (const float*)latents, (float*)out, sigma, n_lat, n_rows, (long)elems);
+  else if (dtype == MX_F16) hipLaunchKernelGGL((euler_scale_input_kernel<_Float16>), grid, block, 0, s, (const _Float16*)latents, (_Float16*)out, sigma, n_lat, n_rows, (long)elems);
+  else if (dtype == MX_BF16) hipLaunchKernelGGL((euler_scale_input_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)latents, (bf16_t*)out, sigma, n_lat, n_rows, (long)elems);
+  else MX_CHECK(false, "euler_scale_input: bad dtype");
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mx_cfg_euler_step(void* stream, const void* noise, void* latents, const float* sigma,
+                                 const float* sigma_next, float guidance_scale, int n_lat, int64_t elems, int dtype) {
+  MX_CHECK(noise && latents && sigma && sigma_next && n_lat > 0 && elems > 0, "cfg_euler_step: bad arguments");
+  const long total = (long)n_lat * elems;
+  dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MX_F32) hipLaunchKernelGGL((cfg_euler_step_kernel<float>), grid, block, 0, s, (const float*)noise, (float*)latents, sigma, sigma_next, guidance_scale, n_lat, (long)elems);
+  else if (dtype == MX_F16) hipLaunchKernelGGL((cfg_euler_step_kernel<_Float16>), grid, block, 0, s, (const _Float16*)noise, (_Float16*)latents, sigma, sigma_next, guidance_scale, n_lat, (long)elems);
+  else if (dtype == MX_BF16) hipLaunchKernelGGL((cfg_euler_step_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)noise, (bf16_t*)latents, sigma, sigma_next, guidance_scale, n_lat, (long)elems);
+  else MX_CHECK(false, "cfg_euler_step: bad dtype");
+  MX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,340 @@
+// bf16 MFMA GEMM and implicit-GEMM 3x3 convolution for gfx950 (MI355X, CDNA4).
+//
+//   C[M, N] = X[M, K] * W[N, K]^T  (+ bias, + per-sample row bias, + residual, SiLU | GEGLU | QKV split)
+//
+// Orientation: the WEIGHT tile is the MFMA "A" operand and the ACTIVATION tile the "B" operand, so
+// the accumulator of v_mfma_f32_16x16x32_bf16 (col = lane&15, row = 4*(lane>>4)+reg) holds, per lane,
+// four CONSECUTIVE output features n of ONE token m: the epilogue stores 8 bytes per lane row-major
+// and fuses bias / residual / activation without a transpose; the transposed V^T store that the
+// attention kernel wants is the lane-contiguous direction (MI355X-first choice: no LDS round trip).
+//
+// Tile: 128 tokens x BN features (BN = 128 or 64) x BK = 64, 256 threads = 4 waves as 2(m) x 2(n);
+// LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by ((row>>1)&7), which makes the
+// ds_read_b128 fragment reads of the 16x16x32 operand conflict-free (cdna guide T2, lane groups of
+// ds_read_b128).  Register-prefetch double buffering, one barrier per K tile.
+//
+// Implicit GEMM conv (CONV=true): K = 9*Cin ordered tap-major, activations NHWC; the loader turns an
+// output pixel + tap into a source pixel (stride 1/2, fused nearest x2 upsample, zero padding, and the
+// reference's sliced-mode halo-corner rule -- see mxdenoise.h) and reads 16 B of channels from it.
+//
+// Reference call sites this serves: F.linear / F.conv2d issued by sduss/model_executor/modules/
+// resnet.py:106,132,163 and attention.py:73-96,148-151,220 (through un-vendored diffusers/torch).
+#include "common.h"
+#include "../../include/mxdenoise.h"
+
+namespace mx {
+
+struct GemmArgs {
+  const bf16_t* a;
+  const bf16_t* w;
+  void* c;
+  const float* bias;
+  const float* rowbias;
+  const bf16_t* residual;
+  bf16_t* vt;
+  int M, N, K;
+  int lda, ldc, ldr, ldrb;
+  int rows_per_batch;
+  int flags;
+  int seg, period, ldvt;
+  int B, Hin, Win, Cin, Hout, Wout, stride, up, corner_patch;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <int BN, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+  constexpr int NI = BN / 32;  // 16-wide feature blocks per wave (wave covers BN/2 features)
+  constexpr int MI = 4;        // 16-wide token blocks per wave (wave covers 64 tokens)
+  constexpr int WROWS = BN / 32;  // W rows staged per thread
+  __shared__ __attribute__((aligned(16))) bf16_t sX[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16_t sW[2][BN * BK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1;  // token half
+  const int wn = wave & 1;   // feature half
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int nk = p.K / BK;
+
+  // ---- staging assignment: thread -> (row = (tid>>3) + 32*i, chunk = tid&7) ----
+  const int srow = tid >> 3;
+  const int sch = tid & 7;
+
+  // activation row descriptors
+  int xoff[4];           // GEMM: element offset of the row start (or -1 when the row is out of range)
+  int cb[4], cy[4], cx[4];  // CONV: batch, centre y/x in virtual-input coordinates (cb = -1: invalid row)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + srow + 32 * i;
+    if constexpr (!CONV) {
+      xoff[i] = (m < p.M) ? m * p.lda + sch * 8 : -1;
+    } else {
+      if (m < p.M) {
+        const int hw = p.Hout * p.Wout;
+        const int b = m / hw;
+        const int r = m - b * hw;
+        const int oy = r / p.Wout;
+        cb[i] = b;
+        cy[i] = oy * p.stride;
+        cx[i] = (r - oy * p.Wout) * p.stride;
+      } else {
+        cb[i] = -1; cy[i] = 0; cx[i] = 0;
+      }
+    }
+  }
+  int woff[WROWS];
+#pragma unroll
+  for (int i = 0; i < WROWS; ++i) {
+    const int n = n0 + srow + 32 * i;
+    woff[i] = (n < p.N) ? n * p.K + sch * 8 : -1;
+  }
+
+  u32x4 rx[4], rw[WROWS];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    if constexpr (!CONV) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rx[i] = (xoff[i] >= 0) ? *reinterpret_cast<const u32x4*>(p.a + xoff[i] + k0) : zero4;
+    } else {
+      const int tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      const int dy = tap / 3 - 1;
+      const int dx = tap - (tap / 3) * 3 - 1;
+      const int Hv = p.Hin << p.up, Wv = p.Win << p.up;
+      const int P = p.corner_patch;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int iy = cy[i] + dy;
+        const int ix = cx[i] + dx;
+        if (P > 0 && dy != 0 && dx != 0) {
+          // halo-corner rule of the reference's sliced path (norm_silu_concat.cu:210-221, 228-239)
+          const bool cross_r = ((iy + P) / P) != ((cy[i] + P) / P);
+          const bool cross_c = ((ix + P) / P) != ((cx[i] + P) / P);
+          if (cross_r && cross_c) iy = cy[i];
+        }
+        const bool ok = (cb[i] >= 0) && (iy >= 0) && (iy < Hv) && (ix >= 0) && (ix < Wv);
+        if (ok) {
+          const long src = (((long)cb[i] * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up)) * p.Cin + c0 + sch * 8;
+          rx[i] = *reinterpret_cast<const u32x4*>(p.a + src);
+        } else {
+          rx[i] = zero4;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i)
+      rw[i] = (woff[i] >= 0) ? *reinterpret_cast<const u32x4*>(p.w + woff[i] + k0) : zero4;
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 32 * i;
+      *reinterpret_cast<u32x4*>(&sX[buf][row * BK + swz(row, sch) * 8]) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
+      const int row = srow + 32 * i;
+      *reinterpret_cast<u32x4*>(&sW[buf][row * BK + swz(row, sch) * 8]) = rw[i];
+    }
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;  // row inside a 16-row fragment
+  const int fq = lane >> 4;  // 16-byte chunk inside the 32-deep k-step
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wf[NI], xf[MI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = wn * (BN / 2) + i * 16 + fr;
+        wf[i] = *reinterpret_cast<const bf16x8*>(&sW[buf][row * BK + swz(row, ks * 4 + fq) * 8]);
+      }
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int row = wm * 64 + j * 16 + fr;
+        xf[j] = *reinterpret_cast<const bf16x8*>(&sX[buf][row * BK + swz(row, ks * 4 + fq) * 8]);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------- epilogue -------------------------------
+  const int flags = p.flags;
+  const int wave_n0 = n0 + wn * (BN / 2);
+  const bool geglu = (flags & MX_EPI_GEGLU) != 0;
+  const bool qkv = (flags & MX_EPI_QKV) != 0;
+  // QKV: the wave's feature range lies inside one segment (seg % 64 == 0)
+  int seg_idx = 0, seg_grp = 0, seg_pos = 0;
+  bool to_vt = false;
+  if (qkv) {
+    seg_idx = wave_n0 / p.seg;
+    seg_grp = seg_idx / p.period;
+    seg_pos = seg_idx - seg_grp * p.period;
+    to_vt = (seg_pos == p.period - 1);
+  }
+
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + fr;
+    if (m >= p.M) continue;
+    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
+#pragma unroll
+    for (int i = 0; i < (NI); ++i) {
+      if (geglu && i >= NI / 2) continue;
+      const int n = wave_n0 + i * 16 + fq * 4;  // packed feature index of v[0]
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q];
+      if (p.bias) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += b4[q];
+      }
+      if (geglu) {
+        float g[4];
+        const int ng = n + (BN / 4);  // gate block = +32 packed rows (NI/2 blocks of 16)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = acc[i + NI / 2][j][q];
+        if (p.bias) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + ng);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) g[q] += b4[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * gelu_f(g[q]);
+        const int nout = wave_n0 / 2 + i * 16 + fq * 4;
+        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + nout) = o;
+        continue;
+      }
+      if (p.rowbias) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ldrb + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += b4[q];
+      }
+      if (p.residual) {
+        const u32x2 r = *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
+        v[0] += bf16lo_to_f32(r[0]); v[1] += bf16hi_to_f32(r[0]);
+        v[2] += bf16lo_to_f32(r[1]); v[3] += bf16hi_to_f32(r[1]);
+      }
+      if (flags & MX_EPI_SILU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
+      }
+      if (qkv) {
+        const int nin = n - seg_idx * p.seg;  // position inside the segment
+        if (to_vt) {
+          const int key = m - bidx * p.rows_per_batch;
+          const int nv = p.N / p.period;
+          bf16_t* dst = p.vt + ((long)bidx * nv + (long)seg_grp * p.seg + nin) * p.ldvt + key;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[(long)q * p.ldvt] = f32_to_bf16(v[q]);
+        } else {
+          const int ccol = seg_grp * (p.period - 1) * p.seg + seg_pos * p.seg + nin;
+          u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + ccol) = o;
+        }
+        continue;
+      }
+      if (flags & MX_EPI_OUT_F32) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + (long)m * p.ldc + n) = o;
+      } else {
+        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
+  MX_CHECK(d != nullptr, "gemm: null descriptor");
+  MX_CHECK(d->a && d->w && (d->c || (d->flags & MX_EPI_QKV)), "gemm: null operand");
+  MX_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem");
+  MX_CHECK(d->K % BK == 0, "gemm: K must be a multiple of 64");
+  MX_CHECK(d->N % 4 == 0, "gemm: N must be a multiple of 4");
+  GemmArgs a;
+  a.a = (const bf16_t*)d->a; a.w = (const bf16_t*)d->w; a.c = d->c;
+  a.bias = d->bias; a.rowbias = d->rowbias; a.residual = (const bf16_t*)d->residual; a.vt = (bf16_t*)d->vt;
+  a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldrb = d->ldrb;
+  a.rows_per_batch = d->rows_per_batch; a.flags = d->flags; a.seg = d->seg; a.period = d->period; a.ldvt = d->ldvt;
+  a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout;
+  a.stride = d->stride; a.up = d->up; a.corner_patch = d->corner_patch;
+  if (!conv) {
+    MX_CHECK(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda must be >= K and a multiple of 8");
+  } else {
+    MX_CHECK(d->Cin % BK == 0 && d->K == 9 * d->Cin, "conv3x3: Cin must be a multiple of 64 and K = 9*Cin");
+    MX_CHECK(d->stride == 1 || d->stride == 2, "conv3x3: stride must be 1 or 2");
+    MX_CHECK(d->up == 0 || d->up == 1, "conv3x3: up must be 0 or 1");
+    MX_CHECK(!(d->up && d->stride != 1), "conv3x3: upsample only with stride 1");
+    const int Hv = d->Hin << d->up, Wv = d->Win << d->up;
+    MX_CHECK(d->Hout == (Hv + d->stride - 1) / d->stride && d->Wout == (Wv + d->stride - 1) / d->stride,
+             "conv3x3: output grid does not match input grid / stride");
+    MX_CHECK((long)d->B * d->Hout * d->Wout == d->M, "conv3x3: M != B*Hout*Wout");
+  }
+  if (d->rowbias || (d->flags & MX_EPI_QKV)) MX_CHECK(d->rows_per_batch > 0, "gemm: rows_per_batch required");
+  if (d->rowbias) MX_CHECK(d->ldrb >= d->N && d->ldrb % 4 == 0, "gemm: bad ldrb");
+  MX_CHECK((long)d->M * (conv ? 1 : d->lda) < 2147483647L && (long)d->N * d->K < 2147483647L, "gemm: operand exceeds 32-bit indexing");
+  if (d->residual) MX_CHECK(d->ldr >= d->N && d->ldr % 4 == 0, "gemm: bad ldr");
+  const bool use128 = (d->N % 128 == 0);
+  if (d->flags & MX_EPI_GEGLU) {
+    MX_CHECK(use128, "gemm: GEGLU needs N % 128 == 0");
+    MX_CHECK(!(d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32)) && !d->residual && !d->rowbias, "gemm: GEGLU excludes other epilogues");
+    MX_CHECK(d->ldc >= d->N / 2 && d->ldc % 4 == 0, "gemm: bad ldc for GEGLU");
+  } else if (d->flags & MX_EPI_QKV) {
+    MX_CHECK(d->seg > 0 && d->seg % 64 == 0 && d->period >= 2 && d->N % (d->seg * d->period) == 0, "gemm: bad QKV segments");
+    MX_CHECK(d->vt != nullptr && d->ldvt >= d->rows_per_batch, "gemm: QKV needs vt and ldvt >= rows_per_batch");
+    MX_CHECK(d->M % d->rows_per_batch == 0, "gemm: QKV needs M % rows_per_batch == 0");
+    MX_CHECK(d->ldc >= d->N / d->period * (d->period - 1) && d->ldc % 4 == 0, "gemm: bad ldc for QKV");
+    MX_CHECK(!(d->flags & MX_EPI_OUT_F32), "gemm: QKV output is bf16");
+  } else {
+    MX_CHECK(d->ldc >= d->N && d->ldc % 4 == 0, "gemm: bad ldc");
+  }
+  dim3 block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (use128) {
+    dim3 grid(cdiv(d->M, BM), d->N / 128);
+    if (conv) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<128, false>), grid, block, 0, s, a);
+  } else {
+    dim3 grid(cdiv(d->M, BM), cdiv(d->N, 64));
+    if (conv) hipLaunchKernelGGL((gemm_kernel<64, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<64, false>), grid, block, 0, s, a);
+  }
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mx
+
+extern "C" int mx_gemm(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, false); }
+extern "C" int mx_conv3x3(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, true); }

@@ -1,0 +1,303 @@
+// NHWC GroupNorm (+SiLU) and LayerNorm for gfx950.  HBM-bound kernels: 16-byte vector accesses,
+// fp32 statistics, one read for the moments and one read + one write for the apply pass.
+//
+// GroupNorm serves the reference's PatchGroupNorm.forward (sduss/model_executor/modules/groupnorm.py:42-61):
+//   patch == 0  -> nn.GroupNorm (is_sliced False, groupnorm.py:52)
+//   patch  > 0  -> the sliced statistics of esymred_mp.groupnorm: per-(patch, group) mean and biased
+//                  variance (norm_silu_concat.cu:41-81), merged over the patches of a latent as mean of
+//                  means / mean of variances (cu:361-386), then y = x*(rstd*gamma) + (beta - rstd*gamma*mean)
+//                  (cu:157-163).  The halo the reference materialises is not needed here: the implicit-GEMM
+//                  conv reads neighbours from the whole NHWC image (see gemm_bf16.hip).
+// SiLU (resnet.py:402,446; unet.py:514) is fused into the apply pass.
+//
+// Pass 1  gn_stats_kernel : per (image, spatial tile, channel) sum / sum-of-squares partials (fp32)
+// Pass 2  gn_fold_kernel  : fp64 fold of the partials -> per (image, channel) scale/shift
+// Pass 3  gn_apply_kernel : y = silu?(x*scale + shift)
+#include "common.h"
+#include "../../include/mxdenoise.h"
+
+namespace mx {
+
+// thread -> (channel vector cv = t % tpr, pixel lane pl = t / tpr); tpr = C/8 threads cover one pixel.
+struct GnGeom {
+  int B, H, W, C;
+  int tpr;      // C / 8
+  int L;        // pixel lanes per block
+  int th, tw;   // spatial tile
+  int tiles_y, tiles_x;
+};
+
+__global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, GnGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [L][C][2]
+  const int t = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int b = blockIdx.y;
+  const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+  const int cv = t % g.tpr;
+  const int pl = t / g.tpr;
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  if (pl < g.L) {
+    const int npix = g.th * g.tw;
+    for (int pi = pl; pi < npix; pi += g.L) {
+      const int py = pi / g.tw, px = pi - py * g.tw;
+      const long off = (((long)b * g.H + ty * g.th + py) * g.W + tx * g.tw + px) * g.C + cv * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bf16lo_to_f32(v[e]), hi = bf16hi_to_f32(v[e]);
+        s[2 * e] += lo; ss[2 * e] += lo * lo;
+        s[2 * e + 1] += hi; ss[2 * e + 1] += hi * hi;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[((long)pl * g.C + cv * 8 + e) * 2] = s[e];
+      red[((long)pl * g.C + cv * 8 + e) * 2 + 1] = ss[e];
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < g.C; c += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int l = 0; l < g.L; ++l) { a += red[((long)l * g.C + c) * 2]; q += red[((long)l * g.C + c) * 2 + 1]; }
+    float* dst = part + (((long)b * (g.tiles_y * g.tiles_x) + tile) * g.C + c) * 2;
+    dst[0] = a; dst[1] = q;
+  }
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per (group, image): fp64 fold of tiles x channels-per-group, patch by patch.
+__global__ __launch_bounds__(64) void gn_fold_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ coef,
+                                                     GnGeom g, int groups, float eps, int patch) {
+  const int grp = blockIdx.x;
+  const int b = blockIdx.y;
+  const int cpg = g.C / groups;
+  const int ntiles = g.tiles_y * g.tiles_x;
+  const int lane = threadIdx.x;
+  // patches: (patch x patch) regions; tiles never straddle a patch (host guarantees th | patch, tw == patch)
+  const int ppy = patch > 0 ? g.H / patch : 1;
+  const int ppx = patch > 0 ? g.W / patch : 1;
+  const int npatch = ppy * ppx;
+  const int tpy = g.tiles_y / ppy, tpx = g.tiles_x / ppx;  // tiles per patch
+  const int nitems = tpy * tpx * cpg;
+  const double cnt = (double)tpy * tpx * g.th * g.tw * cpg;
+  double acc_mean = 0.0, acc_var = 0.0;
+  for (int pidx = 0; pidx < npatch; ++pidx) {
+    const int py = pidx / ppx, px = pidx - py * ppx;
+    double s = 0.0, q = 0.0;
+    for (int it = lane; it < nitems; it += 64) {
+      const int tl = it / cpg, c = it - tl * cpg;
+      const int iy = tl / tpx, ix = tl - iy * tpx;
+      const int tile = (py * tpy + iy) * g.tiles_x + px * tpx + ix;
+      const float* src = part + (((long)b * ntiles + tile) * g.C + grp * cpg + c) * 2;
+      s += (double)src[0];
+      q += (double)src[1];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    acc_mean += mean;   // mean of patch means      (norm_silu_concat.cu:383)
+    acc_var += var;     // mean of patch variances  (norm_silu_concat.cu:384)
+  }
+  const double mean = acc_mean / npatch;
+  const double rstd = 1.0 / sqrt(acc_var / npatch + (double)eps);
+  for (int c = lane; c < cpg; c += 64) {
+    const int ch = grp * cpg + c;
+    const float sc = (float)(rstd * (double)gamma[ch]);
+    const float sf = (float)((double)beta[ch] - rstd * (double)gamma[ch] * mean);
+    coef[((long)b * g.C + ch) * 2] = sc;
+    coef[((long)b * g.C + ch) * 2 + 1] = sf;
+  }
+}
+
+template <bool SILU>
+__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                const float* __restrict__ coef, GnGeom g, int pix_per_block) {
+  const int t = threadIdx.x;
+  const int b = blockIdx.y;
+  const int cv = t % g.tpr;
+  const int pl = t / g.tpr;
+  if (pl >= g.L) return;
+  float sc[8], sf[8];
+  const float* cf = coef + ((long)b * g.C + cv * 8) * 2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = cf[2 * e]; sf[e] = cf[2 * e + 1]; }
+  const int hw = g.H * g.W;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, hw);
+  for (int pi = p0 + pl; pi < p1; pi += g.L) {
+    const long off = ((long)b * hw + pi) * g.C + cv * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lo = bf16lo_to_f32(v[e]) * sc[2 * e] + sf[2 * e];
+      float hi = bf16hi_to_f32(v[e]) * sc[2 * e + 1] + sf[2 * e + 1];
+      if (SILU) { lo = silu_f(lo); hi = silu_f(hi); }
+      o[e] = pack_bf16x2(lo, hi);
+    }
+    *reinterpret_cast<u32x4*>(y + off) = o;
+  }
+}
+
+static int gn_geom(GnGeom& g, int B, int H, int W, int C, int patch) {
+  MX_CHECK(C % 8 == 0 && C / 8 <= 1024, "groupnorm: C must be a multiple of 8 and <= 8192");
+  g.B = B; g.H = H; g.W = W; g.C = C;
+  g.tpr = C / 8;
+  g.L = 1024 / g.tpr;
+  if (g.L > 32) g.L = 32;
+  // spatial tile: full rows of the image (or of the patch), about 256 pixels
+  int tw = (patch > 0) ? patch : W;
+  int th = 256 / tw; if (th < 1) th = 1;
+  const int hlim = (patch > 0) ? patch : H;
+  while (hlim % th != 0) --th;
+  g.th = th; g.tw = tw;
+  if (patch > 0) MX_CHECK(H % patch == 0 && W % patch == 0, "groupnorm: H, W must be multiples of patch");
+  g.tiles_y = H / th; g.tiles_x = W / tw;
+  return 0;
+}
+
+}  // namespace mx
+
+namespace mx {
+size_t gn_workspace_exact(int B, int H, int W, int C, int patch) {
+  GnGeom g;
+  if (patch >= H && patch >= W) patch = 0;
+  if (gn_geom(g, B, H, W, C, patch)) return 0;
+  return ((size_t)B * g.tiles_y * g.tiles_x * C * 2 + (size_t)B * C * 2) * sizeof(float);
+}
+}  // namespace mx
+
+extern "C" size_t mx_groupnorm_nhwc_workspace_bytes(int B, int H, int W, int C) {
+  // loose bound valid for every patch >= 2: the smallest spatial tile then holds >= 4 pixels
+  const size_t tiles = (size_t)H * W / 4 + 1;
+  return ((size_t)B * tiles * C * 2 + (size_t)B * C * 2) * sizeof(float) + 256;
+}
+
+extern "C" int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const float* gamma, const float* beta,
+                                 int B, int H, int W, int C, int groups, float eps, int silu, int patch,
+                                 void* workspace) {
+  using namespace mx;
+  MX_CHECK(x && y && gamma && beta && workspace, "groupnorm: null operand");
+  MX_CHECK(groups > 0 && C % groups == 0, "groupnorm: C % groups != 0");
+  if (patch >= H && patch >= W) patch = 0;  // one patch per image == exact GroupNorm
+  MX_CHECK(patch == 0 || patch >= 2, "groupnorm: patch must be 0 or >= 2");
+  GnGeom g;
+  if (gn_geom(g, B, H, W, C, patch)) return 1;
+  const int ntiles = g.tiles_y * g.tiles_x;
+  float* part = (float*)workspace;
+  float* coef = part + (size_t)B * ntiles * C * 2;
+  MX_CHECK(((size_t)B * ntiles * C * 2 + (size_t)B * C * 2) * sizeof(float) <= mx_groupnorm_nhwc_workspace_bytes(B, H, W, C),
+           "groupnorm: internal workspace bound exceeded");
+  hipStream_t s = (hipStream_t)stream;
+  const int threads = ((g.tpr * g.L + 63) / 64) * 64;
+  const size_t smem = (size_t)g.L * C * 2 * sizeof(float);
+  MX_CHECK(smem <= 160 * 1024, "groupnorm: LDS budget exceeded");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ntiles, B), dim3(threads), smem, s, (const bf16_t*)x, part, g);
+  MX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(groups, B), dim3(64), 0, s, (const float*)part, gamma, beta, coef, g,
+                     groups, eps, patch);
+  MX_LAUNCH_CHECK();
+  const int hw = H * W;
+  int ppb = g.L * 8;  // pixels per block
+  if (ppb > hw) ppb = hw;
+  dim3 grid(cdiv(hw, ppb), B);
+  if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb);
+  else hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wave per row, values held in registers between the passes.
+// Serves BasicTransformerBlock.norm1/2/3 (modules/transformer.py:191,239,266).
+// ------------------------------------------------------------------------------------------
+namespace mx {
+
+template <int VPL>  // 16-byte chunks per lane (C <= 64*8*VPL)
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C / 8;
+  const bf16_t* xr = x + (long)row * C;
+  float v[VPL][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const u32x4 u = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][2 * e] = bf16lo_to_f32(u[e]);
+        v[i][2 * e + 1] = bf16hi_to_f32(u[e]);
+        sum += v[i][2 * e] + v[i][2 * e + 1];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  bf16_t* yr = y + (long)row * C;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+        o[e + 4] = (v[i][e + 4] - mean) * rstd * g1[e] + b1[e];
+      }
+      u32x4 u = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+      *reinterpret_cast<u32x4*>(yr + ch * 8) = u;
+    }
+  }
+}
+
+}  // namespace mx
+
+extern "C" int mx_layernorm(void* stream, const void* x, void* y, const float* gamma, const float* beta,
+                            int M, int C, float eps) {
+  using namespace mx;
+  MX_CHECK(x && y && gamma && beta, "layernorm: null operand");
+  MX_CHECK(C % 8 == 0 && C <= 64 * 8 * 8, "layernorm: C must be a multiple of 8 and <= 4096");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(M, 4)), block(256);
+  const int vpl = cdiv(C / 8, 64);
+  const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y;
+  if (vpl <= 1) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, xp, yp, gamma, beta, M, C, eps);
+  else if (vpl <= 2) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, s, xp, yp, gamma, beta, M, C, eps);
+  else if (vpl <= 3) hipLaunchKernelGGL((layernorm_kernel<3>), grid, block, 0, s, xp, yp, gamma, beta, M, C, eps);
+  else if (vpl <= 4) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, xp, yp, gamma, beta, M, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, xp, yp, gamma, beta, M, C, eps);
+  MX_LAUNCH_CHECK();
+  return 0;
+}

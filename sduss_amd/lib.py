@@ -1,0 +1,116 @@
+"""ctypes binding of libmxdenoise.so (the C ABI declared in include/mxdenoise.h).
+
+The product path has no fallback: if the HIP library is missing, or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmxdenoise.so")
+
+MX_F32, MX_F16, MX_BF16 = 0, 1, 2
+EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV = 1, 2, 4, 8
+
+
+class MxError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (the reference's launcher only printed
+    cudaGetLastError and went on -- norm_silu_concat.cu:434-437; SURVEY.md section 8b asks to raise)."""
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("w", C.c_void_p), ("c", C.c_void_p), ("bias", C.c_void_p), ("rowbias", C.c_void_p),
+        ("residual", C.c_void_p), ("vt", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int), ("ldrb", C.c_int),
+        ("rows_per_batch", C.c_int), ("flags", C.c_int),
+        ("seg", C.c_int), ("period", C.c_int), ("ldvt", C.c_int),
+        ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
+        ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("corner_patch", C.c_int),
+    ]
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int), ("n_levels", C.c_int),
+        ("block_out_channels", C.c_int * 4), ("layers_per_block", C.c_int),
+        ("down_has_attn", C.c_int * 4), ("transformer_layers", C.c_int * 4), ("num_heads", C.c_int * 4),
+        ("cross_attention_dim", C.c_int), ("addition_time_embed_dim", C.c_int),
+        ("projection_class_embeddings_input_dim", C.c_int), ("norm_num_groups", C.c_int),
+        ("norm_eps", C.c_float), ("transformer_norm_eps", C.c_float), ("layer_norm_eps", C.c_float),
+    ]
+
+
+class WeightEntry(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+# every symbol include/mxdenoise.h declares: (name, restype, argtypes)
+_vp, _i, _f, _d, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64, C.c_size_t
+SYMBOLS = {
+    "mx_last_error": (C.c_char_p, []),
+    "mx_version": (_i, []),
+    "mx_groupnorm_halo_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mx_groupnorm_halo": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "mx_halo_only": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i]),
+    "mx_gemm": (_i, [_vp, C.POINTER(GemmDesc)]),
+    "mx_conv3x3": (_i, [_vp, C.POINTER(GemmDesc)]),
+    "mx_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _f]),
+    "mx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
+    "mx_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mx_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "mx_unet_create": (_vp, [C.POINTER(UNetConfigC)]),
+    "mx_unet_destroy": (None, [_vp]),
+    "mx_unet_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),
+    "mx_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "mx_unet_validate": (_i, [_vp, _i, _i, _i, _i]),
+    "mx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
+    "mx_unet_forward_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz,
+                                   C.c_char_p, _vp, _sz]),
+    "mx_euler_scale_input": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i]),
+    "mx_cfg_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libmxdenoise.so and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MxError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"(or `make -C sduss_amd/csrc`). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().mx_last_error().decode("utf-8", "replace")
+        raise MxError(f"{what}: {msg}" if what else msg)
+
+
+def torch_dtype_code(dtype) -> int:
+    import torch
+    if dtype == torch.float32:
+        return MX_F32
+    if dtype == torch.float16:
+        return MX_F16
+    if dtype == torch.bfloat16:
+        return MX_BF16
+    raise MxError(f"unsupported dtype {dtype}")
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

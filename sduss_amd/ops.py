@@ -1,0 +1,143 @@
+"""Thin torch-tensor wrappers over the per-kernel entry points of the C ABI (mx_gemm, mx_conv3x3, mx_attention,
+mx_layernorm, mx_groupnorm_nhwc, scheduler steps).  They allocate outputs with torch and pass raw pointers + the current
+stream; nothing is computed in Python.  Used by the parity tests and by ``pipeline.py``."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _bf16(t):
+    assert t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(), "expected a contiguous CUDA bf16 tensor"
+    return t
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, silu: bool = False, geglu: bool = False,
+         out_f32: bool = False) -> torch.Tensor:
+    """C[M,N] = A[M,K] W[N,K]^T (+bias +rowbias +residual, silu | geglu).  With ``geglu`` the weight/bias rows must be
+    interleaved as weights._geglu_interleave does; the output is [M, N/2]."""
+    l = _lib.load()
+    _bf16(a); _bf16(w)
+    m, k = a.shape
+    n = w.shape[0]
+    d = _lib.GemmDesc()
+    flags = (_lib.EPI_SILU if silu else 0) | (_lib.EPI_GEGLU if geglu else 0) | (_lib.EPI_OUT_F32 if out_f32 else 0)
+    nout = n // 2 if geglu else n
+    c = torch.empty((m, nout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    d.a, d.w, d.c = a.data_ptr(), w.data_ptr(), c.data_ptr()
+    d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
+    d.M, d.N, d.K, d.lda, d.ldc = m, n, k, k, nout
+    d.ldr = residual.shape[1] if residual is not None else 0
+    d.ldrb = rowbias.shape[1] if rowbias is not None else 0
+    d.rows_per_batch, d.flags = rows_per_batch, flags
+    _lib.check(l.mx_gemm(_lib.current_stream(), C.byref(d)), "mx_gemm")
+    return c
+
+
+def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_batch: int):
+    """Fused projection with the V segments written transposed.  Returns (c [M, N/period*(period-1)],
+    vt [M/rows_per_batch, N/period, ldvt])."""
+    l = _lib.load()
+    _bf16(a); _bf16(w)
+    m, k = a.shape
+    n = w.shape[0]
+    nb = m // rows_per_batch
+    ldvt = (rows_per_batch + 7) // 8 * 8
+    c = torch.empty((m, n // period * (period - 1)), dtype=torch.bfloat16, device=a.device)
+    vt = torch.zeros((nb, n // period, ldvt), dtype=torch.bfloat16, device=a.device)
+    d = _lib.GemmDesc()
+    d.a, d.w, d.c, d.vt = a.data_ptr(), w.data_ptr(), c.data_ptr(), vt.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldc = m, n, k, k, c.shape[1]
+    d.rows_per_batch, d.flags, d.seg, d.period, d.ldvt = rows_per_batch, _lib.EPI_QKV, seg, period, ldvt
+    _lib.check(l.mx_gemm(_lib.current_stream(), C.byref(d)), "mx_gemm(qkv)")
+    return c, vt
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, up: int = 0,
+            corner_patch: int = 0, rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x NHWC bf16 [B,H,W,Cin]; w bf16 [Cout, 9*Cin] tap-major; returns NHWC bf16 [B,Ho,Wo,Cout]."""
+    l = _lib.load()
+    _bf16(x); _bf16(w)
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    hv, wv = h << up, wd << up
+    ho, wo = (hv + stride - 1) // stride, (wv + stride - 1) // stride
+    c = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+    d = _lib.GemmDesc()
+    d.a, d.w, d.c, d.bias, d.rowbias, d.residual = x.data_ptr(), w.data_ptr(), c.data_ptr(), _p(bias), _p(rowbias), _p(residual)
+    d.M, d.N, d.K, d.ldc, d.ldr = b * ho * wo, cout, 9 * cin, cout, cout
+    d.ldrb = rowbias.shape[1] if rowbias is not None else 0
+    d.rows_per_batch = ho * wo
+    d.B, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.up, d.corner_patch = b, h, wd, cin, ho, wo, stride, up, corner_patch
+    _lib.check(l.mx_conv3x3(_lib.current_stream(), C.byref(d)), "mx_conv3x3")
+    return c
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, lq: int, lk: int) -> torch.Tensor:
+    """q [B*Lq, H*64], k [B*Lk, H*64], vt [B, H*64, ldvt] (all bf16) -> o [B*Lq, H*64]."""
+    l = _lib.load()
+    _bf16(q); _bf16(k); _bf16(vt)
+    b = vt.shape[0]
+    o = torch.empty_like(q)
+    _lib.check(l.mx_attention(_lib.current_stream(), q.data_ptr(), q.shape[1], k.data_ptr(), k.shape[1], vt.data_ptr(),
+                              vt.shape[2], vt.shape[1] * vt.shape[2], o.data_ptr(), o.shape[1], b, heads, lq, lk,
+                              0.125), "mx_attention")
+    return o
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    l = _lib.load()
+    _bf16(x)
+    y = torch.empty_like(x)
+    _lib.check(l.mx_layernorm(_lib.current_stream(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                              x.shape[0], x.shape[1], eps), "mx_layernorm")
+    return y
+
+
+def groupnorm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
+                   patch: int = 0) -> torch.Tensor:
+    l = _lib.load()
+    _bf16(x)
+    b, h, w, c = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty(l.mx_groupnorm_nhwc_workspace_bytes(b, h, w, c), dtype=torch.uint8, device=x.device)
+    _lib.check(l.mx_groupnorm_nhwc(_lib.current_stream(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                   b, h, w, c, groups, eps, int(silu), patch, ws.data_ptr()), "mx_groupnorm_nhwc")
+    return y
+
+
+def euler_scale_input(latents: torch.Tensor, sigma: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """[n_lat, ...] -> [n_rows, ...] = latents[r % n_lat] / sqrt(sigma^2+1)  (CFG duplication fused)."""
+    l = _lib.load()
+    latents = latents.contiguous()
+    n_lat = latents.shape[0]
+    elems = latents[0].numel()
+    out = torch.empty((n_rows, *latents.shape[1:]), dtype=latents.dtype, device=latents.device)
+    sg = sigma.to(device=latents.device, dtype=torch.float32).contiguous()
+    _lib.check(l.mx_euler_scale_input(_lib.current_stream(), latents.data_ptr(), out.data_ptr(), sg.data_ptr(), n_lat, n_rows,
+                                      elems, _lib.torch_dtype_code(latents.dtype)), "mx_euler_scale_input")
+    return out
+
+
+def cfg_euler_step_(noise: torch.Tensor, latents: torch.Tensor, sigma: torch.Tensor, sigma_next: torch.Tensor,
+                    guidance_scale: float) -> torch.Tensor:
+    """In place: latents <- Euler step with eps = u + g (t - u); noise = [uncond rows ; cond rows] (g > 0)
+    or the plain prediction (g <= 0)."""
+    l = _lib.load()
+    assert latents.is_contiguous() and noise.is_contiguous() and noise.dtype == latents.dtype
+    n_lat = latents.shape[0]
+    sg = sigma.to(device=latents.device, dtype=torch.float32).contiguous()
+    sn = sigma_next.to(device=latents.device, dtype=torch.float32).contiguous()
+    _lib.check(l.mx_cfg_euler_step(_lib.current_stream(), noise.data_ptr(), latents.data_ptr(), sg.data_ptr(), sn.data_ptr(),
+                                   float(guidance_scale), n_lat, latents[0].numel(), _lib.torch_dtype_code(latents.dtype)),
+               "mx_cfg_euler_step")
+    return latents

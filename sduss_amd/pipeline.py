@@ -1,0 +1,138 @@
+"""The caller of the model slot: one ``denoising_step`` over a heterogeneous batch of requests, mirroring
+``ESyMReDStableDiffusionXLPipeline.denoising_step``
+(sduss/model_executor/diffusers/pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl_esymred.py:259-403)
+and the batched Euler scheduler either side of it (schedulers/scheduling_euler_discrete.py:161-274).
+
+What stays host-side is bookkeeping (which request is at which step); the arithmetic -- input scaling with the CFG
+duplication, the UNet, the CFG combine and the Euler step -- runs in libmxdenoise.so.  Text encoders and the VAE
+(prepare_inference / post_inference) are out of scope and stay on stock PyTorch.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .unet import MxUNet
+
+
+def euler_tables(num_inference_steps: int, num_train_timesteps: int = 1000, beta_start: float = 0.00085,
+                 beta_end: float = 0.012, steps_offset: int = 1):
+    """diffusers EulerDiscreteScheduler.set_timesteps for the SDXL-base scheduler config (scaled_linear betas,
+    'leading' spacing, steps_offset 1, linear sigma interpolation) -- what ``batch_set_timesteps``
+    (scheduling_euler_discrete.py:72-113) stores per request.  Returns (timesteps f32[n], sigmas f32[n+1], init_noise_sigma)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+    step_ratio = num_train_timesteps // num_inference_steps
+    timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.float32) + steps_offset
+    sig = (((1 - alphas_cumprod) / alphas_cumprod) ** 0.5).numpy()
+    sigmas = np.interp(timesteps, np.arange(0, len(sig)), sig)
+    sigmas = np.concatenate([sigmas, [0.0]]).astype(np.float32)
+    return timesteps, sigmas, float((sigmas.max() ** 2 + 1) ** 0.5)
+
+
+@dataclass
+class Request:
+    """The per-request state the reference keeps on RunnerRequest (worker/runner/wrappers.py:19-36)."""
+    request_id: int
+    resolution: int
+    num_inference_steps: int
+    latents: torch.Tensor                 # [1, 4, res/8, res/8] model dtype, on device
+    prompt_embeds: torch.Tensor           # [1, 77, 2048]
+    negative_prompt_embeds: torch.Tensor  # [1, 77, 2048]
+    pooled_prompt_embeds: torch.Tensor    # [1, 1280]
+    negative_pooled_prompt_embeds: torch.Tensor
+    add_time_ids: torch.Tensor            # [1, 6]
+    negative_add_time_ids: torch.Tensor
+    timesteps: np.ndarray = None
+    sigmas: np.ndarray = None
+    step_index: int = 0
+    arrival: float = 0.0
+    start: Optional[float] = None
+    finish: Optional[float] = None
+
+    def done(self) -> bool:
+        return self.step_index >= self.num_inference_steps
+
+
+class SDXLDenoiser:
+    def __init__(self, unet: MxUNet, guidance_scale: float = 5.0):
+        self.unet = unet
+        self.guidance_scale = guidance_scale   # reference default (pipeline_..._esymred.py:265)
+        self._tables: Dict[int, tuple] = {}
+
+    def set_timesteps(self, req: Request) -> None:
+        if req.num_inference_steps not in self._tables:
+            self._tables[req.num_inference_steps] = euler_tables(req.num_inference_steps)
+        req.timesteps, req.sigmas, _ = self._tables[req.num_inference_steps]
+        req.step_index = 0
+
+    def init_noise_sigma(self, num_inference_steps: int) -> float:
+        if num_inference_steps not in self._tables:
+            self._tables[num_inference_steps] = euler_tables(num_inference_steps)
+        return self._tables[num_inference_steps][2]
+
+    @torch.inference_mode()
+    def denoising_step(self, worker_reqs: Dict[str, List[Request]], do_classifier_free_guidance: bool = True,
+                       is_sliced: bool = False, patch_size: int = 256) -> None:
+        """One timestep for every request in ``worker_reqs`` ({str(res): [requests]}), in place."""
+        res_list = sorted(worker_reqs.keys(), key=lambda r: int(r))         # :275-276
+        dev = self.unet.device
+        for res in res_list:                                                 # one launch sequence per resolution
+            reqs = worker_reqs[res]
+            if not reqs:
+                continue
+            n = len(reqs)
+            lat = torch.cat([r.latents for r in reqs], dim=0).contiguous()   # :287-312
+            sig = torch.tensor([float(r.sigmas[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
+            sig_next = torch.tensor([float(r.sigmas[r.step_index + 1]) for r in reqs], dtype=torch.float32, device=dev)
+            ts = torch.tensor([float(r.timesteps[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
+            if do_classifier_free_guidance:                                  # :322-339 row order [uncond..., cond...]
+                ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+                # add_time_ids are interleaved neg/pos per request in the reference (:302-305)
+                tids = torch.cat([t for r in reqs for t in (r.negative_add_time_ids, r.add_time_ids)], dim=0)
+                ts2 = torch.cat([ts, ts], dim=0)
+                rows = 2 * n
+            else:
+                ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
+                tids = torch.cat([r.add_time_ids for r in reqs], dim=0)
+                ts2 = ts
+                rows = n
+            x_in = ops.euler_scale_input(lat, sig, rows)                     # :357-360 (+ the cat of :327)
+            noise = self.unet.forward({res: x_in}, ts2, ehs, added_cond_kwargs={"text_embeds": pooled, "time_ids": tids},
+                                      return_dict=False, is_sliced=is_sliced, patch_size=patch_size,
+                                      input_indices={res: [str(r.request_id) for r in reqs]})[0][res]   # :369-380
+            g = self.guidance_scale if do_classifier_free_guidance else 0.0
+            ops.cfg_euler_step_(noise, lat, sig, sig_next, g)                # :382-397
+            for i, r in enumerate(reqs):                                     # :399-403
+                r.step_index += 1
+                r.latents = lat[i:i + 1]
+
+
+def synthetic_request(rid: int, resolution: int, steps: int, cfg, denoiser: SDXLDenoiser, device, dtype=torch.bfloat16,
+                      seed: int = 10086, shared: Optional[dict] = None) -> Request:
+    """Fixed-prompt synthetic request: embeddings ~N(0,1) from the reference seed, time ids
+    (res, res, 0, 0, res, res) (pipeline_..._esymred.py:181-187), latents randn * init_noise_sigma."""
+    g = torch.Generator(device="cpu").manual_seed(seed + 17 * rid)
+    if shared is None or "pe" not in shared:
+        ge = torch.Generator(device="cpu").manual_seed(seed)
+        pe = torch.randn(1, 77, cfg.cross_attention_dim, generator=ge).to(device=device, dtype=dtype)
+        ne = torch.randn(1, 77, cfg.cross_attention_dim, generator=ge).to(device=device, dtype=dtype)
+        pp = torch.randn(1, cfg.text_embed_dim, generator=ge).to(device=device, dtype=dtype)
+        npp = torch.randn(1, cfg.text_embed_dim, generator=ge).to(device=device, dtype=dtype)
+        if shared is not None:
+            shared.update(pe=pe, ne=ne, pp=pp, npp=npp)
+    else:
+        pe, ne, pp, npp = shared["pe"], shared["ne"], shared["pp"], shared["npp"]
+    r = float(resolution)
+    tid = torch.tensor([[r, r, 0.0, 0.0, r, r]], device=device, dtype=torch.float32)
+    lat = torch.randn(1, cfg.in_channels, resolution // 8, resolution // 8, generator=g)
+    lat = (lat * denoiser.init_noise_sigma(steps)).to(device=device, dtype=dtype)
+    req = Request(rid, resolution, steps, lat, pe, ne, pp, npp, tid, tid.clone())
+    denoiser.set_timesteps(req)
+    return req

@@ -1,0 +1,157 @@
+"""The model-slot adapter: presents ``PatchUNet.forward``'s signature
+(sduss/model_executor/modules/unet.py:205-225, 521-530) over the MI355X step plan in libmxdenoise.so.
+
+Installed where ``instantiate_pipeline`` puts ``PatchUNet(unet)``
+(pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl_esymred.py:30-41) -- see INTEGRATION.md.
+PyTorch is used for device memory and the current stream only; every FLOP runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import lib as _lib
+from .config import UNetConfig
+from .weights import PackedWeights, pack
+
+
+class _Config(dict):
+    """``.config`` as the pipeline reads it (attribute and item access)."""
+    __getattr__ = dict.__getitem__
+
+
+class MxUNet:
+    """Drop-in for ``PatchUNet``: ``forward(sample_dict, timestep, encoder_hidden_states, ..., added_cond_kwargs,
+    return_dict=False, is_sliced, patch_size, input_indices) -> (dict,)``.
+
+    Row order contract (same as the reference): resolutions in the dict's (ascending) order, the conditioning rows
+    of all resolutions concatenated in that order (pipeline_..._esymred.py:275-276, 327-339).
+    """
+
+    def __init__(self, cfg: UNetConfig, params: Dict[str, torch.Tensor], device="cuda:0"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = torch.bfloat16
+        self._lib = _lib.load()
+        cc = _lib.UNetConfigC()
+        cc.in_channels, cc.out_channels = cfg.in_channels, cfg.out_channels
+        cc.n_levels = len(cfg.block_out_channels)
+        for i, v in enumerate(cfg.block_out_channels):
+            cc.block_out_channels[i] = v
+            cc.down_has_attn[i] = int(cfg.down_has_attn[i])
+            cc.transformer_layers[i] = cfg.transformer_layers_per_block[i]
+            cc.num_heads[i] = cfg.num_heads[i]
+        cc.layers_per_block = cfg.layers_per_block
+        cc.cross_attention_dim = cfg.cross_attention_dim
+        cc.addition_time_embed_dim = cfg.addition_time_embed_dim
+        cc.projection_class_embeddings_input_dim = cfg.projection_class_embeddings_input_dim
+        cc.norm_num_groups = cfg.norm_num_groups
+        cc.norm_eps, cc.transformer_norm_eps, cc.layer_norm_eps = cfg.norm_eps, cfg.transformer_norm_eps, cfg.layer_norm_eps
+        self._handle = self._lib.mx_unet_create(C.byref(cc))
+        if not self._handle:
+            raise _lib.MxError("mx_unet_create: " + self._lib.mx_last_error().decode())
+        self.weights = PackedWeights(pack(cfg, params), self.device)
+        _lib.check(self._lib.mx_unet_set_weights(self._handle, self.weights.blob.data_ptr(), self.weights.blob.numel(),
+                                                 self.weights.table, len(self.weights.names)), "mx_unet_set_weights")
+        self._ws: Optional[torch.Tensor] = None
+        self.config = _Config(in_channels=cfg.in_channels, time_cond_proj_dim=None,
+                              addition_time_embed_dim=cfg.addition_time_embed_dim,
+                              projection_class_embeddings_input_dim=cfg.projection_class_embeddings_input_dim,
+                              sample_size=128, center_input_sample=False)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            self._lib.mx_unet_destroy(h)
+            self._handle = None
+
+    def to(self, *args, **kwargs):
+        return self
+
+    # -------------------------------------------------------------------------------------------------
+    def _workspace(self, batch: int, h: int, w: int, ctx_len: int) -> torch.Tensor:
+        need = self._lib.mx_unet_workspace_bytes(self._handle, batch, h, w, ctx_len)
+        if need == 0:
+            raise _lib.MxError("mx_unet_workspace_bytes: " + self._lib.mx_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward_one(self, sample: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                    text_embeds: torch.Tensor, time_ids: torch.Tensor, gn_patch: int = 0,
+                    stage: Optional[str] = None, stage_shape=None) -> torch.Tensor:
+        """One launch sequence over a batch of same-resolution latents [B, C, H, W] (any of fp32/fp16/bf16)."""
+        assert sample.is_cuda and sample.ndim == 4
+        sample = sample.contiguous()
+        b, _c, h, w = sample.shape
+        ctx_len = encoder_hidden_states.shape[1]
+        ts = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+        if ts.numel() == 1:
+            ts = ts.expand(b)
+        ts = ts.contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        te = text_embeds.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        ti = time_ids.to(device=self.device, dtype=torch.float32).contiguous()
+        assert ts.shape[0] == b and ehs.shape[0] == b and te.shape[0] == b and ti.shape == (b, 6)
+        assert ehs.shape[2] == self.cfg.cross_attention_dim and te.shape[1] == self.cfg.text_embed_dim
+        out = torch.empty((b, self.cfg.out_channels, h, w), dtype=sample.dtype, device=self.device)
+        ws = self._workspace(b, h, w, ctx_len)
+        code = _lib.torch_dtype_code(sample.dtype)
+        stream = _lib.current_stream()
+        if stage is None:
+            _lib.check(self._lib.mx_unet_forward(self._handle, stream, sample.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
+                                                 te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, h, w, ctx_len, gn_patch,
+                                                 ws.data_ptr(), ws.numel()), "mx_unet_forward")
+            return out
+        st = torch.empty(stage_shape, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self._lib.mx_unet_forward_trace(self._handle, stream, sample.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
+                                                   te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, h, w, ctx_len, gn_patch,
+                                                   ws.data_ptr(), ws.numel(), stage.encode(), st.data_ptr(),
+                                                   st.numel() * 2), "mx_unet_forward_trace")
+        return st
+
+    def forward(self, sample: Dict[str, torch.Tensor], timestep, encoder_hidden_states: torch.Tensor,
+                class_labels=None, timestep_cond=None, attention_mask=None, cross_attention_kwargs=None,
+                added_cond_kwargs: Optional[dict] = None, down_block_additional_residuals=None,
+                mid_block_additional_residual=None, down_intrablock_additional_residuals=None,
+                encoder_attention_mask=None, return_dict: bool = True, record: bool = False, patch_size: int = None,
+                is_sliced: bool = False, save_index: int = 0, input_indices: dict = None):
+        # same argument contract as unet.py:229-238
+        assert (class_labels is None and timestep_cond is None and attention_mask is None
+                and cross_attention_kwargs is None and down_block_additional_residuals is None
+                and mid_block_additional_residual is None and down_intrablock_additional_residuals is None
+                and encoder_attention_mask is None)
+        assert added_cond_kwargs is not None, "SDXL needs added_cond_kwargs (text_embeds, time_ids)"
+        text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+        out: Dict[str, torch.Tensor] = {}
+        row = 0
+        keys = [k for k in sample if sample[k] is not None and sample[k].shape[0] > 0]
+        if not is_sliced:
+            keys = keys[:1]  # the reference's unsliced branch runs the first resolution only (unet.py:268-272)
+        for key in keys:
+            x = sample[key]
+            n = x.shape[0]
+            gn_patch = 0
+            if is_sliced:
+                assert patch_size is not None and int(key) % patch_size == 0
+                gn_patch = patch_size // 8
+            sl = slice(row, row + n)
+            ts = timestep if (not torch.is_tensor(timestep) or timestep.ndim == 0) else timestep[sl]
+            if not torch.is_tensor(ts):
+                ts = torch.tensor([float(ts)], device=self.device)
+            out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl], gn_patch)
+            row += n
+        return (out,)
+
+    __call__ = forward
+
+    @property
+    def add_embedding(self):  # unet.py:533-535; the pipeline only reads .linear_1.in_features
+        class _L:  # noqa
+            in_features = self.cfg.projection_class_embeddings_input_dim
+        class _A:  # noqa
+            linear_1 = _L
+        return _A

@@ -1,0 +1,169 @@
+"""Weight loading and packing for the MI355X step plan.
+
+The reference rebuilds every Conv2d/Linear/GroupNorm as fp16 ``Split*`` modules and fuses to_k/to_v into one
+``to_kv`` at load (sduss/model_executor/modules/unet.py:31-100, attention.py:33-49).  Here the HF state dict is
+packed ONCE into a single device blob in the layouts the gfx950 kernels read:
+
+  conv  O,I,3,3        -> bf16 [O, 9*I]  tap-major (k = (ky*3+kx)*I + c)   NHWC implicit GEMM; conv_in's I padded to 64
+  linear [N, K]        -> bf16 [N, K]    as is
+  attn1 to_q/to_k/to_v -> bf16 [3C, C]   one fused QKV GEMM
+  attn2 to_k/to_v      -> bf16 [L*2C, ctx] for ALL L cross-attention layers of one width, [K_l ; V_l] per layer
+  ff.net.0.proj (GEGLU)-> rows interleaved in groups of 32 hidden | 32 gate so that the GEMM epilogue finds the
+                          pair in the same lane (gemm_bf16.hip)
+  time_emb_proj        -> bf16 [sum C_out, T] for all resnets in execution order (one GEMM per step)
+  biases / norm affine -> fp32
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import lib as _lib
+from .config import UNetConfig, param_shapes, resnet_names, transformer_names
+
+_ALIGN = 256
+CONV_IN_PAD = 64
+
+
+def synthetic_params(cfg: UNetConfig, device="cpu", seed: int = 10086) -> Dict[str, torch.Tensor]:
+    """Random-init weights of the architecture (no checkpoint on the box): N(0,1)*fan_in^-1/2 matrices,
+    gains ~1, small biases; seed 10086 = the reference's default (sduss/engine/arg_utils.py:20)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = {}
+    for name, shape in param_shapes(cfg).items():
+        if name.endswith(".weight") and len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=g, device=device) * fan_in ** -0.5
+        elif name.endswith(".weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        else:
+            t = 0.05 * torch.randn(shape, generator=g, device=device)
+        out[name] = t.to(torch.bfloat16)
+    return out
+
+
+def load_safetensors_dir(unet_dir: str) -> Tuple[UNetConfig, Dict[str, torch.Tensor]]:
+    """Reads the HF layout the reference loads from (model_loader.py:64-66): <dir>/config.json +
+    diffusion_pytorch_model*.safetensors."""
+    from safetensors.torch import load_file
+    cfg = UNetConfig.from_hf_json(os.path.join(unet_dir, "config.json"))
+    params: Dict[str, torch.Tensor] = {}
+    files = sorted(f for f in os.listdir(unet_dir) if f.endswith(".safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no .safetensors under {unet_dir}")
+    pick = [f for f in files if "fp16" not in f] or files
+    for f in pick:
+        params.update(load_file(os.path.join(unet_dir, f)))
+    return cfg, params
+
+
+def _conv_pack(w: torch.Tensor, pad_in: int = 0) -> torch.Tensor:
+    o, i, kh, kw = w.shape
+    w = w.permute(0, 2, 3, 1)  # O, kh, kw, I
+    if pad_in and pad_in > i:
+        w = torch.nn.functional.pad(w, (0, pad_in - i))
+    return w.reshape(o, -1).contiguous()
+
+
+def _geglu_interleave(t: torch.Tensor) -> torch.Tensor:
+    """rows [hidden(4C) ; gate(4C)] -> groups of [32 hidden | 32 gate]."""
+    half = t.shape[0] // 2
+    h = t[:half].reshape(half // 32, 32, *t.shape[1:])
+    g = t[half:].reshape(half // 32, 32, *t.shape[1:])
+    return torch.cat([h, g], dim=1).reshape(t.shape).contiguous()
+
+
+def pack(cfg: UNetConfig, P: Dict[str, torch.Tensor]) -> List[Tuple[str, torch.Tensor]]:
+    """HF-named params -> ordered list of (packed name, tensor in its blob dtype)."""
+    missing = [k for k in param_shapes(cfg) if k not in P]
+    if missing:
+        raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+    bf, f32 = torch.bfloat16, torch.float32
+    out: List[Tuple[str, torch.Tensor]] = []
+
+    def mat(name, t):
+        out.append((name, t.to(bf).contiguous()))
+
+    def vec(name, t):
+        out.append((name, t.to(f32).contiguous()))
+
+    mat("conv_in.weight", _conv_pack(P["conv_in.weight"], CONV_IN_PAD))
+    vec("conv_in.bias", P["conv_in.bias"])
+    for nm in ("time_embedding", "add_embedding"):
+        for l in ("linear_1", "linear_2"):
+            mat(f"{nm}.{l}.weight", P[f"{nm}.{l}.weight"])
+            vec(f"{nm}.{l}.bias", P[f"{nm}.{l}.bias"])
+    res = resnet_names(cfg)
+    mat("temb_proj_all.weight", torch.cat([P[f"{p}.time_emb_proj.weight"] for p, _, _ in res], dim=0))
+    vec("temb_proj_all.bias", torch.cat([P[f"{p}.time_emb_proj.bias"] for p, _, _ in res], dim=0))
+    for p, cin, cout in res:
+        vec(f"{p}.norm1.weight", P[f"{p}.norm1.weight"]); vec(f"{p}.norm1.bias", P[f"{p}.norm1.bias"])
+        mat(f"{p}.conv1.weight", _conv_pack(P[f"{p}.conv1.weight"])); vec(f"{p}.conv1.bias", P[f"{p}.conv1.bias"])
+        vec(f"{p}.norm2.weight", P[f"{p}.norm2.weight"]); vec(f"{p}.norm2.bias", P[f"{p}.norm2.bias"])
+        mat(f"{p}.conv2.weight", _conv_pack(P[f"{p}.conv2.weight"])); vec(f"{p}.conv2.bias", P[f"{p}.conv2.bias"])
+        if cin != cout:
+            mat(f"{p}.conv_shortcut.weight", P[f"{p}.conv_shortcut.weight"].reshape(cout, cin))
+            vec(f"{p}.conv_shortcut.bias", P[f"{p}.conv_shortcut.bias"])
+    kv_by_dim: Dict[int, List[torch.Tensor]] = {}
+    for p, dim, _h, layers in transformer_names(cfg):
+        vec(f"{p}.norm.weight", P[f"{p}.norm.weight"]); vec(f"{p}.norm.bias", P[f"{p}.norm.bias"])
+        for l in ("proj_in", "proj_out"):
+            mat(f"{p}.{l}.weight", P[f"{p}.{l}.weight"].reshape(dim, dim)); vec(f"{p}.{l}.bias", P[f"{p}.{l}.bias"])
+        for k in range(layers):
+            b = f"{p}.transformer_blocks.{k}"
+            for nn in ("norm1", "norm2", "norm3"):
+                vec(f"{b}.{nn}.weight", P[f"{b}.{nn}.weight"]); vec(f"{b}.{nn}.bias", P[f"{b}.{nn}.bias"])
+            mat(f"{b}.attn1.to_qkv.weight", torch.cat([P[f"{b}.attn1.to_q.weight"], P[f"{b}.attn1.to_k.weight"],
+                                                       P[f"{b}.attn1.to_v.weight"]], dim=0))
+            mat(f"{b}.attn1.to_out.0.weight", P[f"{b}.attn1.to_out.0.weight"]); vec(f"{b}.attn1.to_out.0.bias", P[f"{b}.attn1.to_out.0.bias"])
+            mat(f"{b}.attn2.to_q.weight", P[f"{b}.attn2.to_q.weight"])
+            kv_by_dim.setdefault(dim, []).append(torch.cat([P[f"{b}.attn2.to_k.weight"], P[f"{b}.attn2.to_v.weight"]], dim=0))
+            mat(f"{b}.attn2.to_out.0.weight", P[f"{b}.attn2.to_out.0.weight"]); vec(f"{b}.attn2.to_out.0.bias", P[f"{b}.attn2.to_out.0.bias"])
+            mat(f"{b}.ff.net.0.proj.weight", _geglu_interleave(P[f"{b}.ff.net.0.proj.weight"]))
+            vec(f"{b}.ff.net.0.proj.bias", _geglu_interleave(P[f"{b}.ff.net.0.proj.bias"]))
+            mat(f"{b}.ff.net.2.weight", P[f"{b}.ff.net.2.weight"]); vec(f"{b}.ff.net.2.bias", P[f"{b}.ff.net.2.bias"])
+    for dim, lst in kv_by_dim.items():
+        mat(f"attn2_kv_all.{dim}.weight", torch.cat(lst, dim=0))
+    n = len(cfg.block_out_channels)
+    for i in range(n - 1):
+        for p in (f"down_blocks.{i}.downsamplers.0.conv", f"up_blocks.{i}.upsamplers.0.conv"):
+            mat(f"{p}.weight", _conv_pack(P[f"{p}.weight"])); vec(f"{p}.bias", P[f"{p}.bias"])
+    vec("conv_norm_out.weight", P["conv_norm_out.weight"]); vec("conv_norm_out.bias", P["conv_norm_out.bias"])
+    co = P["conv_out.weight"].shape[0]
+    pad = (-co) % 4
+    w = _conv_pack(P["conv_out.weight"]); bias = P["conv_out.bias"]
+    if pad:
+        w = torch.nn.functional.pad(w, (0, 0, 0, pad)); bias = torch.nn.functional.pad(bias, (0, pad))
+    mat("conv_out.weight", w); vec("conv_out.bias", bias)
+    return out
+
+
+class PackedWeights:
+    """One device blob + the (name, offset, bytes) table mx_unet_set_weights takes."""
+
+    def __init__(self, entries: List[Tuple[str, torch.Tensor]], device):
+        total = 0
+        offs = []
+        for _n, t in entries:
+            total = (total + _ALIGN - 1) // _ALIGN * _ALIGN
+            offs.append(total)
+            total += t.numel() * t.element_size()
+        self.blob = torch.empty(total + _ALIGN, dtype=torch.uint8, device=device)
+        self.names = []
+        for (name, t), off in zip(entries, offs):
+            nb = t.numel() * t.element_size()
+            self.blob[off:off + nb].copy_(t.reshape(-1).view(torch.uint8).to(device), non_blocking=False)
+            self.names.append((name, off, nb))
+        self.nbytes = total
+        self._keep = [n.encode() for n, _, _ in self.names]
+        arr = (_lib.WeightEntry * len(self.names))()
+        for i, (n, off, nb) in enumerate(self.names):
+            arr[i].name = self._keep[i]
+            arr[i].offset = off
+            arr[i].bytes = nb
+        self.table = arr

@@ -1,0 +1,142 @@
+"""CPU suite (-m "not gpu"): the oracle against itself and its invariants, the host logic, and that the C-ABI library
+loads and exports every symbol include/mxdenoise.h declares (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import patch_ref, scheduler_ref, sdxl_unet_ref as ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = ref.UNetConfig.tiny()
+    return cfg, ref.init_params(cfg)
+
+
+def test_oracle_gn_single_patch_is_group_norm():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 8, 8, generator=g); w = torch.randn(64, generator=g); b = torch.randn(64, generator=g)
+    assert torch.allclose(ref.group_norm_patchavg(x, 32, w, b, 1e-5, 8), F.group_norm(x, 32, w, b, 1e-5), atol=1e-5)
+
+
+def test_oracle_split_concat_roundtrip():
+    g = torch.Generator().manual_seed(1)
+    samples = {"256": torch.randn(2, 4, 32, 32, generator=g), "512": torch.randn(1, 4, 64, 64, generator=g)}
+    pidx, lo, ro, patches, pm = patch_ref.split_sample(samples, 128)
+    assert patches.shape == (2 * 4 + 16, 4, 18, 18) and lo == [0, 4, 8, 24] and ro == [0, 2, 3]
+    assert pm.tolist() == [1] * 4 + [2] * 4 + [3] * 16
+    back = patch_ref.concat_sample(128, patches[:, :, 1:-1, 1:-1], lo)
+    for k in samples:
+        assert torch.equal(back[k], samples[k])
+    # halo cells of split_sample are the true neighbour pixels / zero at the image border
+    assert torch.equal(patches[0, :, 1:-1, -1], samples["256"][0, :, 0:16, 16])
+    assert patches[0, :, 0, :].abs().max() == 0
+
+
+def test_oracle_halo_semantics():
+    """interior copy, edge rows/cols from neighbours, corners replicated by the left/right sender (cu:210-239)."""
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(1, 3, 8, 8, generator=g)
+    pidx, lo, ro, patches, pm = patch_ref.split_sample({"64": img}, 32)   # 2x2 patches of 4x4
+    x = patches[:, :, 1:-1, 1:-1].contiguous()
+    y = patch_ref.mock_groupnorm(x, pidx)
+    assert torch.equal(y[:, :, 1:-1, 1:-1], x)
+    assert torch.equal(y[0, :, 1:-1, 5], x[1, :, :, 0])      # right halo of patch 0 = first column of patch 1
+    assert torch.equal(y[0, :, 5, 1:-1], x[2, :, 0, :])      # bottom halo of patch 0 = first row of patch 2
+    assert torch.equal(y[0, :, 5, 5], x[1, :, 3, 0])         # corner: replicated from the RIGHT neighbour, not the diagonal
+    assert not torch.equal(y[0, :, 5, 5], x[3, :, 0, 0])
+    assert torch.equal(y[0, :, 0, 5], x[1, :, 0, 0])         # image-border junction gets a non-zero corner
+    assert y[0, :, 0, 0:5].abs().max() == 0
+
+
+def test_oracle_sliced_equals_whole_image_with_corner_rule(tiny):
+    cfg, P = tiny
+    s, t, e, te, ti = ref.make_inputs(cfg, 2, 32)
+    for patch_px, gp in ((128, 16), (64, 8)):
+        lit = patch_ref.unet_forward_sliced(P, cfg, {"256": s}, t, e, te, ti, patch_size=patch_px)["256"]
+        whole = ref.unet_forward(P, cfg, s, t, e, te, ti, gn_patch=gp, sliced_corners=True)
+        assert (lit - whole).abs().max() < 5e-5
+    one = patch_ref.unet_forward_sliced(P, cfg, {"256": s}, t, e, te, ti, patch_size=256)["256"]
+    assert (one - ref.unet_forward(P, cfg, s, t, e, te, ti)).abs().max() < 5e-5
+
+
+def test_oracle_euler_closed_form():
+    ts, sig, init = scheduler_ref.sdxl_euler_tables(50)
+    assert ts[0] == 981 and ts[-1] == 1 and len(sig) == 51 and sig[-1] == 0
+    assert abs(sig[0].item() - 13.0) < 1.0 and abs(init - (sig[0].item() ** 2 + 1) ** 0.5) < 1e-6
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 8, 8, generator=g); eps = torch.randn(2, 4, 8, 8, generator=g)
+    out = scheduler_ref.euler_step(eps, x, sig[[3, 4]], sig[[4, 5]])
+    assert torch.allclose(out, x + eps * (sig[[4, 5]] - sig[[3, 4]]).reshape(2, 1, 1, 1), atol=1e-5)
+
+
+def test_param_inventories_agree():
+    from sduss_amd import config
+    for a, b in ((config.UNetConfig.tiny(), ref.UNetConfig.tiny()), (config.UNetConfig.sdxl_base(), ref.UNetConfig.sdxl_base())):
+        pa, pb = config.param_shapes(a), ref.param_shapes(b)
+        assert set(pa.items()) == set(pb.items())
+    total = sum(torch.Size(v).numel() for v in config.param_shapes(config.UNetConfig.sdxl_base()).values())
+    assert abs(total - 2.567e9) < 2e6     # SDXL-base UNet: 2.57 B parameters
+
+
+def test_library_exports_every_declared_symbol():
+    from sduss_amd import lib
+    l = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "mxdenoise.h")).read()
+    declared = set(re.findall(r"\b(mx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(l, name)
+    assert l.mx_version() == 1
+
+
+def test_step_plan_resolves_packed_weights_on_host(tiny):
+    """mx_unet_validate walks the C++ step plan with no launches: every packed tensor name/size the plan asks for must
+    be what weights.pack produced."""
+    from sduss_amd import config, lib, weights
+    cfg, P = tiny
+    l = lib.load()
+    pcfg = config.UNetConfig.tiny()
+    pw = weights.PackedWeights(weights.pack(pcfg, P), "cpu")
+    cc = lib.UNetConfigC()
+    cc.in_channels, cc.out_channels, cc.n_levels, cc.layers_per_block = 4, 4, 3, 2
+    for i, v in enumerate(pcfg.block_out_channels):
+        cc.block_out_channels[i] = v; cc.down_has_attn[i] = int(pcfg.down_has_attn[i])
+        cc.transformer_layers[i] = pcfg.transformer_layers_per_block[i]; cc.num_heads[i] = pcfg.num_heads[i]
+    cc.cross_attention_dim, cc.addition_time_embed_dim = pcfg.cross_attention_dim, pcfg.addition_time_embed_dim
+    cc.projection_class_embeddings_input_dim, cc.norm_num_groups = pcfg.projection_class_embeddings_input_dim, 32
+    h = l.mx_unet_create(C.byref(cc))
+    assert h
+    assert l.mx_unet_set_weights(h, pw.blob.data_ptr(), pw.blob.numel(), pw.table, len(pw.names)) == 0
+    assert l.mx_unet_validate(h, 2, 32, 32, 77) == 0, l.mx_last_error()
+    assert l.mx_unet_workspace_bytes(h, 2, 32, 32, 77) > 0
+    # a wrong-sized tensor is reported, not ignored
+    bad = [(n, t if n != "conv_out.bias" else torch.zeros(8)) for n, t in weights.pack(pcfg, P)]
+    pw2 = weights.PackedWeights(bad, "cpu")
+    assert l.mx_unet_set_weights(h, pw2.blob.data_ptr(), pw2.blob.numel(), pw2.table, len(pw2.names)) == 0
+    assert l.mx_unet_validate(h, 2, 32, 32, 77) != 0 and b"conv_out.bias" in l.mx_last_error()
+    l.mx_unet_destroy(h)
+
+
+def test_bad_arguments_raise():
+    from sduss_amd import lib
+    l = lib.load()
+    d = lib.GemmDesc()
+    assert l.mx_gemm(None, C.byref(d)) != 0 and b"gemm" in l.mx_last_error()
+    with pytest.raises(lib.MxError):
+        lib.check(l.mx_attention(None, None, 0, None, 0, None, 0, 0, None, 0, 1, 1, 1, 1, 0.125), "mx_attention")
+    assert l.mx_unet_create(None) is None
+
+
+def test_geglu_interleave_layout():
+    from sduss_amd.weights import _geglu_interleave
+    t = torch.arange(8 * 64).float()          # dim 64: hidden rows 0..255, gate rows 256..511
+    p = _geglu_interleave(t)
+    assert p[:32].tolist() == list(range(0, 32)) and p[32:64].tolist() == list(range(256, 288))
+    assert p[64:96].tolist() == list(range(32, 64))

@@ -1,0 +1,221 @@
+"""GPU parity of every HIP kernel, called through the C ABI, against the CPU oracle / a torch fp32 reference of the
+same op on the same seeded inputs.  Floating-point path: tolerances are stated per test (bf16 storage = 8 mantissa
+bits: one rounding is 2^-9 relative; accumulations are fp32)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import patch_ref, scheduler_ref, sdxl_unet_ref as ref  # noqa: E402  (checker only)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rt(t):
+    """bf16 round trip, fp32 result: what the kernel actually receives."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _close(got, want, rel, what):
+    got = got.float().cpu()
+    scale = want.abs().max().item() + 1e-6
+    err = (got - want).abs().max().item()
+    assert math.isfinite(err), f"{what}: non-finite"
+    assert err <= rel * scale, f"{what}: max err {err:.5f} > {rel} * {scale:.4f}"
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _conv_pack(w):
+    o, i, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(o, -1).contiguous()
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 128, 64), (200, 320, 192), (77 * 2, 256, 128), (1024, 640, 640), (130, 4, 576)])
+def test_gemm_bias_residual(cuda_device, m, n, k):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = _rt(torch.randn(m, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
+    b = torch.randn(n, generator=g); r = _rt(torch.randn(m, n, generator=g))
+    want = a @ w.t() + b + r
+    got = ops.gemm(_bf(a).cuda(), _bf(w).cuda(), b.cuda(), residual=_bf(r).cuda())
+    _close(got, want, 2.0 ** -7, "gemm+bias+residual")
+    got = ops.gemm(_bf(a).cuda(), _bf(w).cuda(), b.cuda(), silu=True, out_f32=True)
+    _close(got, F.silu(a @ w.t() + b), 1e-4, "gemm+silu f32")
+
+
+def test_gemm_rowbias(cuda_device):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(3)
+    bsz, rows, n, k = 3, 64, 192, 128
+    a = _rt(torch.randn(bsz * rows, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
+    rb = torch.randn(bsz, n + 64, generator=g)  # wider row stride than N, column offset 0
+    want = a @ w.t() + rb[:, :n].repeat_interleave(rows, dim=0)
+    got = ops.gemm(_bf(a).cuda(), _bf(w).cuda(), None, rowbias=rb.cuda(), rows_per_batch=rows)
+    _close(got, want, 2.0 ** -7, "gemm+rowbias")
+
+
+def test_gemm_geglu(cuda_device):
+    from sduss_amd import ops
+    from sduss_amd.weights import _geglu_interleave
+    g = torch.Generator().manual_seed(5)
+    m, dim = 192, 64
+    a = _rt(torch.randn(m, dim, generator=g)); w = _rt(torch.randn(8 * dim, dim, generator=g) * dim ** -0.5)
+    b = torch.randn(8 * dim, generator=g)
+    hid, gate = (a @ w.t() + b).chunk(2, dim=-1)
+    want = hid * F.gelu(gate)
+    got = ops.gemm(_bf(a).cuda(), _bf(_geglu_interleave(w)).cuda(), _geglu_interleave(b).cuda(), geglu=True)
+    assert got.shape == (m, 4 * dim)
+    _close(got, want, 2.0 ** -7, "gemm+geglu")
+
+
+@pytest.mark.parametrize("period,rows,dim", [(3, 64, 128), (2, 77, 64), (3, 256, 64)])
+def test_gemm_qkv_split(cuda_device, period, rows, dim):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(period * 11 + rows)
+    nb, k, groups = 2, 128, 2 if period == 2 else 1
+    n = groups * period * dim
+    a = _rt(torch.randn(nb * rows, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
+    full = a @ w.t()
+    c, vt = ops.gemm_qkv(_bf(a).cuda(), _bf(w).cuda(), dim, period, rows)
+    segs = full.reshape(nb * rows, groups, period, dim)
+    want_c = segs[:, :, :period - 1].reshape(nb * rows, -1)
+    want_v = segs[:, :, period - 1].reshape(nb, rows, groups * dim).permute(0, 2, 1)   # [nb, V cols, key]
+    _close(c, want_c, 2.0 ** -7, "qkv row-major part")
+    _close(vt[:, :, :rows], want_v, 2.0 ** -7, "qkv transposed V")
+
+
+@pytest.mark.parametrize("stride,up,corner,hw,cin,cout", [(1, 0, 0, 16, 64, 128), (2, 0, 0, 16, 128, 64), (1, 1, 0, 8, 64, 64),
+                                                          (1, 0, 4, 16, 64, 64), (2, 0, 8, 16, 64, 64), (1, 1, 8, 8, 64, 64),
+                                                          (1, 0, 0, 12, 192, 320)])
+def test_conv3x3(cuda_device, stride, up, corner, hw, cin, cout):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(stride * 100 + up * 10 + corner + cin)
+    b = 2
+    x = _rt(torch.randn(b, cin, hw, hw, generator=g)); w = _rt(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    want = ref.conv3x3(xin, w, bias, stride, corner if corner else None)
+    got = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(w)).cuda(), bias.cuda(), stride=stride, up=up, corner_patch=corner)
+    _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, f"conv3x3 s{stride} up{up} corner{corner}")
+
+
+def test_conv3x3_rowbias_residual(cuda_device):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(9)
+    b, c, hw = 2, 64, 8
+    x = _rt(torch.randn(b, c, hw, hw, generator=g)); w = _rt(torch.randn(c, c, 3, 3, generator=g) * (9 * c) ** -0.5)
+    bias = torch.randn(c, generator=g); temb = torch.randn(b, c, generator=g); r = _rt(torch.randn(b, c, hw, hw, generator=g))
+    want = F.conv2d(x, w, bias, padding=1) + temb[:, :, None, None] + r
+    got = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(w)).cuda(), bias.cuda(), rowbias=temb.cuda(),
+                      residual=_bf(_nhwc(r)).cuda().reshape(-1, c))
+    _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, "conv3x3+temb+residual")
+
+
+@pytest.mark.parametrize("lq,lk,heads", [(256, 256, 2), (1024, 1024, 1), (64, 77, 4), (200, 77, 1), (4096, 4096, 1)])
+def test_attention(cuda_device, lq, lk, heads):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(lq + lk + heads)
+    b, c = 2, heads * 64
+    q = _rt(torch.randn(b, lq, c, generator=g)); k = _rt(torch.randn(b, lk, c, generator=g)); v = _rt(torch.randn(b, lk, c, generator=g))
+    want = ref.attention(q, k, v, heads)
+    ldvt = (lk + 7) // 8 * 8
+    vt = torch.full((b, c, ldvt), float("nan"))       # the pad must never leak
+    vt[:, :, :lk] = v.permute(0, 2, 1)
+    got = ops.attention(_bf(q.reshape(-1, c)).cuda(), _bf(k.reshape(-1, c)).cuda(), _bf(vt).cuda(), heads, lq, lk)
+    _close(got.reshape(b, lq, c), want, 2.0 ** -6, f"attention {lq}x{lk}")
+
+
+def test_attention_spiked_max(cuda_device):
+    """forces the running-max rescale branch at a late KV tile (cdna guide rule 26)."""
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(1)
+    b, l, c = 1, 512, 64
+    q = _rt(torch.randn(b, l, c, generator=g)); k = _rt(torch.randn(b, l, c, generator=g)); v = _rt(torch.randn(b, l, c, generator=g))
+    k[0, 300] = q[0, 5] * 4.0   # one key aligned with one query: the max jumps in tile 4
+    k[0, 450] = q[0, 77] * 6.0
+    want = ref.attention(q, k, v, 1)
+    got = ops.attention(_bf(q.reshape(-1, c)).cuda(), _bf(k.reshape(-1, c)).cuda(), _bf(v.permute(0, 2, 1).contiguous()).cuda(), 1, l, l)
+    _close(got.reshape(b, l, c), want, 2.0 ** -6, "attention spiked")
+
+
+@pytest.mark.parametrize("c", [64, 640, 1280, 256])
+def test_layernorm(cuda_device, c):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(c)
+    x = _rt(torch.randn(300, c, generator=g) * 2 + 0.5); ga = torch.randn(c, generator=g); be = torch.randn(c, generator=g)
+    want = F.layer_norm(x, (c,), ga, be, 1e-5)
+    got = ops.layernorm(_bf(x).cuda(), ga.cuda(), be.cuda(), 1e-5)
+    _close(got, want, 2.0 ** -7, "layernorm")
+
+
+@pytest.mark.parametrize("c,hw,patch,silu", [(64, 16, 0, True), (320, 32, 0, True), (192, 16, 4, False), (640, 16, 8, True),
+                                            (2560, 8, 0, True), (128, 32, 16, True)])
+def test_groupnorm_nhwc(cuda_device, c, hw, patch, silu):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(c + hw + patch)
+    x = _rt(torch.randn(2, c, hw, hw, generator=g) * 1.5 + 0.7); ga = torch.randn(c, generator=g); be = torch.randn(c, generator=g)
+    want = ref._gn(x, 32, ga, be, 1e-5, patch if patch else None)
+    if silu:
+        want = F.silu(want)
+    got = ops.groupnorm_nhwc(_bf(_nhwc(x)).cuda(), ga.cuda(), be.cuda(), 32, 1e-5, silu, patch)
+    _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, f"groupnorm nhwc C{c} p{patch}")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 2.0 ** -9), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("padding", [True, False])
+def test_esymred_groupnorm(cuda_device, dtype, tol, padding):
+    """The inner boundary: same call as groupnorm.py:50,58 on a split_sample() patch batch of two resolutions."""
+    from sduss_amd import esymred_mp
+    g = torch.Generator().manual_seed(21)
+    c, cpg = 64, 2
+    samples = {"256": torch.randn(1, c, 32, 32, generator=g), "384": torch.randn(2, c, 48, 48, generator=g)}
+    pidx, lat_off, _res_off, patches, pmap = patch_ref.split_sample(samples, 128)
+    x = patches[:, :, 1:-1, 1:-1].contiguous().to(dtype).to(torch.float32)   # interior: what the op receives mid-network
+    ga = torch.randn(c, generator=g).to(dtype).float(); be = torch.randn(c, generator=g).to(dtype).float()
+    want = patch_ref.groupnorm(x, ga, be, cpg, 1e-5, padding, lat_off, pmap, pidx)
+    n, _, h, w = x.shape
+    got = esymred_mp.groupnorm(x.to(dtype).cuda(), ga.to(dtype).cuda(), be.to(dtype).cuda(), n, c, h, w, cpg, 1e-5, padding,
+                               torch.tensor(lat_off, dtype=torch.int32).cuda(), pmap.cuda(), pidx.cuda())
+    assert got.shape == want.shape and got.dtype == dtype
+    _close(got, want, tol, f"esymred_mp.groupnorm {dtype} pad={padding}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_esymred_mock_groupnorm_bit_exact(cuda_device, dtype):
+    """Halo exchange is pure data movement: bit-exact."""
+    from sduss_amd import esymred_mp
+    g = torch.Generator().manual_seed(22)
+    c = 32
+    samples = {"512": torch.randn(2, c, 64, 64, generator=g)}
+    pidx, _lo, _ro, patches, _pm = patch_ref.split_sample(samples, 128)
+    x = patches[:, :, 1:-1, 1:-1].contiguous().to(dtype)
+    want = patch_ref.mock_groupnorm(x, pidx)
+    n, _, h, w = x.shape
+    got = esymred_mp.mock_groupnorm(x.cuda(), n, c, h, w, 1, pidx.cuda()).cpu()
+    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_scheduler_steps(cuda_device, dtype):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(31)
+    _ts, sigmas, _ = scheduler_ref.sdxl_euler_tables(50)
+    n = 3
+    lat = (torch.randn(n, 4, 16, 16, generator=g) * 10).to(dtype)
+    sig = sigmas[[0, 7, 30]]; sig_next = sigmas[[1, 8, 31]]
+    want = scheduler_ref.scale_model_input(torch.cat([lat, lat]), torch.cat([sig, sig]))
+    got = ops.euler_scale_input(lat.cuda(), sig, 2 * n).cpu()
+    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), "scale_model_input must be bit-exact"
+    noise = torch.randn(2 * n, 4, 16, 16, generator=g).to(dtype)
+    want = scheduler_ref.euler_step(scheduler_ref.cfg_combine(noise, 5.0), lat, sig, sig_next)
+    got = ops.cfg_euler_step_(noise.cuda(), lat.cuda().clone(), sig, sig_next, 5.0).cpu()
+    # torch evaluates sigma*eps etc. with the same IEEE ops; allow 1 ulp of the storage dtype for pow/sqrt differences
+    _close(got, want.float(), {torch.float32: 1e-6, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype], "cfg+euler step")
