@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SDXL-base 1024x1024, 50-step, CFG, bf16 -- images/s of the denoising hot path, one replica per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one ``denoising_step`` (scale+CFG dup -> UNet -> CFG combine -> Euler) over one batch of B=4 synthetic
+1024^2 requests (UNet batch 8), i.e. BASELINE.json configs[1].  images/s = N * B / (50 * step time).  Inputs and
+weights are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra legs (outside the timed region):
+  roofline     one more step with every GEMM/conv/attention launch bracketed by hipEvents on its stream
+               (mx_profile_enable): achieved = algorithmic FLOPs / summed launch time of the dominant kernel
+  stream       a short fixed-prompt Poisson stream with continuous batching (p50 / p90 request latency)
+  cpu_baseline the CPU oracle (torch fp32, all host cores) timed on ONE UNet sample-forward at 1024^2 = 1/100 image
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEPS_PER_IMAGE = 50
+SDXL_FLOP_PER_SAMPLE_FORWARD = 6.76e12     # SURVEY.md section 8d (3.381 TMAC)
+MFMA_PEAK_BF16 = 2.5e15                    # dense, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<128,true> (conv3x3)",
+              "gemm_kernel<64,true> (conv3x3)", "attn_fwd_kernel", "groupnorm (3 kernels)"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="requests per step (UNet batch is 2x under CFG)")
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--sliced", action="store_true", help="is_sliced=True, patch_size=256 (the reference's mixed-policy setting)")
+    ap.add_argument("--stream-requests", type=int, default=12)
+    ap.add_argument("--stream-load", type=float, default=0.9)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_batch(den, cfg, n, res, device, shared, base_id=0):
+    from sduss_amd.pipeline import synthetic_request
+    return [synthetic_request(base_id + i, res, STEPS_PER_IMAGE, cfg, den, device, shared=shared) for i in range(n)]
+
+
+def run_stream(den, cfg, args, device, shared, step_s, rank, world):
+    """Fixed-prompt Poisson stream, continuous batching (FCFS, max batch = --batch), requests dealt round-robin to the
+    replicas.  Returns this rank's per-request latencies and its busy window."""
+    n_total = args.stream_requests * world
+    cap_per_gpu = args.batch / (STEPS_PER_IMAGE * step_s)
+    rate = args.stream_load * cap_per_gpu * world
+    rng = np.random.RandomState(10086)                      # reference seed (arg_utils.py:20)
+    arrivals = np.cumsum(rng.exponential(1.0 / rate, size=n_total))
+    mine = [(i, arrivals[i]) for i in range(n_total) if i % world == rank]
+    pending = make_batch(den, cfg, len(mine), args.res, device, shared, base_id=1000)
+    for r, (_i, a) in zip(pending, mine):
+        r.arrival = float(a)
+    active, done = [], []
+    t0 = time.perf_counter()
+    while pending or active:
+        now = time.perf_counter() - t0
+        while pending and len(active) < args.batch and pending[0].arrival <= now:
+            r = pending.pop(0)
+            r.start = now
+            active.append(r)
+        if not active:
+            time.sleep(max(0.0, pending[0].arrival - now))
+            continue
+        den.denoising_step({str(args.res): active}, is_sliced=args.sliced, patch_size=256)
+        torch.cuda.synchronize()
+        now = time.perf_counter() - t0
+        for r in [r for r in active if r.done()]:
+            r.finish = now
+            done.append(r)
+        active = [r for r in active if not r.done()]
+    lat = [r.finish - r.arrival for r in done]
+    return lat, (min(r.arrival for r in done), max(r.finish for r in done))
+
+
+def cpu_baseline(res):
+    """The oracle (kind 'port') on the host cores: one SDXL UNet sample-forward at full width."""
+    from oracle import sdxl_unet_ref as ref
+    cfg = ref.UNetConfig.sdxl_base()
+    P = ref.fast_params(cfg)      # timing-equivalent weights without 2.6e9 RNG draws
+    sample, t, ehs, text, tids = ref.make_inputs(cfg, 1, res // 8)
+    threads = torch.get_num_threads()
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        out = ref.unet_forward(P, cfg, sample, t, ehs, text, tids)
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return {"value": 1.0 / (dt * 2 * STEPS_PER_IMAGE), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 UNet sample-forward (batch 1, {res}x{res}, fp32 torch oracle) = 1/{2 * STEPS_PER_IMAGE} image, "
+                      f"{dt:.1f} s on {threads} threads of {os.cpu_count()} host CPUs; extrapolated x{2 * STEPS_PER_IMAGE}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)   # RCCL; used for the barrier + max-over-ranks only: replicas share nothing
+
+    from sduss_amd import lib
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.pipeline import SDXLDenoiser
+    from sduss_amd.unet import MxUNet
+    from sduss_amd.weights import synthetic_params
+
+    cfg = UNetConfig.sdxl_base()
+    net = MxUNet(cfg, synthetic_params(cfg, device=device), device=device)
+    den = SDXLDenoiser(net, guidance_scale=5.0)
+    shared = {}
+    reqs = make_batch(den, cfg, args.batch, args.res, device, shared)
+    key = str(args.res)
+
+    def step():
+        den.denoising_step({key: reqs}, is_sliced=args.sliced, patch_size=256)
+        for r in reqs:
+            if r.done():
+                r.step_index = 0        # steady state: keep the batch full
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_s = elapsed / args.steps
+    images_per_s = world * args.batch / (STEPS_PER_IMAGE * step_s)
+    finite = all(torch.isfinite(r.latents.float()).all().item() for r in reqs)
+
+    result = {
+        "metric": "images/sec (node), SDXL 1024^2 50-step, fixed prompt, CFG", "value": images_per_s, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SDXL-base-1.0 UNet {args.res}x{args.res} 50-step Euler, CFG 5.0, {args.batch} requests/step "
+                               f"(UNet batch {2 * args.batch}) per GPU, is_sliced={args.sliced}, random-init weights of the "
+                               f"real architecture (2.57 B params), one data-parallel replica per GPU, no collective",
+                   "requests_per_step": args.batch, "resolution": args.res, "steps_per_image": STEPS_PER_IMAGE},
+        "outputs_finite": finite,
+        "achieved_tflops_whole_step": 2 * args.batch * SDXL_FLOP_PER_SAMPLE_FORWARD / step_s / 1e12 if args.res == 1024 else None,
+        "frac_of_mfma_peak_whole_step": 2 * args.batch * SDXL_FLOP_PER_SAMPLE_FORWARD / step_s / MFMA_PEAK_BF16 if args.res == 1024 else None,
+    }
+
+    # ---- roofline leg: per-launch hipEvents on the launch stream ----
+    if not args.no_roofline and rank == 0:
+        l = lib.load()
+        l.mx_profile_enable(1)
+        step()
+        torch.cuda.synchronize()
+        buf = (C.c_double * 24)()
+        lib.check(l.mx_profile_collect(buf), "mx_profile_collect")
+        l.mx_profile_enable(0)
+        kinds = []
+        for k, name in enumerate(KIND_NAMES):
+            n, ms, fl, by = buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]
+            if n > 0:
+                kinds.append({"kernel": name, "launches": int(n), "ms_total": ms, "avg_us": 1e3 * ms / n,
+                              "tflops": fl / (ms * 1e-3) / 1e12 if fl else None, "gbps": by / (ms * 1e-3) / 1e9})
+        result["kernels"] = kinds
+        mf = [k for k in kinds if k["tflops"]]
+        if mf:
+            dom = max(mf, key=lambda k: k["ms_total"])
+            result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_BF16 / 1e12,
+                                  "unit": "TFLOP/s", "frac": dom["tflops"] / (MFMA_PEAK_BF16 / 1e12), "traffic": None,
+                                  "launches_per_step": dom["launches"], "avg_launch_us": dom["avg_us"]}
+    if dist is not None:
+        dist.barrier()
+
+    # ---- stream leg: p50 request latency under Poisson arrivals ----
+    if args.stream_requests > 0:
+        lat, window = run_stream(den, cfg, args, device, shared, step_s, rank, world)
+        if dist is not None:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (lat, window))
+            lat = [x for g in gathered for x in g[0]]
+            window = (min(g[1][0] for g in gathered), max(g[1][1] for g in gathered))
+        if rank == 0:
+            result["stream"] = {"requests": len(lat), "offered_load_frac_of_capacity": args.stream_load,
+                                "p50_latency_s": float(np.percentile(lat, 50)), "p90_latency_s": float(np.percentile(lat, 90)),
+                                "throughput_images_per_s": len(lat) / (window[1] - window[0]),
+                                "arrivals": "exponential inter-arrival, numpy seed 10086, round-robin over replicas"}
+            result["p50_latency_s"] = result["stream"]["p50_latency_s"]
+
+    # ---- CPU baseline leg ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.res)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,6 +32,12 @@ enum { MX_F32 = 0, MX_F16 = 1, MX_BF16 = 2 };
 
 const char* mx_last_error(void);
 int mx_version(void);
+/* Optional per-launch timing for bench.py's roofline leg: while enabled, every GEMM / conv / attention / norm launch
+ * is bracketed by hipEvents on its own stream.  mx_profile_collect (after the stream is synchronised) fills
+ * out[24] = for kind in {gemm<128>, gemm<64>, conv3x3<128>, conv3x3<64>, attention, groupnorm}:
+ *           {launches, milliseconds, algorithmic flops, algorithmic bytes}. */
+int mx_profile_enable(int on);
+int mx_profile_collect(double* out);
 
 /* ------------------------------------------------------------------------------------------
  * Inner boundary: drop-in for the reference's only native op (NCHW patch batches).

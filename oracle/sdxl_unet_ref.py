@@ -233,6 +233,34 @@ def init_params(cfg: UNetConfig, seed: int = 10086, bf16_round: bool = True) -> 
     return out
 
 
+def fast_params(cfg: UNetConfig, seed: int = 10086) -> Dict[str, torch.Tensor]:
+    """Same distribution as ``init_params`` but tiled from one 16M-element random pool, so the 2.57 B-parameter
+    SDXL-base inventory is ready in seconds (full-width parity test, bench cpu_baseline)."""
+    g = torch.Generator().manual_seed(seed)
+    pool = torch.randn(1 << 24, generator=g)
+    out: Dict[str, torch.Tensor] = {}
+    off = 0
+    for name, shape in param_shapes(cfg).items():
+        n = 1
+        for d in shape:
+            n *= d
+        if n <= pool.numel():
+            off = off if off + n <= pool.numel() else 0
+            t = pool[off:off + n]
+            off += n
+        else:
+            t = pool.repeat((n + pool.numel() - 1) // pool.numel())[:n]
+        t = t.reshape(shape)
+        if name.endswith(".weight") and len(shape) >= 2:
+            t = t * (n // shape[0]) ** -0.5
+        elif name.endswith(".weight"):
+            t = 1.0 + 0.1 * t
+        else:
+            t = 0.05 * t
+        out[name] = t.to(torch.bfloat16).to(torch.float32)
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # primitives
 # --------------------------------------------------------------------------------------

@@ -232,7 +232,10 @@ extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k,
   a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale_log2 = scale * 1.4426950408889634f;
   dim3 grid(cdiv(Lq, 128), H, B);
+  prof_begin((hipStream_t)stream, PROF_ATTN, 4.0 * B * H * (double)Lq * Lk * 64.0,
+             2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk));
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  prof_end((hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return 0;
 }

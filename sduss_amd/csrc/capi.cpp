@@ -1,5 +1,6 @@
-// Error plumbing of the C ABI (include/mxdenoise.h).
+// Error plumbing and the optional launch profiler of the C ABI (include/mxdenoise.h).
 #include <string>
+#include <vector>
 
 #include "../../include/mxdenoise.h"
 #include "common.h"
@@ -7,7 +8,54 @@
 namespace mx {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+
+struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+bool prof_enabled() { return g_prof; }
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+void prof_begin(hipStream_t s, int kind, double flops, double bytes) {
+  if (!g_prof) return;
+  ProfRec r; r.a = get_event(); r.b = get_event(); r.kind = kind; r.flops = flops; r.bytes = bytes;
+  (void)hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+}
+void prof_end(hipStream_t s) {
+  if (!g_prof || g_recs.empty()) return;
+  (void)hipEventRecord(g_recs.back().b, s);
+}
 }  // namespace mx
 
 extern "C" const char* mx_last_error(void) { return mx::g_err.c_str(); }
 extern "C" int mx_version(void) { return 1; }
+
+extern "C" int mx_profile_enable(int on) {
+  mx::g_prof = on != 0;
+  if (on) {
+    for (auto& r : mx::g_recs) { mx::g_pool.push_back(r.a); mx::g_pool.push_back(r.b); }
+    mx::g_recs.clear();
+  }
+  return 0;
+}
+
+// Synchronises the recorded events (call after the stream has been synchronised) and sums, per kernel kind,
+// launches / milliseconds / algorithmic flops / algorithmic bytes.  out: double[4 * 6] = kind-major {n, ms, flops, bytes}.
+extern "C" int mx_profile_collect(double* out) {
+  MX_CHECK(out != nullptr, "profile_collect: null output");
+  for (int i = 0; i < 4 * mx::PROF_KINDS; ++i) out[i] = 0.0;
+  for (auto& r : mx::g_recs) {
+    MX_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    MX_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    double* o = out + 4 * r.kind;
+    o[0] += 1.0; o[1] += ms; o[2] += r.flops; o[3] += r.bytes;
+    mx::g_pool.push_back(r.a); mx::g_pool.push_back(r.b);
+  }
+  mx::g_recs.clear();
+  return 0;
+}

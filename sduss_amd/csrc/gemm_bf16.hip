@@ -321,6 +321,14 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   }
   dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (prof_enabled()) {
+    // algorithmic work: true (unpadded) contraction; bytes = operands read once + result written once
+    const double kk = conv ? 9.0 * d->Cin : (double)d->K;
+    const double flops = 2.0 * d->M * (double)d->N * kk;
+    const double in_elems = conv ? (double)d->B * d->Hin * d->Win * d->Cin : (double)d->M * d->K;
+    const double bytes = 2.0 * (in_elems + (double)d->N * d->K + (double)d->M * d->N);
+    prof_begin(s, (conv ? PROF_CONV128 : PROF_GEMM128) + ((d->N % 128 == 0) ? 0 : 1), flops, bytes);
+  }
   if (use128) {
     dim3 grid(cdiv(d->M, BM), d->N / 128);
     if (conv) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, block, 0, s, a);
@@ -330,6 +338,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     if (conv) hipLaunchKernelGGL((gemm_kernel<64, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel<64, false>), grid, block, 0, s, a);
   }
+  prof_end(s);
   MX_LAUNCH_CHECK();
   return 0;
 }

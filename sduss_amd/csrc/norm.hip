@@ -202,6 +202,7 @@ extern "C" int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const flo
   const int threads = ((g.tpr * g.L + 63) / 64) * 64;
   const size_t smem = (size_t)g.L * C * 2 * sizeof(float);
   MX_CHECK(smem <= 160 * 1024, "groupnorm: LDS budget exceeded");
+  prof_begin(s, PROF_NORM, 0.0, 3.0 * 2.0 * B * H * (double)W * C);  // stats read + apply read + write
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ntiles, B), dim3(threads), smem, s, (const bf16_t*)x, part, g);
   MX_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_fold_kernel, dim3(groups, B), dim3(64), 0, s, (const float*)part, gamma, beta, coef, g,
@@ -213,6 +214,7 @@ extern "C" int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const flo
   dim3 grid(cdiv(hw, ppb), B);
   if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb);
   else hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb);
+  prof_end(s);
   MX_LAUNCH_CHECK();
   return 0;
 }

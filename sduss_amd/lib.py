@@ -53,6 +53,8 @@ _vp, _i, _f, _d, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int
 SYMBOLS = {
     "mx_last_error": (C.c_char_p, []),
     "mx_version": (_i, []),
+    "mx_profile_enable": (_i, [_i]),
+    "mx_profile_collect": (_i, [C.POINTER(C.c_double)]),
     "mx_groupnorm_halo_workspace_bytes": (_sz, [_i, _i, _i]),
     "mx_groupnorm_halo": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "mx_halo_only": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i]),

