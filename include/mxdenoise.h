@@ -38,6 +38,8 @@ int mx_version(void);
  *           {launches, milliseconds, algorithmic flops, algorithmic bytes}. */
 int mx_profile_enable(int on);
 int mx_profile_collect(double* out);
+/* per-launch records of the last collect: out[6*i..] = {kind, M, N, K, ms, flops}; returns the number written */
+int mx_profile_records(double* out, int max_records);
 
 /* ------------------------------------------------------------------------------------------
  * Inner boundary: drop-in for the reference's only native op (NCHW patch batches).

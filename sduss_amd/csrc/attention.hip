@@ -233,7 +233,7 @@ extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k,
   a.scale_log2 = scale * 1.4426950408889634f;
   dim3 grid(cdiv(Lq, 128), H, B);
   prof_begin((hipStream_t)stream, PROF_ATTN, 4.0 * B * H * (double)Lq * Lk * 64.0,
-             2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk));
+             2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   prof_end((hipStream_t)stream);
   MX_LAUNCH_CHECK();

@@ -9,7 +9,8 @@ namespace mx {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
-struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; int m, n, k; float ms; };
+static std::vector<ProfRec> g_last;
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -19,9 +20,9 @@ static hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
-void prof_begin(hipStream_t s, int kind, double flops, double bytes) {
+void prof_begin(hipStream_t s, int kind, double flops, double bytes, int m, int n, int k) {
   if (!g_prof) return;
-  ProfRec r; r.a = get_event(); r.b = get_event(); r.kind = kind; r.flops = flops; r.bytes = bytes;
+  ProfRec r; r.a = get_event(); r.b = get_event(); r.kind = kind; r.flops = flops; r.bytes = bytes; r.m = m; r.n = n; r.k = k; r.ms = 0.f;
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
 }
@@ -48,14 +49,28 @@ extern "C" int mx_profile_enable(int on) {
 extern "C" int mx_profile_collect(double* out) {
   MX_CHECK(out != nullptr, "profile_collect: null output");
   for (int i = 0; i < 4 * mx::PROF_KINDS; ++i) out[i] = 0.0;
+  mx::g_last.clear();
   for (auto& r : mx::g_recs) {
     MX_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
     MX_HIP(hipEventElapsedTime(&ms, r.a, r.b));
     double* o = out + 4 * r.kind;
     o[0] += 1.0; o[1] += ms; o[2] += r.flops; o[3] += r.bytes;
+    r.ms = ms; mx::g_last.push_back(r);
     mx::g_pool.push_back(r.a); mx::g_pool.push_back(r.b);
   }
   mx::g_recs.clear();
   return 0;
+}
+
+// per-launch records of the last mx_profile_collect: out[i*6 .. i*6+5] = {kind, M, N, K, ms, flops}; returns the count
+extern "C" int mx_profile_records(double* out, int max_records) {
+  int n = 0;
+  for (auto& r : mx::g_last) {
+    if (n >= max_records) break;
+    double* o = out + 6 * n;
+    o[0] = r.kind; o[1] = r.m; o[2] = r.n; o[3] = r.k; o[4] = r.ms; o[5] = r.flops;
+    ++n;
+  }
+  return n;
 }

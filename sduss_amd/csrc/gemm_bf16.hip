@@ -327,7 +327,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     const double flops = 2.0 * d->M * (double)d->N * kk;
     const double in_elems = conv ? (double)d->B * d->Hin * d->Win * d->Cin : (double)d->M * d->K;
     const double bytes = 2.0 * (in_elems + (double)d->N * d->K + (double)d->M * d->N);
-    prof_begin(s, (conv ? PROF_CONV128 : PROF_GEMM128) + ((d->N % 128 == 0) ? 0 : 1), flops, bytes);
+    prof_begin(s, (conv ? PROF_CONV128 : PROF_GEMM128) + ((d->N % 128 == 0) ? 0 : 1), flops, bytes, d->M, d->N, (int)kk);
   }
   if (use128) {
     dim3 grid(cdiv(d->M, BM), d->N / 128);

@@ -55,6 +55,7 @@ SYMBOLS = {
     "mx_version": (_i, []),
     "mx_profile_enable": (_i, [_i]),
     "mx_profile_collect": (_i, [C.POINTER(C.c_double)]),
+    "mx_profile_records": (_i, [C.POINTER(C.c_double), _i]),
     "mx_groupnorm_halo_workspace_bytes": (_sz, [_i, _i, _i]),
     "mx_groupnorm_halo": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "mx_halo_only": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i]),
