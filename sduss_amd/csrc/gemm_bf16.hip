@@ -19,26 +19,13 @@
 //
 // Reference call sites this serves: F.linear / F.conv2d issued by sduss/model_executor/modules/
 // resnet.py:106,132,163 and attention.py:73-96,148-151,220 (through un-vendored diffusers/torch).
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/mxdenoise.h"
+#include "gemm_args.h"
 
 namespace mx {
-
-struct GemmArgs {
-  const bf16_t* a;
-  const bf16_t* w;
-  void* c;
-  const float* bias;
-  const float* rowbias;
-  const bf16_t* residual;
-  bf16_t* vt;
-  int M, N, K;
-  int lda, ldc, ldr, ldrb;
-  int rows_per_batch;
-  int flags;
-  int seg, period, ldvt;
-  int B, Hin, Win, Cin, Hout, Wout, stride, up, corner_patch;
-};
 
 constexpr int BM = 128;
 constexpr int BK = 64;
@@ -186,94 +173,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     __syncthreads();
   }
 
-  // ------------------------------- epilogue -------------------------------
-  const int flags = p.flags;
-  const int wave_n0 = n0 + wn * (BN / 2);
-  const bool geglu = (flags & MX_EPI_GEGLU) != 0;
-  const bool qkv = (flags & MX_EPI_QKV) != 0;
-  // QKV: the wave's feature range lies inside one segment (seg % 64 == 0)
-  int seg_idx = 0, seg_grp = 0, seg_pos = 0;
-  bool to_vt = false;
-  if (qkv) {
-    seg_idx = wave_n0 / p.seg;
-    seg_grp = seg_idx / p.period;
-    seg_pos = seg_idx - seg_grp * p.period;
-    to_vt = (seg_pos == p.period - 1);
-  }
+  gemm_epilogue<NI, MI, BN>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq);
+}
 
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + fr;
-    if (m >= p.M) continue;
-    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
-#pragma unroll
-    for (int i = 0; i < (NI); ++i) {
-      if (geglu && i >= NI / 2) continue;
-      const int n = wave_n0 + i * 16 + fq * 4;  // packed feature index of v[0]
-      if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q];
-      if (p.bias) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += b4[q];
-      }
-      if (geglu) {
-        float g[4];
-        const int ng = n + (BN / 4);  // gate block = +32 packed rows (NI/2 blocks of 16)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) g[q] = acc[i + NI / 2][j][q];
-        if (p.bias) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + ng);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) g[q] += b4[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] * gelu_f(g[q]);
-        const int nout = wave_n0 / 2 + i * 16 + fq * 4;
-        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + nout) = o;
-        continue;
-      }
-      if (p.rowbias) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ldrb + n);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += b4[q];
-      }
-      if (p.residual) {
-        const u32x2 r = *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
-        v[0] += bf16lo_to_f32(r[0]); v[1] += bf16hi_to_f32(r[0]);
-        v[2] += bf16lo_to_f32(r[1]); v[3] += bf16hi_to_f32(r[1]);
-      }
-      if (flags & MX_EPI_SILU) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
-      }
-      if (qkv) {
-        const int nin = n - seg_idx * p.seg;  // position inside the segment
-        if (to_vt) {
-          const int key = m - bidx * p.rows_per_batch;
-          const int nv = p.N / p.period;
-          bf16_t* dst = p.vt + ((long)bidx * nv + (long)seg_grp * p.seg + nin) * p.ldvt + key;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) dst[(long)q * p.ldvt] = f32_to_bf16(v[q]);
-        } else {
-          const int ccol = seg_grp * (p.period - 1) * p.seg + seg_pos * p.seg + nin;
-          u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + ccol) = o;
-        }
-        continue;
-      }
-      if (flags & MX_EPI_OUT_F32) {
-        f32x4 o = {v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + (long)m * p.ldc + n) = o;
-      } else {
-        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + n) = o;
-      }
-    }
+int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn);
+
+// Tile choice for the pipelined 256-row kernel: the feature tile (160 or 128) that needs the fewest full-chip rounds
+// of 256 workgroups (one per CU); 0 = use the generic 128-row kernel.
+static int pick_v2_bn(const mx_gemm_desc* d) {
+  static const bool disabled = [] { const char* e = getenv("MX_GEMM_V2"); return e && e[0] == '0'; }();
+  if (disabled || d->M < 256 || d->K < 128) return 0;
+  const bool geglu = (d->flags & MX_EPI_GEGLU) != 0, qkv = (d->flags & MX_EPI_QKV) != 0;
+  int best = 0;
+  long best_cost = 0;
+  const int cands[2] = {160, 128};
+  for (int c = 0; c < 2; ++c) {
+    const int bn = cands[c];
+    if (d->N % bn != 0) continue;
+    if (geglu && bn != 128) continue;
+    if (qkv && d->seg % (bn / 2) != 0) continue;
+    const long tiles = (long)cdiv(d->M, 256) * (d->N / bn);
+    const long cost = ((tiles + 255) / 256) * bn;
+    if (best == 0 || cost < best_cost) { best = bn; best_cost = cost; }
   }
+  return best;
 }
 
 static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
@@ -306,6 +229,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   MX_CHECK((long)d->M * (conv ? 1 : d->lda) < 2147483647L && (long)d->N * d->K < 2147483647L, "gemm: operand exceeds 32-bit indexing");
   if (d->residual) MX_CHECK(d->ldr >= d->N && d->ldr % 4 == 0, "gemm: bad ldr");
   const bool use128 = (d->N % 128 == 0);
+  const int v2bn = pick_v2_bn(d);
   if (d->flags & MX_EPI_GEGLU) {
     MX_CHECK(use128, "gemm: GEGLU needs N % 128 == 0");
     MX_CHECK(!(d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32)) && !d->residual && !d->rowbias, "gemm: GEGLU excludes other epilogues");
@@ -327,9 +251,12 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     const double flops = 2.0 * d->M * (double)d->N * kk;
     const double in_elems = conv ? (double)d->B * d->Hin * d->Win * d->Cin : (double)d->M * d->K;
     const double bytes = 2.0 * (in_elems + (double)d->N * d->K + (double)d->M * d->N);
-    prof_begin(s, (conv ? PROF_CONV128 : PROF_GEMM128) + ((d->N % 128 == 0) ? 0 : 1), flops, bytes, d->M, d->N, (int)kk);
+    const int kind = v2bn ? (conv ? PROF_CONV_V2 : PROF_GEMM_V2) : (conv ? PROF_CONV128 : PROF_GEMM128) + (use128 ? 0 : 1);
+    prof_begin(s, kind, flops, bytes, d->M, d->N, (int)kk);
   }
-  if (use128) {
+  if (v2bn) {
+    launch_v2(s, a, conv, v2bn);
+  } else if (use128) {
     dim3 grid(cdiv(d->M, BM), d->N / 128);
     if (conv) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel<128, false>), grid, block, 0, s, a);

@@ -38,7 +38,8 @@ def _conv_pack(w):
     return w.permute(0, 2, 3, 1).reshape(o, -1).contiguous()
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 128, 64), (200, 320, 192), (77 * 2, 256, 128), (1024, 640, 640), (130, 4, 576)])
+@pytest.mark.parametrize("m,n,k", [(256, 128, 64), (200, 320, 192), (77 * 2, 256, 128), (1024, 640, 640), (130, 4, 576),
+                                   (512, 320, 192), (700, 1280, 1280), (300, 2560, 128), (8192, 1280, 640)])
 def test_gemm_bias_residual(cuda_device, m, n, k):
     from sduss_amd import ops
     g = torch.Generator().manual_seed(m * 7 + n)
@@ -65,8 +66,14 @@ def test_gemm_rowbias(cuda_device):
 def test_gemm_geglu(cuda_device):
     from sduss_amd import ops
     from sduss_amd.weights import _geglu_interleave
+    _geglu_case(192, 64)
+    _geglu_case(600, 128)      # 256-row pipelined kernel
+
+
+def _geglu_case(m, dim):
+    from sduss_amd import ops
+    from sduss_amd.weights import _geglu_interleave
     g = torch.Generator().manual_seed(5)
-    m, dim = 192, 64
     a = _rt(torch.randn(m, dim, generator=g)); w = _rt(torch.randn(8 * dim, dim, generator=g) * dim ** -0.5)
     b = torch.randn(8 * dim, generator=g)
     hid, gate = (a @ w.t() + b).chunk(2, dim=-1)
@@ -76,11 +83,11 @@ def test_gemm_geglu(cuda_device):
     _close(got, want, 2.0 ** -7, "gemm+geglu")
 
 
-@pytest.mark.parametrize("period,rows,dim", [(3, 64, 128), (2, 77, 64), (3, 256, 64)])
+@pytest.mark.parametrize("period,rows,dim", [(3, 64, 128), (2, 77, 64), (3, 256, 64), (3, 256, 640), (2, 77, 320), (3, 512, 128)])
 def test_gemm_qkv_split(cuda_device, period, rows, dim):
     from sduss_amd import ops
     g = torch.Generator().manual_seed(period * 11 + rows)
-    nb, k, groups = 2, 128, 2 if period == 2 else 1
+    nb, k, groups = (2 if rows > 77 else 5), 128, 2 if period == 2 else 1
     n = groups * period * dim
     a = _rt(torch.randn(nb * rows, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
     full = a @ w.t()
@@ -94,7 +101,8 @@ def test_gemm_qkv_split(cuda_device, period, rows, dim):
 
 @pytest.mark.parametrize("stride,up,corner,hw,cin,cout", [(1, 0, 0, 16, 64, 128), (2, 0, 0, 16, 128, 64), (1, 1, 0, 8, 64, 64),
                                                           (1, 0, 4, 16, 64, 64), (2, 0, 8, 16, 64, 64), (1, 1, 8, 8, 64, 64),
-                                                          (1, 0, 0, 12, 192, 320)])
+                                                          (1, 0, 0, 12, 192, 320), (1, 0, 0, 16, 64, 640), (2, 0, 8, 32, 64, 320),
+                                                          (1, 1, 8, 16, 128, 160), (1, 0, 4, 16, 64, 256)])
 def test_conv3x3(cuda_device, stride, up, corner, hw, cin, cout):
     from sduss_amd import ops
     g = torch.Generator().manual_seed(stride * 100 + up * 10 + corner + cin)
