@@ -32,8 +32,8 @@ SDXL_FLOP_PER_SAMPLE_FORWARD = 6.76e12     # SURVEY.md section 8d (3.381 TMAC)
 MFMA_PEAK_BF16 = 2.5e15                    # dense, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<128,true> (conv3x3)",
-              "gemm_kernel<64,true> (conv3x3)", "attn_fwd_kernel", "groupnorm (3 kernels)", "gemm_v2_kernel<*,false>",
-              "gemm_v2_kernel<*,true> (conv3x3)"]
+              "gemm_kernel<64,true> (conv3x3)", "attn_fwd_kernel", "groupnorm (3 kernels)", "gemm_v2_kernel<160,false>",
+              "gemm_v2_kernel<160,true> (conv3x3)", "gemm_v2_kernel<128,false>", "gemm_v2_kernel<128,true> (conv3x3)"]
 
 
 def parse():
@@ -181,7 +181,7 @@ def main():
         l.mx_profile_enable(1)
         step()
         torch.cuda.synchronize()
-        buf = (C.c_double * 32)()
+        buf = (C.c_double * 40)()
         lib.check(l.mx_profile_collect(buf), "mx_profile_collect")
         l.mx_profile_enable(0)
         kinds = []

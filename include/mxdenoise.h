@@ -34,7 +34,8 @@ const char* mx_last_error(void);
 int mx_version(void);
 /* Optional per-launch timing for bench.py's roofline leg: while enabled, every GEMM / conv / attention / norm launch
  * is bracketed by hipEvents on its own stream.  mx_profile_collect (after the stream is synchronised) fills
- * out[32] = for kind in {gemm<128>, gemm<64>, conv3x3<128>, conv3x3<64>, attention, groupnorm, gemm_v2, conv3x3_v2}:
+ * out[40] = for kind in {gemm<128>, gemm<64>, conv3x3<128>, conv3x3<64>, attention, groupnorm, gemm_v2<160>,
+ *           conv3x3_v2<160>, gemm_v2<128>, conv3x3_v2<128>}:
  *           {launches, milliseconds, algorithmic flops, algorithmic bytes}. */
 int mx_profile_enable(int on);
 int mx_profile_collect(double* out);

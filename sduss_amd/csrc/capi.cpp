@@ -45,7 +45,7 @@ extern "C" int mx_profile_enable(int on) {
 }
 
 // Synchronises the recorded events (call after the stream has been synchronised) and sums, per kernel kind,
-// launches / milliseconds / algorithmic flops / algorithmic bytes.  out: double[4 * 8] = kind-major {n, ms, flops, bytes}.
+// launches / milliseconds / algorithmic flops / algorithmic bytes.  out: double[4 * 10] = kind-major {n, ms, flops, bytes}.
 extern "C" int mx_profile_collect(double* out) {
   MX_CHECK(out != nullptr, "profile_collect: null output");
   for (int i = 0; i < 4 * mx::PROF_KINDS; ++i) out[i] = 0.0;

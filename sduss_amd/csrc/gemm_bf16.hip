@@ -251,7 +251,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     const double flops = 2.0 * d->M * (double)d->N * kk;
     const double in_elems = conv ? (double)d->B * d->Hin * d->Win * d->Cin : (double)d->M * d->K;
     const double bytes = 2.0 * (in_elems + (double)d->N * d->K + (double)d->M * d->N);
-    const int kind = v2bn ? (conv ? PROF_CONV_V2 : PROF_GEMM_V2) : (conv ? PROF_CONV128 : PROF_GEMM128) + (use128 ? 0 : 1);
+    const int kind = v2bn ? (conv ? PROF_CONV_V2_160 : PROF_GEMM_V2_160) + (v2bn == 160 ? 0 : 2) : (conv ? PROF_CONV128 : PROF_GEMM128) + (use128 ? 0 : 1);
     prof_begin(s, kind, flops, bytes, d->M, d->N, (int)kk);
   }
   if (v2bn) {

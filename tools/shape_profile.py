@@ -15,7 +15,7 @@ from sduss_amd.pipeline import SDXLDenoiser, synthetic_request  # noqa: E402
 from sduss_amd.unet import MxUNet  # noqa: E402
 from sduss_amd.weights import synthetic_params  # noqa: E402
 
-KINDS = ["gemm128", "gemm64", "conv128", "conv64", "attn", "gnorm", "gemm_v2", "conv_v2"]
+KINDS = ["gemm128", "gemm64", "conv128", "conv64", "attn", "gnorm", "gemm_v2_160", "conv_v2_160", "gemm_v2_128", "conv_v2_128"]
 
 
 def main():
@@ -33,7 +33,7 @@ def main():
     l.mx_profile_enable(1)
     den.denoising_step({"1024": reqs})
     torch.cuda.synchronize()
-    buf = (C.c_double * 32)()
+    buf = (C.c_double * 40)()
     lib.check(l.mx_profile_collect(buf))
     l.mx_profile_enable(0)
     rec = (C.c_double * (6 * 4096))()
@@ -45,10 +45,10 @@ def main():
         a = agg.setdefault(key, [0, 0.0, 0.0])
         a[0] += 1; a[1] += ms; a[2] += fl
     tot = sum(a[1] for a in agg.values())
-    print(f"{'kernel':8s} {'M':>7s} {'N':>6s} {'K':>6s} {'n':>4s} {'ms':>8s} {'%':>6s} {'us/launch':>10s} {'TFLOP/s':>8s}")
+    print(f"{'kernel':11s} {'M':>7s} {'N':>6s} {'K':>6s} {'n':>4s} {'ms':>8s} {'%':>6s} {'us/launch':>10s} {'TFLOP/s':>8s}")
     for (kind, m, nn, k), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         tf = fl / (ms * 1e-3) / 1e12 if fl else 0.0
-        print(f"{kind:8s} {m:7d} {nn:6d} {k:6d} {cnt:4d} {ms:8.3f} {100 * ms / tot:6.2f} {1e3 * ms / cnt:10.1f} {tf:8.1f}")
+        print(f"{kind:11s} {m:7d} {nn:6d} {k:6d} {cnt:4d} {ms:8.3f} {100 * ms / tot:6.2f} {1e3 * ms / cnt:10.1f} {tf:8.1f}")
     print(f"total profiled {tot:.2f} ms")
 
 
