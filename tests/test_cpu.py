@@ -134,6 +134,32 @@ def test_bad_arguments_raise():
     assert l.mx_unet_create(None) is None
 
 
+def test_c_restatement_agrees_with_python_restatement():
+    """Two independent restatements of the native op (oracle/gn_halo_ref.c, oracle/patch_ref.py) must agree."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libgnhalo_ref.so"))
+    g = torch.Generator().manual_seed(4)
+    c, cpg = 16, 4
+    samples = {"256": torch.randn(1, c, 32, 32, generator=g), "384": torch.randn(2, c, 48, 48, generator=g)}
+    pidx, lo, _ro, patches, pm = patch_ref.split_sample(samples, 128)
+    x = patches[:, :, 1:-1, 1:-1].contiguous()
+    ga = torch.randn(c, generator=g); be = torch.randn(c, generator=g)
+    n, _, h, w = x.shape
+    fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int)
+    lo_t = torch.tensor(lo, dtype=torch.int32)
+    for padding in (1, 0):
+        want = patch_ref.groupnorm(x, ga, be, cpg, 1e-5, bool(padding), lo, pm, pidx)
+        out = torch.empty_like(want)
+        rc = lib.gnhalo_groupnorm(C.cast(x.data_ptr(), fp), C.cast(ga.data_ptr(), fp), C.cast(be.data_ptr(), fp),
+                                  C.cast(out.data_ptr(), fp), n, c, h, w, cpg, C.c_double(1e-5), padding,
+                                  C.cast(lo_t.data_ptr(), ip), C.cast(pm.data_ptr(), ip), C.cast(pidx.data_ptr(), ip))
+        assert rc == 0 and torch.allclose(out, want, atol=2e-5)
+    out = torch.empty(n, c, h + 2, w + 2)
+    lib.gnhalo_mock(C.cast(x.data_ptr(), fp), C.cast(out.data_ptr(), fp), C.cast(pidx.data_ptr(), ip), n, c, h, w)
+    assert torch.equal(out, patch_ref.mock_groupnorm(x, pidx))
+
+
 def test_geglu_interleave_layout():
     from sduss_amd.weights import _geglu_interleave
     t = torch.arange(8 * 64).float()          # dim 64: hidden rows 0..255, gate rows 256..511
