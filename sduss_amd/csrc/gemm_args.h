@@ -24,9 +24,26 @@ struct GemmArgs {
   int B, Hin, Win, Cin, Hout, Wout, stride, up, corner_patch;
 };
 
-template <int NI, int MI, int BN>
+// Residual values of the plain epilogue path, fetched by the caller BEFORE its main loop (older than every LDS-DMA, so the
+// kernel's counted vmcnt waits cover them and the HBM read hides under the K loop).
+template <int NI, int MI>
+__device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& p, u32x2 (&pre)[NI][MI], const int m_wave0,
+                                                       const int wave_n0, const int fr, const int fq) {
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m_wave0 + j * 16 + fr;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = wave_n0 + i * 16 + fq * 4;
+      pre[i][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n) : u32x2{0u, 0u};
+    }
+  }
+}
+
+template <int NI, int MI, int BN, bool PRE = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0,
-                                              const int wave_n0, const int fr, const int fq) {
+                                              const int wave_n0, const int fr, const int fq,
+                                              const u32x2 (*pre)[MI] = nullptr) {
   const int flags = p.flags;
   const bool geglu = (flags & MX_EPI_GEGLU) != 0;
   const bool qkv = (flags & MX_EPI_QKV) != 0;
@@ -69,7 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
           for (int q = 0; q < 4; ++q) g[q] += b4[q];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] * gelu_f(g[q]);
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * gelu_fast(g[q]);
         const int nout = wave_n0 / 2 + i * 16 + fq * 4;
         u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + nout) = o;
@@ -81,7 +98,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
         for (int q = 0; q < 4; ++q) v[q] += b4[q];
       }
       if (p.residual) {
-        const u32x2 r = *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
+        u32x2 r;
+        if constexpr (PRE) r = pre[i][j];
+        else r = *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
         v[0] += bf16lo_to_f32(r[0]); v[1] += bf16hi_to_f32(r[0]);
         v[2] += bf16lo_to_f32(r[1]); v[3] += bf16hi_to_f32(r[1]);
       }

@@ -183,6 +183,8 @@ int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn);
 static int pick_v2_bn(const mx_gemm_desc* d) {
   static const bool disabled = [] { const char* e = getenv("MX_GEMM_V2"); return e && e[0] == '0'; }();
   if (disabled || d->M < 256 || d->K < 128) return 0;
+  // the pipelined kernel addresses its operands with 32-bit byte offsets from a uniform base
+  if ((long)d->M * d->lda * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
   const bool geglu = (d->flags & MX_EPI_GEGLU) != 0, qkv = (d->flags & MX_EPI_QKV) != 0;
   int best = 0;
   long best_cost = 0;
@@ -212,6 +214,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   a.rows_per_batch = d->rows_per_batch; a.flags = d->flags; a.seg = d->seg; a.period = d->period; a.ldvt = d->ldvt;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout;
   a.stride = d->stride; a.up = d->up; a.corner_patch = d->corner_patch;
+
   if (!conv) {
     MX_CHECK(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda must be >= K and a multiple of 8");
   } else {

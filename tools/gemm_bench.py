@@ -1,0 +1,60 @@
+"""GEMM / conv microbenchmark over the SDXL step shapes (random bf16 data), through the C ABI.
+Usage on the GPU box: MX_V2_VAR=1 python tools/gemm_bench.py"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sduss_amd import ops  # noqa: E402
+
+SHAPES = [  # (kind, M, N, K or (hw, cin))
+    ("gemm", 8192, 1280, 1280), ("gemm", 8192, 1280, 5120), ("gemm", 8192, 3840, 1280), ("geglu", 8192, 10240, 1280),
+    ("gemm", 32768, 640, 640), ("geglu", 32768, 5120, 640), ("gemm", 32768, 640, 2560),
+    ("conv", 8, 1280, (32, 1280)), ("conv", 8, 320, (128, 320)), ("conv", 8, 640, (64, 640)),
+]
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    print(f"MX_V2_VAR={os.environ.get('MX_V2_VAR', '0')} MX_GEMM_V2={os.environ.get('MX_GEMM_V2', '1')}")
+    for kind, m, n, k in SHAPES:
+        if kind == "conv":
+            hw, cin = k
+            x = torch.randn(m, hw, hw, cin, device=dev, generator=g).to(torch.bfloat16)
+            w = (torch.randn(n, 9 * cin, device=dev, generator=g) * (9 * cin) ** -0.5).to(torch.bfloat16)
+            bias = torch.randn(n, device=dev, generator=g)
+            t = bench(lambda: ops.conv3x3(x, w, bias))
+            fl = 2.0 * m * hw * hw * n * 9 * cin
+            label = f"conv  B{m} {hw}x{hw} {cin}->{n}"
+        else:
+            a = torch.randn(m, k, device=dev, generator=g).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev, generator=g) * k ** -0.5).to(torch.bfloat16)
+            bias = torch.randn(n, device=dev, generator=g)
+            if kind == "geglu":
+                t = bench(lambda: ops.gemm(a, w, bias, geglu=True))
+            else:
+                r = torch.randn(m, n, device=dev, generator=g).to(torch.bfloat16)
+                t = bench(lambda: ops.gemm(a, w, bias, residual=r))
+            fl = 2.0 * m * n * k
+            label = f"{kind:5s} M{m} N{n} K{k}"
+        print(f"{label:32s} {t * 1e6:9.1f} us  {fl / t / 1e12:8.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
