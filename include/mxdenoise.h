@@ -79,8 +79,10 @@ enum {
   MX_EPI_SILU     = 1 << 0,  /* out = silu(v) */
   MX_EPI_GEGLU    = 1 << 1,  /* weight rows interleaved [32 hidden | 32 gate]; out[M, N/2] = h * gelu(g) */
   MX_EPI_OUT_F32  = 1 << 2,  /* C is fp32 instead of bf16 */
-  MX_EPI_QKV      = 1 << 3   /* column segments of width seg: segment s with (s % period) == period-1
+  MX_EPI_QKV      = 1 << 3,  /* column segments of width seg: segment s with (s % period) == period-1
                                 is written transposed into vt[b][vcol][key]; others row-major, compacted */
+  MX_EPI_GELU_TANH = 1 << 4, /* out = gelu(v), tanh approximation (diffusers FeedForward "gelu-approximate") */
+  MX_EPI_RES_BCAST = 1 << 5  /* residual row = output row modulo rows_per_batch (positional table broadcast over the batch) */
 };
 
 typedef struct mx_gemm_desc {
@@ -103,6 +105,13 @@ typedef struct mx_gemm_desc {
   int up;                /* 1: input is nearest-upsampled x2 on the fly (Hout = 2*Hin) */
   int corner_patch;      /* >0: sliced-mode halo-corner rule with this patch edge (output-grid pixels
                             for stride 1, input-grid pixels for stride 2); 0: plain zero padding */
+  /* joint-sequence support (MMDiT): rows live in per-sample blocks of a longer sequence.
+   * input  row of m = (m / rows_per_batch) * a_batch_rows + a_row_off + m % rows_per_batch   (a_batch_rows > 0)
+   * output row of m = (m / rows_per_batch) * c_batch_rows + c_row_off + m % rows_per_batch   (c_batch_rows > 0);
+   * it addresses C, the residual and, under MX_EPI_QKV, the key index of vt (then ldvt >= c_batch_rows). */
+  int a_batch_rows, a_row_off, c_batch_rows, c_row_off;
+  const float* gate;     /* fp32 [M / rows_per_batch, ldg] or NULL: v = gate * (acc + bias) before the residual add */
+  int ldg;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -118,6 +127,15 @@ int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, c
 /* y = LayerNorm(x) * gamma + beta over the last dim C; x,y bf16 [M, C]; gamma/beta fp32 [C] */
 int mx_layernorm(void* stream, const void* x, void* y, const float* gamma, const float* beta,
                  int M, int C, float eps);
+
+/* AdaLN modulate: y = LayerNorm(x) * (1 + scale[b]) + shift[b] (no affine), optional second output y2 with
+ * (scale2, shift2) sharing the normalisation; x,y bf16 [M, C]; scale/shift fp32 rows with stride ldmod, b = row / rows_per_batch */
+int mx_layernorm_mod(void* stream, const void* x, void* y, void* y2, const float* scale, const float* shift,
+                     const float* scale2, const float* shift2, int ldmod, int M, int C, int rows_per_batch, float eps);
+/* in-place RMSNorm over every 64-wide head of rows (b*batch_rows + row_off + i), i < rows_per_batch, of a bf16 [*, ld] matrix;
+ * heads [0, heads_q) use weight wq[64], heads [heads_q, heads_total) use wk[64] (fp32) */
+int mx_rmsnorm_heads(void* stream, void* x, int ld, int nbatch, int rows_per_batch, int batch_rows, int row_off,
+                     int heads_total, int heads_q, const float* wq, const float* wk, float eps);
 
 /* NHWC GroupNorm (+ optional SiLU): x,y bf16 [B, H, W, C]; gamma/beta fp32 [C].
  * patch > 0 selects the reference's sliced statistics (average over patch x patch tiles of
@@ -182,6 +200,34 @@ int mx_unet_forward_trace(mx_unet* u, void* stream, const void* latents, int io_
                           size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * Outer boundary: the SD3.5 MMDiT in the ``transformer`` slot
+ * (PatchSD3Transformer2DModel.forward, sduss/model_executor/modules/SD3Transformer.py:60-262, invoked at
+ *  pipelines/stable_diffusion_3/pipeline_stable_diffusion_3_esymred.py:312-322).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mx_mmdit_config {
+  int patch_size, in_channels, out_channels;
+  int num_layers;               /* <= 64 */
+  int num_attention_heads;      /* head_dim is 64 */
+  int joint_attention_dim, pooled_projection_dim, pos_embed_max_size;
+  int dual_attention[64];       /* 1 where the block has the second, image-only attention (SD3.5 dual_attention_layers) */
+  float norm_eps;
+} mx_mmdit_config;
+
+typedef struct mx_mmdit mx_mmdit;
+mx_mmdit* mx_mmdit_create(const mx_mmdit_config* cfg);
+void mx_mmdit_destroy(mx_mmdit* u);
+int mx_mmdit_set_weights(mx_mmdit* u, const void* blob, uint64_t blob_bytes, const mx_weight_entry* table, int n_entries);
+size_t mx_mmdit_workspace_bytes(const mx_mmdit* u, int batch, int H, int W, int ctx_len);
+int mx_mmdit_validate(const mx_mmdit* u, int batch, int H, int W, int ctx_len);
+/* latents [batch, in_channels, H, W] of io_dtype (NCHW); timesteps fp32 [batch]; ehs bf16 [batch, ctx_len, joint_attention_dim];
+ * pooled bf16 [batch, pooled_projection_dim]; out [batch, out_channels, H, W] of io_dtype */
+int mx_mmdit_forward(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
+                     const void* pooled, void* out, int batch, int H, int W, int ctx_len, void* workspace, size_t workspace_bytes);
+int mx_mmdit_forward_trace(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
+                           const void* pooled, void* out, int batch, int H, int W, int ctx_len, void* workspace,
+                           size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes);
+
+/* ------------------------------------------------------------------------------------------
  * The element-wise steps either side of the model call.
  * ------------------------------------------------------------------------------------------ */
 /* out[b] = x[b mod n_lat] / sqrt(sigma[b mod n_lat]^2 + 1) for b in [0, n_rows)   (batch_scale_model_input, CFG
@@ -192,6 +238,11 @@ int mx_euler_scale_input(void* stream, const void* latents, void* out, const flo
  * noise: [2*n_lat, elems] = [uncond..., cond...] (guidance > 0) ; epsilon-prediction Euler step */
 int mx_cfg_euler_step(void* stream, const void* noise, void* latents, const float* sigma, const float* sigma_next,
                       float guidance_scale, int n_lat, int64_t elems_per_latent, int dtype);
+
+/* latents <- latents + (sigma_next - sigma) * (u + g (t - u))   (FlowMatchEulerDiscreteScheduler.batch_step,
+ * schedulers/scheduling_flow_match_euler_discrete.py:159-202; CFG combine pipeline_stable_diffusion_3_esymred.py:365-367) */
+int mx_cfg_flow_step(void* stream, const void* noise, void* latents, const float* sigma, const float* sigma_next,
+                     float guidance_scale, int n_lat, int64_t elems_per_latent, int dtype);
 
 #ifdef __cplusplus
 }

@@ -151,3 +151,94 @@ def param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
     s["conv_norm_out.weight"] = (ch[0],); s["conv_norm_out.bias"] = (ch[0],)
     s["conv_out.weight"] = (cfg.out_channels, ch[0], 3, 3); s["conv_out.bias"] = (cfg.out_channels,)
     return s
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SD3.5 MMDiT (transformer/config.json of stabilityai/stable-diffusion-3.5-medium)
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class MMDiTConfig:
+    sample_size: int = 128
+    patch_size: int = 2
+    in_channels: int = 16
+    out_channels: int = 16
+    num_layers: int = 24
+    attention_head_dim: int = 64
+    num_attention_heads: int = 24
+    joint_attention_dim: int = 4096
+    caption_projection_dim: int = 1536
+    pooled_projection_dim: int = 2048
+    pos_embed_max_size: int = 384
+    dual_attention_layers: Tuple[int, ...] = tuple(range(13))
+    norm_eps: float = 1e-6
+
+    @property
+    def dim(self) -> int:
+        return self.attention_head_dim * self.num_attention_heads
+
+    @staticmethod
+    def sd35_medium() -> "MMDiTConfig":
+        return MMDiTConfig()
+
+    @staticmethod
+    def tiny() -> "MMDiTConfig":
+        return MMDiTConfig(sample_size=16, num_layers=4, num_attention_heads=2, joint_attention_dim=128,
+                           caption_projection_dim=128, pooled_projection_dim=64, pos_embed_max_size=24,
+                           dual_attention_layers=(0, 1))
+
+    @staticmethod
+    def from_hf_json(path: str) -> "MMDiTConfig":
+        with open(path) as f:
+            c = json.load(f)
+        return MMDiTConfig(sample_size=c["sample_size"], patch_size=c["patch_size"], in_channels=c["in_channels"],
+                           out_channels=c.get("out_channels", c["in_channels"]), num_layers=c["num_layers"],
+                           attention_head_dim=c["attention_head_dim"], num_attention_heads=c["num_attention_heads"],
+                           joint_attention_dim=c["joint_attention_dim"], caption_projection_dim=c["caption_projection_dim"],
+                           pooled_projection_dim=c["pooled_projection_dim"], pos_embed_max_size=c["pos_embed_max_size"],
+                           dual_attention_layers=tuple(c.get("dual_attention_layers", ())))
+
+
+def mmdit_param_shapes(cfg: MMDiTConfig) -> Dict[str, Tuple[int, ...]]:
+    """{HF state-dict key: shape} of transformer/diffusion_pytorch_model.safetensors."""
+    d = cfg.dim
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(name, n, k):
+        s[f"{name}.weight"] = (n, k)
+        s[f"{name}.bias"] = (n,)
+
+    s["pos_embed.pos_embed"] = (1, cfg.pos_embed_max_size ** 2, d)
+    s["pos_embed.proj.weight"] = (d, cfg.in_channels, cfg.patch_size, cfg.patch_size)
+    s["pos_embed.proj.bias"] = (d,)
+    lin("time_text_embed.timestep_embedder.linear_1", d, 256)
+    lin("time_text_embed.timestep_embedder.linear_2", d, d)
+    lin("time_text_embed.text_embedder.linear_1", d, cfg.pooled_projection_dim)
+    lin("time_text_embed.text_embedder.linear_2", d, d)
+    lin("context_embedder", d, cfg.joint_attention_dim)
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}"
+        last = i == cfg.num_layers - 1
+        dual = i in cfg.dual_attention_layers
+        lin(f"{b}.norm1.linear", (9 if dual else 6) * d, d)
+        lin(f"{b}.norm1_context.linear", (2 if last else 6) * d, d)
+        for nm in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj"):
+            lin(f"{b}.attn.{nm}", d, d)
+        for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            s[f"{b}.attn.{nm}.weight"] = (cfg.attention_head_dim,)
+        lin(f"{b}.attn.to_out.0", d, d)
+        if not last:
+            lin(f"{b}.attn.to_add_out", d, d)
+        if dual:
+            for nm in ("to_q", "to_k", "to_v"):
+                lin(f"{b}.attn2.{nm}", d, d)
+            for nm in ("norm_q", "norm_k"):
+                s[f"{b}.attn2.{nm}.weight"] = (cfg.attention_head_dim,)
+            lin(f"{b}.attn2.to_out.0", d, d)
+        lin(f"{b}.ff.net.0.proj", 4 * d, d)
+        lin(f"{b}.ff.net.2", d, 4 * d)
+        if not last:
+            lin(f"{b}.ff_context.net.0.proj", 4 * d, d)
+            lin(f"{b}.ff_context.net.2", d, 4 * d)
+    lin("norm_out.linear", 2 * d, d)
+    lin("proj_out", cfg.patch_size ** 2 * cfg.out_channels, d)
+    return s

@@ -44,6 +44,11 @@ __device__ __forceinline__ float erf_as(float x) {
   const float r = 1.0f - p * t * __expf(-ax * ax);
   return copysignf(r, x);
 }
+// tanh-approximated GELU (torch F.gelu(approximate="tanh")): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2u)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -216,3 +216,132 @@ extern "C" int mx_cfg_euler_step(void* stream, const void* noise, void* latents,
   MX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// MMDiT edge kernels (SD3Transformer.py:82-83, 250-259; scheduling_flow_match_euler_discrete.py:186-196)
+// ------------------------------------------------------------------------------------------
+namespace mx {
+
+// PatchEmbed im2col: latents NCHW -> tokens [B*h*w, ps*ps*C] bf16, k = (dy*ps + dx)*C + c
+template <typename T>
+__global__ void patchify_kernel(const T* __restrict__ in, bf16_t* __restrict__ out, int B, int Cc, int H, int W, int ps) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = ps * ps * Cc;
+  const int h = H / ps, w = W / ps;
+  if (idx >= (long)B * h * w * K) return;
+  const int k = (int)(idx % K);
+  const long tok = idx / K;
+  const int c = k % Cc;
+  const int dd = k / Cc;
+  const int dy = dd / ps, dx = dd % ps;
+  const int x = (int)(tok % w);
+  const int y = (int)((tok / w) % h);
+  const int b = (int)(tok / ((long)w * h));
+  out[idx] = f32_to_bf16(load_as_f32<T>(in, (((long)b * Cc + c) * H + y * ps + dy) * W + x * ps + dx));
+}
+
+// tokens [B*h*w, ld] (first ps*ps*C columns, (p, q, c) order) -> NCHW [B, C, h*ps, w*ps]   ("nhwpqc->nchpwq")
+template <typename T>
+__global__ void unpatchify_kernel(const bf16_t* __restrict__ in, T* __restrict__ out, int B, int Cc, int H, int W, int ps, int ld) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*H*W
+  if (idx >= (long)B * Cc * H * W) return;
+  const int X = (int)(idx % W);
+  const int Y = (int)((idx / W) % H);
+  const int c = (int)((idx / ((long)W * H)) % Cc);
+  const int b = (int)(idx / ((long)W * H * Cc));
+  const int w = W / ps, h = H / ps;
+  const long tok = ((long)b * h + Y / ps) * w + X / ps;
+  const int k = ((Y % ps) * ps + (X % ps)) * Cc + c;
+  store_from_f32<T>(out, idx, bf16_to_f32(in[tok * ld + k]));
+}
+
+// rows (top + y, left + x) of a [m, m, d] table -> [h*w, d]   (PatchEmbed.cropped_pos_embed)
+__global__ void crop_pos_kernel(const bf16_t* __restrict__ table, bf16_t* __restrict__ out, int m, int h, int w, int d) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // 16-byte chunks
+  const int chunks = d / 8;
+  if (idx >= (long)h * w * chunks) return;
+  const int ch = (int)(idx % chunks);
+  const long tok = idx / chunks;
+  const int x = (int)(tok % w), y = (int)(tok / w);
+  const int top = (m - h) / 2, left = (m - w) / 2;
+  const long src = ((long)(top + y) * m + left + x) * d + ch * 8;
+  *reinterpret_cast<u32x4*>(out + idx * 8) = *reinterpret_cast<const u32x4*>(table + src);
+}
+
+// [cos | sin] sinusoid of one scalar per row (Timesteps(dim, flip_sin_to_cos=True, freq_shift 0)), bf16 out
+__global__ void sinus_embed_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int dim) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dim) return;
+  const int half = dim / 2;
+  const int j = (i < half) ? i : i - half;
+  const float ang = t[b] * __expf(-9.210340371976184f * (float)j / (float)half);
+  out[(long)b * dim + i] = f32_to_bf16((i < half) ? cosf(ang) : sinf(ang));
+}
+
+// CFG combine + flow-match Euler step: x <- x + (sigma_next - sigma) * v, fp32 math
+template <typename T>
+__global__ void cfg_flow_step_kernel(const T* __restrict__ noise, T* __restrict__ lat, const float* __restrict__ sigma,
+                                     const float* __restrict__ sigma_next, float g, int n_lat, long elems) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_lat * elems) return;
+  const int row = (int)(idx / elems);
+  float v;
+  if (g > 0.f) {
+    const float u = load_as_f32<T>(noise, idx);
+    const float t = load_as_f32<T>(noise, (long)n_lat * elems + idx);
+    v = rnd<T>(__fadd_rn(u, rnd<T>(__fmul_rn(g, rnd<T>(__fsub_rn(t, u))))));   // pipeline_stable_diffusion_3_esymred.py:365-367
+  } else {
+    v = load_as_f32<T>(noise, idx);
+  }
+  const float x = load_as_f32<T>(lat, idx);
+  store_from_f32<T>(lat, idx, __fadd_rn(x, __fmul_rn(__fsub_rn(sigma_next[row], sigma[row]), v)));
+}
+
+int launch_patchify(hipStream_t s, const void* in, int dtype, void* out, int B, int C, int H, int W, int ps) {
+  const long total = (long)B * H * W * C;
+  dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+  if (dtype == MX_F32) hipLaunchKernelGGL((patchify_kernel<float>), grid, block, 0, s, (const float*)in, (bf16_t*)out, B, C, H, W, ps);
+  else if (dtype == MX_F16) hipLaunchKernelGGL((patchify_kernel<_Float16>), grid, block, 0, s, (const _Float16*)in, (bf16_t*)out, B, C, H, W, ps);
+  else if (dtype == MX_BF16) hipLaunchKernelGGL((patchify_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)in, (bf16_t*)out, B, C, H, W, ps);
+  else MX_CHECK(false, "patchify: bad dtype");
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_unpatchify(hipStream_t s, const void* in, void* out, int dtype, int B, int C, int H, int W, int ps, int ld) {
+  const long total = (long)B * H * W * C;
+  dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+  if (dtype == MX_F32) hipLaunchKernelGGL((unpatchify_kernel<float>), grid, block, 0, s, (const bf16_t*)in, (float*)out, B, C, H, W, ps, ld);
+  else if (dtype == MX_F16) hipLaunchKernelGGL((unpatchify_kernel<_Float16>), grid, block, 0, s, (const bf16_t*)in, (_Float16*)out, B, C, H, W, ps, ld);
+  else if (dtype == MX_BF16) hipLaunchKernelGGL((unpatchify_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)in, (bf16_t*)out, B, C, H, W, ps, ld);
+  else MX_CHECK(false, "unpatchify: bad dtype");
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_crop_pos(hipStream_t s, const void* table, void* out, int m, int h, int w, int d) {
+  MX_CHECK(d % 8 == 0 && h <= m && w <= m, "crop_pos: bad geometry");
+  const long total = (long)h * w * (d / 8);
+  hipLaunchKernelGGL(crop_pos_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, (const bf16_t*)table, (bf16_t*)out, m, h, w, d);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_sinus_embed(hipStream_t s, const float* t, void* out, int B, int dim) {
+  hipLaunchKernelGGL(sinus_embed_kernel, dim3(cdiv(dim, 256), B), dim3(256), 0, s, t, (bf16_t*)out, dim);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mx
+
+extern "C" int mx_cfg_flow_step(void* stream, const void* noise, void* latents, const float* sigma, const float* sigma_next,
+                                float guidance_scale, int n_lat, int64_t elems, int dtype) {
+  MX_CHECK(noise && latents && sigma && sigma_next && n_lat > 0 && elems > 0, "cfg_flow_step: bad arguments");
+  const long total = (long)n_lat * elems;
+  dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MX_F32) hipLaunchKernelGGL((cfg_flow_step_kernel<float>), grid, block, 0, s, (const float*)noise, (float*)latents, sigma, sigma_next, guidance_scale, n_lat, (long)elems);
+  else if (dtype == MX_F16) hipLaunchKernelGGL((cfg_flow_step_kernel<_Float16>), grid, block, 0, s, (const _Float16*)noise, (_Float16*)latents, sigma, sigma_next, guidance_scale, n_lat, (long)elems);
+  else if (dtype == MX_BF16) hipLaunchKernelGGL((cfg_flow_step_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)noise, (bf16_t*)latents, sigma, sigma_next, guidance_scale, n_lat, (long)elems);
+  else MX_CHECK(false, "cfg_flow_step: bad dtype");
+  MX_LAUNCH_CHECK();
+  return 0;
+}

@@ -22,7 +22,21 @@ struct GemmArgs {
   int flags;
   int seg, period, ldvt;
   int B, Hin, Win, Cin, Hout, Wout, stride, up, corner_patch;
+  int a_batch_rows, a_row_off, c_batch_rows, c_row_off;
+  const float* gate;
+  int ldg;
 };
+
+// row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)
+__device__ __forceinline__ long gemm_in_row(const GemmArgs& p, int m) {
+  if (p.a_batch_rows <= 0) return m;
+  const int b = m / p.rows_per_batch;
+  return (long)b * p.a_batch_rows + p.a_row_off + (m - b * p.rows_per_batch);
+}
+__device__ __forceinline__ long gemm_out_row(const GemmArgs& p, int m, int bidx) {
+  if (p.c_batch_rows <= 0) return m;
+  return (long)bidx * p.c_batch_rows + p.c_row_off + (m - bidx * p.rows_per_batch);
+}
 
 // Residual values of the plain epilogue path, fetched by the caller BEFORE its main loop (older than every LDS-DMA, so the
 // kernel's counted vmcnt waits cover them and the HBM read hides under the K loop).
@@ -35,7 +49,12 @@ __device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& p, u32x2 
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int n = wave_n0 + i * 16 + fq * 4;
-      pre[i][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n) : u32x2{0u, 0u};
+      long rr = m;
+      if (m < p.M) {
+        const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
+        rr = (p.flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
+      }
+      pre[i][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const u32x2*>(p.residual + rr * p.ldr + n) : u32x2{0u, 0u};
     }
   }
 }
@@ -62,6 +81,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
     const int m = m_wave0 + j * 16 + fr;
     if (m >= p.M) continue;
     const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
+    const long orow = gemm_out_row(p, m, bidx);
+    const long rrow = (flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : orow;
 #pragma unroll
     for (int i = 0; i < (NI); ++i) {
       if (geglu && i >= NI / 2) continue;
@@ -97,10 +118,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += b4[q];
       }
+      if (p.gate) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gate + (long)bidx * p.ldg + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= g4[q];
+      }
       if (p.residual) {
         u32x2 r;
         if constexpr (PRE) r = pre[i][j];
-        else r = *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
+        else r = *reinterpret_cast<const u32x2*>(p.residual + rrow * p.ldr + n);
         v[0] += bf16lo_to_f32(r[0]); v[1] += bf16hi_to_f32(r[0]);
         v[2] += bf16lo_to_f32(r[1]); v[3] += bf16hi_to_f32(r[1]);
       }
@@ -108,10 +134,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
       }
+      if (flags & MX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gelu_tanh_f(v[q]);
+      }
       if (qkv) {
         const int nin = n - seg_idx * p.seg;  // position inside the segment
         if (to_vt) {
-          const int key = m - bidx * p.rows_per_batch;
+          const int key = (p.c_batch_rows > 0 ? p.c_row_off : 0) + m - bidx * p.rows_per_batch;
           const int nv = p.N / p.period;
           bf16_t* dst = p.vt + ((long)bidx * nv + (long)seg_grp * p.seg + nin) * p.ldvt + key;
 #pragma unroll
@@ -119,16 +149,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
         } else {
           const int ccol = seg_grp * (p.period - 1) * p.seg + seg_pos * p.seg + nin;
           u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + ccol) = o;
+          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + ccol) = o;
         }
         continue;
       }
       if (flags & MX_EPI_OUT_F32) {
         f32x4 o = {v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + (long)m * p.ldc + n) = o;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + orow * p.ldc + n) = o;
       } else {
         u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + n) = o;
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + n) = o;
       }
     }
   }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + srow + 32 * i;
     if constexpr (!CONV) {
-      xoff[i] = (m < p.M) ? m * p.lda + sch * 8 : -1;
+      xoff[i] = (m < p.M) ? (int)(gemm_in_row(p, m) * p.lda) + sch * 8 : -1;
     } else {
       if (m < p.M) {
         const int hw = p.Hout * p.Wout;
@@ -184,7 +184,8 @@ static int pick_v2_bn(const mx_gemm_desc* d) {
   static const bool disabled = [] { const char* e = getenv("MX_GEMM_V2"); return e && e[0] == '0'; }();
   if (disabled || d->M < 256 || d->K < 128) return 0;
   // the pipelined kernel addresses its operands with 32-bit byte offsets from a uniform base
-  if ((long)d->M * d->lda * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
+  const long in_rows = d->a_batch_rows > 0 ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
+  if (in_rows * d->lda * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
   const bool geglu = (d->flags & MX_EPI_GEGLU) != 0, qkv = (d->flags & MX_EPI_QKV) != 0;
   int best = 0;
   long best_cost = 0;
@@ -214,6 +215,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   a.rows_per_batch = d->rows_per_batch; a.flags = d->flags; a.seg = d->seg; a.period = d->period; a.ldvt = d->ldvt;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout;
   a.stride = d->stride; a.up = d->up; a.corner_patch = d->corner_patch;
+  a.a_batch_rows = d->a_batch_rows; a.a_row_off = d->a_row_off; a.c_batch_rows = d->c_batch_rows; a.c_row_off = d->c_row_off;
+  a.gate = d->gate; a.ldg = d->ldg;
 
   if (!conv) {
     MX_CHECK(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda must be >= K and a multiple of 8");
@@ -227,9 +230,16 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
              "conv3x3: output grid does not match input grid / stride");
     MX_CHECK((long)d->B * d->Hout * d->Wout == d->M, "conv3x3: M != B*Hout*Wout");
   }
-  if (d->rowbias || (d->flags & MX_EPI_QKV)) MX_CHECK(d->rows_per_batch > 0, "gemm: rows_per_batch required");
+  if (d->rowbias || d->gate || d->a_batch_rows > 0 || d->c_batch_rows > 0 || (d->flags & (MX_EPI_QKV | MX_EPI_RES_BCAST)))
+    MX_CHECK(d->rows_per_batch > 0, "gemm: rows_per_batch required");
+  if (d->gate) MX_CHECK(d->ldg >= d->N && d->ldg % 4 == 0, "gemm: bad ldg");
+  if (d->a_batch_rows > 0) MX_CHECK(!conv && d->a_row_off >= 0 && d->a_row_off + d->rows_per_batch <= d->a_batch_rows, "gemm: bad input row remap");
+  if (d->c_batch_rows > 0) MX_CHECK(d->c_row_off >= 0 && d->c_row_off + d->rows_per_batch <= d->c_batch_rows, "gemm: bad output row remap");
   if (d->rowbias) MX_CHECK(d->ldrb >= d->N && d->ldrb % 4 == 0, "gemm: bad ldrb");
-  MX_CHECK((long)d->M * (conv ? 1 : d->lda) < 2147483647L && (long)d->N * d->K < 2147483647L, "gemm: operand exceeds 32-bit indexing");
+  {
+    const long in_rows = (!conv && d->a_batch_rows > 0) ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
+    MX_CHECK(in_rows * (conv ? 1 : d->lda) < 2147483647L && (long)d->N * d->K < 2147483647L, "gemm: operand exceeds 32-bit indexing");
+  }
   if (d->residual) MX_CHECK(d->ldr >= d->N && d->ldr % 4 == 0, "gemm: bad ldr");
   const bool use128 = (d->N % 128 == 0);
   const int v2bn = pick_v2_bn(d);
@@ -239,7 +249,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(d->ldc >= d->N / 2 && d->ldc % 4 == 0, "gemm: bad ldc for GEGLU");
   } else if (d->flags & MX_EPI_QKV) {
     MX_CHECK(d->seg > 0 && d->seg % 64 == 0 && d->period >= 2 && d->N % (d->seg * d->period) == 0, "gemm: bad QKV segments");
-    MX_CHECK(d->vt != nullptr && d->ldvt >= d->rows_per_batch, "gemm: QKV needs vt and ldvt >= rows_per_batch");
+    MX_CHECK(d->vt != nullptr && d->ldvt >= (d->c_batch_rows > 0 ? d->c_batch_rows : d->rows_per_batch), "gemm: QKV needs vt and ldvt >= keys per batch");
     MX_CHECK(d->M % d->rows_per_batch == 0, "gemm: QKV needs M % rows_per_batch == 0");
     MX_CHECK(d->ldc >= d->N / d->period * (d->period - 1) && d->ldc % 4 == 0, "gemm: bad ldc for QKV");
     MX_CHECK(!(d->flags & MX_EPI_OUT_F32), "gemm: QKV output is bf16");

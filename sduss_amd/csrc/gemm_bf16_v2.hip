@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
     const int m = m0 + row;
     if constexpr (!CONV) {
       const int mc = m < p.M ? m : p.M - 1;   // clamped rows are computed and discarded by the epilogue mask
-      xoff[i] = (unsigned)(((long)mc * p.lda + ch * 8) * 2);
+      xoff[i] = (unsigned)((gemm_in_row(p, mc) * p.lda + ch * 8) * 2);
     } else {
       xchb[i] = ch * 16;
       if (m < p.M) {

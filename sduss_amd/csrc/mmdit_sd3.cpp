@@ -1,0 +1,338 @@
+// Step plan of the SD3.5 MMDiT in the sduss ``transformer`` slot: a flat launch sequence on one HIP stream over
+// token-major bf16 activations in a caller-provided workspace.
+//
+// Replaces PatchSD3Transformer2DModel.forward (sduss/model_executor/modules/SD3Transformer.py:60-262) and the blocks it
+// drives (PatchJointTransformerBlock modules/transformer.py:299-388, PatchSD3Attention modules/attention.py:241-424).
+// With the block cache off the reference's sliced branch only re-chunks and regroups the token axis, so one plan serves
+// is_sliced True and False (oracle/sd3_mmdit_ref.py).
+// MI355X-first choices:
+//   * every AdaLN projection of the step (24 x norm1 / norm1_context + norm_out, 325 d columns) is ONE GEMM on
+//     silu(temb); LayerNorm-modulate kernels and GEMM epilogues (gated residual) read their fp32 rows from it;
+//   * image and text tokens share one joint Q|K buffer, one V^T buffer and one O buffer per step: the two QKV GEMMs
+//     write their rows straight into the joint sequence (row remap in the epilogue, V transposed), so the joint
+//     attention of attention.py:347-350 is a single kernel launch with no torch.cat; to_out / to_add_out read their
+//     token ranges back through the loader's row remap;
+//   * PatchEmbed's 2x2 stride-2 conv is an im2col + GEMM whose epilogue adds bias and the cropped positional table.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mxdenoise.h"
+#include "common.h"
+
+namespace mx {
+int launch_patchify(hipStream_t s, const void* in, int dtype, void* out, int B, int C, int H, int W, int ps);
+int launch_unpatchify(hipStream_t s, const void* in, void* out, int dtype, int B, int C, int H, int W, int ps, int ld);
+int launch_crop_pos(hipStream_t s, const void* table, void* out, int m, int h, int w, int d);
+int launch_sinus_embed(hipStream_t s, const float* t, void* out, int B, int dim);
+}  // namespace mx
+
+using mx::bf16_t;
+
+struct mx_mmdit {
+  mx_mmdit_config cfg;
+  const char* blob = nullptr;
+  uint64_t blob_bytes = 0;
+  std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> table;
+};
+
+namespace {
+
+struct Arena {
+  char* base; size_t cap; size_t top; size_t peak; bool dry;
+  void* alloc(size_t bytes) {
+    const size_t a = (top + 255) & ~(size_t)255;
+    top = a + bytes;
+    if (top > peak) peak = top;
+    if (dry) return (void*)(uintptr_t)(0x1000 + a);
+    return (top <= cap) ? base + a : nullptr;
+  }
+};
+
+struct Plan {
+  mx_mmdit* u;
+  hipStream_t stream;
+  Arena ar;
+  int B, H, W, Lt;
+  bool dry, lookup = false;
+  const char* stage = nullptr; void* stage_out = nullptr; size_t stage_bytes = 0; bool stage_hit = false;
+  std::string err;
+
+  bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
+  bool ok() const { return err.empty(); }
+  const void* w(const std::string& name, size_t expect_bytes) {
+    if (dry && !lookup) return (const void*)(uintptr_t)0x1000;
+    auto it = u->table.find(name);
+    if (it == u->table.end()) { fail("missing weight '" + name + "'"); return nullptr; }
+    if (it->second.second != expect_bytes) {
+      fail("weight '" + name + "' has " + std::to_string(it->second.second) + " bytes, expected " + std::to_string(expect_bytes));
+      return nullptr;
+    }
+    return u->blob + it->second.first;
+  }
+  const bf16_t* wb(const std::string& name, size_t elems) { return (const bf16_t*)w(name, elems * 2); }
+  const float* wf(const std::string& name, size_t elems) { return (const float*)w(name, elems * 4); }
+  template <typename T> T* alloc(size_t elems) {
+    T* p = (T*)ar.alloc(elems * sizeof(T));
+    if (!p) fail("workspace too small");
+    return p;
+  }
+  bool gemm(mx_gemm_desc& d) {
+    if (!ok()) return false;
+    if (dry) return true;
+    if (mx_gemm(stream, &d)) return fail(std::string("gemm: ") + mx_last_error());
+    return true;
+  }
+  // C = A W^T + bias with the optional fused pieces
+  bool linear(const void* a, int lda, const std::string& name, void* c, int ldc, int M, int N, int K, int flags = 0,
+              const void* residual = nullptr, int ldr = 0, const float* gate = nullptr, int ldg = 0, int rows_per_batch = 0,
+              int a_batch_rows = 0, int a_row_off = 0) {
+    mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+    d.a = a; d.lda = lda; d.w = wb(name + ".weight", (size_t)N * K); d.bias = wf(name + ".bias", N);
+    d.c = c; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.flags = flags; d.residual = residual; d.ldr = ldr;
+    d.gate = gate; d.ldg = ldg; d.rows_per_batch = rows_per_batch; d.a_batch_rows = a_batch_rows; d.a_row_off = a_row_off;
+    return gemm(d);
+  }
+  // fused q|k|v projection of `rows_per_batch` tokens per sample into the joint buffers at row offset `row_off`
+  bool qkv(const void* a, const std::string& name, bf16_t* qk, bf16_t* vt, int ldvt, int M, int d_model, int rows_per_batch,
+           int joint_rows, int row_off) {
+    mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+    d.a = a; d.lda = d_model; d.w = wb(name + ".weight", (size_t)3 * d_model * d_model); d.bias = wf(name + ".bias", 3 * d_model);
+    d.c = qk; d.ldc = 2 * d_model; d.M = M; d.N = 3 * d_model; d.K = d_model; d.flags = MX_EPI_QKV; d.seg = d_model; d.period = 3;
+    d.vt = vt; d.ldvt = ldvt; d.rows_per_batch = rows_per_batch; d.c_batch_rows = joint_rows; d.c_row_off = row_off;
+    return gemm(d);
+  }
+  bool lnmod(const bf16_t* x, bf16_t* y, bf16_t* y2, const float* scale, const float* shift, const float* scale2,
+             const float* shift2, int ldmod, int M, int C, int rows_per_batch) {
+    if (!ok()) return false;
+    if (dry) return true;
+    if (mx_layernorm_mod(stream, x, y, y2, scale, shift, scale2, shift2, ldmod, M, C, rows_per_batch, u->cfg.norm_eps))
+      return fail(std::string("layernorm_mod: ") + mx_last_error());
+    return true;
+  }
+  bool rms(bf16_t* x, int ld, int rows_per_batch, int batch_rows, int row_off, int heads, const std::string& qname, const std::string& kname) {
+    if (!ok()) return false;
+    const float* wq = wf(qname, 64); const float* wk = wf(kname, 64);
+    if (!ok() || dry) return ok();
+    if (mx_rmsnorm_heads(stream, x, ld, B, rows_per_batch, batch_rows, row_off, 2 * heads, heads, wq, wk, u->cfg.norm_eps))
+      return fail(std::string("rmsnorm_heads: ") + mx_last_error());
+    return true;
+  }
+  bool attention(const bf16_t* qk, int d_model, const bf16_t* vt, int ldvt, bf16_t* o, int heads, int L) {
+    if (!ok()) return false;
+    if (dry) return true;
+    if (mx_attention(stream, qk, 2 * d_model, qk + d_model, 2 * d_model, vt, ldvt, (int64_t)d_model * ldvt, o, d_model, B, heads, L, L, 0.125f))
+      return fail(std::string("attention: ") + mx_last_error());
+    return true;
+  }
+  void dump(const std::string& name, const bf16_t* t, size_t elems) {
+    if (!stage || dry || !ok() || stage_hit) return;
+    if (name != stage) return;
+    if (elems * 2 > stage_bytes) { fail("stage buffer too small for '" + name + "'"); return; }
+    if (hipMemcpyAsync(stage_out, t, elems * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess) fail("stage copy failed");
+    stage_hit = true;
+  }
+
+  bool run(const void* latents, int io_dtype, const float* timesteps, const void* ehs, const void* pooled, void* outp) {
+    const mx_mmdit_config& c = u->cfg;
+    const int d = c.num_attention_heads * 64;
+    const int heads = c.num_attention_heads;
+    const int ps = c.patch_size;
+    const int h = H / ps, wd = W / ps;
+    const int L = h * wd;
+    const int Lj = L + Lt;
+    const int ldvt_j = (Lj + 7) / 8 * 8;
+    const int ldvt_i = (L + 7) / 8 * 8;
+    const int Kp = ps * ps * c.in_channels;
+    const int MI = B * L, MT = B * Lt;
+
+    // ---- AdaLN column layout of the one projection GEMM ----
+    std::vector<int> off_img(c.num_layers), off_ctx(c.num_layers);
+    int ntot = 0;
+    for (int i = 0; i < c.num_layers; ++i) {
+      const bool dual = c.dual_attention[i] != 0, last = i == c.num_layers - 1;
+      off_img[i] = ntot; ntot += (dual ? 9 : 6) * d;
+      off_ctx[i] = ntot; ntot += (last ? 2 : 6) * d;
+    }
+    const int off_out = ntot; ntot += 2 * d;
+
+    // ---- conditioning (SD3Transformer.py:81): temb = timestep_embedder(sinusoid(t)) + text_embedder(pooled) ----
+    bf16_t* tsin = alloc<bf16_t>((size_t)B * 256);
+    if (ok() && !dry && mx::launch_sinus_embed(stream, timesteps, tsin, B, 256)) fail(mx_last_error());
+    bf16_t* t1 = alloc<bf16_t>((size_t)B * d); bf16_t* t2 = alloc<bf16_t>((size_t)B * d);
+    bf16_t* p1 = alloc<bf16_t>((size_t)B * d); bf16_t* semb = alloc<bf16_t>((size_t)B * d);
+    linear(tsin, 256, "time_text_embed.timestep_embedder.linear_1", t1, d, B, d, 256, MX_EPI_SILU);
+    linear(t1, d, "time_text_embed.timestep_embedder.linear_2", t2, d, B, d, d);
+    linear(pooled, c.pooled_projection_dim, "time_text_embed.text_embedder.linear_1", p1, d, B, d, c.pooled_projection_dim, MX_EPI_SILU);
+    // silu(temb): every consumer of temb applies SiLU first (AdaLayerNormZero / ZeroX / Continuous)
+    linear(p1, d, "time_text_embed.text_embedder.linear_2", semb, d, B, d, d, MX_EPI_SILU, t2, d);
+    float* mod = alloc<float>((size_t)B * ntot);
+    linear(semb, d, "adaln_all", mod, ntot, B, ntot, d, MX_EPI_OUT_F32);
+
+    // ---- PatchEmbed + positional table (:82-83), context_embedder (:115) ----
+    bf16_t* patches = alloc<bf16_t>((size_t)MI * Kp);
+    if (ok() && !dry && mx::launch_patchify(stream, latents, io_dtype, patches, B, c.in_channels, H, W, ps)) fail(mx_last_error());
+    bf16_t* pos = alloc<bf16_t>((size_t)L * d);
+    {
+      const bf16_t* table = wb("pos_embed.table", (size_t)c.pos_embed_max_size * c.pos_embed_max_size * d);
+      if (ok() && !dry && mx::launch_crop_pos(stream, table, pos, c.pos_embed_max_size, h, wd, d)) fail(mx_last_error());
+    }
+    bf16_t* x = alloc<bf16_t>((size_t)MI * d);
+    linear(patches, Kp, "pos_embed.proj", x, d, MI, d, Kp, MX_EPI_RES_BCAST, pos, d, nullptr, 0, L);
+    bf16_t* ctx = alloc<bf16_t>((size_t)MT * d);
+    linear(ehs, c.joint_attention_dim, "context_embedder", ctx, d, MT, d, c.joint_attention_dim);
+    dump("embed", x, (size_t)MI * d);
+    dump("context_embed", ctx, (size_t)MT * d);
+
+    // ---- per-step buffers reused by every block ----
+    bf16_t* xin = alloc<bf16_t>((size_t)MI * d);
+    bf16_t* x2in = alloc<bf16_t>((size_t)MI * d);
+    bf16_t* cin = alloc<bf16_t>((size_t)MT * d);
+    bf16_t* qk_j = alloc<bf16_t>((size_t)B * Lj * 2 * d);
+    bf16_t* vt_j = alloc<bf16_t>((size_t)B * d * ldvt_j);
+    bf16_t* o_j = alloc<bf16_t>((size_t)B * Lj * d);
+    bf16_t* qk_i = alloc<bf16_t>((size_t)MI * 2 * d);
+    bf16_t* vt_i = alloc<bf16_t>((size_t)B * d * ldvt_i);
+    bf16_t* o_i = alloc<bf16_t>((size_t)MI * d);
+    bf16_t* ff = alloc<bf16_t>((size_t)MI * 4 * d);
+    bf16_t* ffc = alloc<bf16_t>((size_t)MT * 4 * d);
+
+    for (int i = 0; i < c.num_layers && ok(); ++i) {
+      const std::string b = "transformer_blocks." + std::to_string(i);
+      const bool dual = c.dual_attention[i] != 0, last = i == c.num_layers - 1;
+      const float* mi = mod + off_img[i];   // chunks: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp[, shift2, scale2, gate2]
+      const float* mc = mod + off_ctx[i];
+      // AdaLN-Zero(-X) on the image stream, AdaLN-Zero / -continuous on the context stream (transformer.py:316-328)
+      lnmod(x, xin, dual ? x2in : nullptr, mi + d, mi, dual ? mi + 7 * d : nullptr, dual ? mi + 6 * d : nullptr, ntot, MI, d, L);
+      if (last) lnmod(ctx, cin, nullptr, mc, mc + d, nullptr, nullptr, ntot, MT, d, Lt);        // continuous: (scale, shift)
+      else lnmod(ctx, cin, nullptr, mc + d, mc, nullptr, nullptr, ntot, MT, d, Lt);
+      // joint attention (attention.py:256-372): image rows first, then text rows
+      qkv(xin, b + ".attn.to_qkv", qk_j, vt_j, ldvt_j, MI, d, L, Lj, 0);
+      qkv(cin, b + ".attn.add_qkv", qk_j, vt_j, ldvt_j, MT, d, Lt, Lj, L);
+      rms(qk_j, 2 * d, L, Lj, 0, heads, b + ".attn.norm_q.weight", b + ".attn.norm_k.weight");
+      rms(qk_j, 2 * d, Lt, Lj, L, heads, b + ".attn.norm_added_q.weight", b + ".attn.norm_added_k.weight");
+      attention(qk_j, d, vt_j, ldvt_j, o_j, heads, Lj);
+      // x += gate_msa * to_out(attn[:, :L])                                   (transformer.py:344-345)
+      linear(o_j, d, b + ".attn.to_out.0", x, d, MI, d, d, 0, x, d, mi + 2 * d, ntot, L, Lj, 0);
+      if (dual) {                                                             // attn2: image-only self-attention (:347-357)
+        qkv(x2in, b + ".attn2.to_qkv", qk_i, vt_i, ldvt_i, MI, d, L, 0, 0);
+        rms(qk_i, 2 * d, L, L, 0, heads, b + ".attn2.norm_q.weight", b + ".attn2.norm_k.weight");
+        attention(qk_i, d, vt_i, ldvt_i, o_i, heads, L);
+        linear(o_i, d, b + ".attn2.to_out.0", x, d, MI, d, d, 0, x, d, mi + 8 * d, ntot, L);
+      }
+      // x += gate_mlp * ff(LN(x) * (1 + scale_mlp) + shift_mlp)               (:359-366)
+      lnmod(x, xin, nullptr, mi + 4 * d, mi + 3 * d, nullptr, nullptr, ntot, MI, d, L);
+      linear(xin, d, b + ".ff.net.0.proj", ff, 4 * d, MI, 4 * d, d, MX_EPI_GELU_TANH);
+      linear(ff, 4 * d, b + ".ff.net.2", x, d, MI, d, 4 * d, 0, x, d, mi + 5 * d, ntot, L);
+      if (!last) {                                                            // context stream (:371-386)
+        linear(o_j, d, b + ".attn.to_add_out", ctx, d, MT, d, d, 0, ctx, d, mc + 2 * d, ntot, Lt, Lj, L);
+        lnmod(ctx, cin, nullptr, mc + 4 * d, mc + 3 * d, nullptr, nullptr, ntot, MT, d, Lt);
+        linear(cin, d, b + ".ff_context.net.0.proj", ffc, 4 * d, MT, 4 * d, d, MX_EPI_GELU_TANH);
+        linear(ffc, 4 * d, b + ".ff_context.net.2", ctx, d, MT, d, 4 * d, 0, ctx, d, mc + 5 * d, ntot, Lt);
+        dump(b + ".context", ctx, (size_t)MT * d);
+      }
+      dump(b, x, (size_t)MI * d);
+    }
+    // ---- norm_out (AdaLN-continuous) + proj_out + unpatchify (SD3Transformer.py:238-259) ----
+    lnmod(x, xin, nullptr, mod + off_out, mod + off_out + d, nullptr, nullptr, ntot, MI, d, L);
+    const int No = ps * ps * c.out_channels;
+    bf16_t* o = alloc<bf16_t>((size_t)MI * No);
+    linear(xin, d, "proj_out", o, No, MI, No, d);
+    dump("proj_out", o, (size_t)MI * No);
+    if (ok() && !dry && mx::launch_unpatchify(stream, o, outp, io_dtype, B, c.out_channels, H, W, ps, No)) fail(mx_last_error());
+    if (stage && !dry && ok() && !stage_hit) fail(std::string("unknown stage '") + stage + "'");
+    return ok();
+  }
+};
+
+int check_cfg(const mx_mmdit_config* c) {
+  MX_CHECK(c != nullptr, "mmdit: null config");
+  MX_CHECK(c->num_layers >= 1 && c->num_layers <= 64, "mmdit: num_layers must be 1..64");
+  MX_CHECK(c->num_attention_heads >= 1, "mmdit: bad head count (head_dim is fixed at 64)");
+  MX_CHECK(c->patch_size >= 1 && (c->patch_size * c->patch_size * c->in_channels) % 64 == 0, "mmdit: patch_size^2 * in_channels must be a multiple of 64");
+  MX_CHECK((c->patch_size * c->patch_size * c->out_channels) % 4 == 0, "mmdit: bad out_channels");
+  MX_CHECK(c->joint_attention_dim % 64 == 0 && c->pooled_projection_dim % 64 == 0, "mmdit: conditioning widths must be multiples of 64");
+  MX_CHECK(c->pos_embed_max_size > 0, "mmdit: pos_embed_max_size required");
+  return 0;
+}
+
+int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
+                 const void* pooled, void* out, int batch, int H, int W, int ctx_len, void* workspace, size_t workspace_bytes,
+                 const char* stage, void* stage_out, size_t stage_bytes, bool dry, size_t* peak, bool lookup = false) {
+  MX_CHECK(u != nullptr, "mmdit: null handle");
+  MX_CHECK(batch > 0 && H > 0 && W > 0 && ctx_len > 0, "mmdit: bad shape");
+  MX_CHECK(H % u->cfg.patch_size == 0 && W % u->cfg.patch_size == 0, "mmdit: H, W must be multiples of patch_size");
+  MX_CHECK(H / u->cfg.patch_size <= u->cfg.pos_embed_max_size && W / u->cfg.patch_size <= u->cfg.pos_embed_max_size, "mmdit: latent larger than the positional table");
+  if (!dry) {
+    MX_CHECK(latents && timesteps && ehs && pooled && out && workspace, "mmdit: null operand");
+    MX_CHECK(u->blob != nullptr, "mmdit: weights not set");
+    MX_CHECK(io_dtype == MX_F32 || io_dtype == MX_F16 || io_dtype == MX_BF16, "mmdit: bad io dtype");
+  }
+  Plan p;
+  p.u = u; p.stream = (hipStream_t)stream; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
+  p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
+  p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
+  const bool okr = p.run(latents, io_dtype, timesteps, ehs, pooled, out);
+  if (peak) *peak = p.ar.peak;
+  if (!okr) { mx::set_error(p.err); return 1; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" mx_mmdit* mx_mmdit_create(const mx_mmdit_config* cfg) {
+  if (check_cfg(cfg)) return nullptr;
+  mx_mmdit* u = new mx_mmdit();
+  u->cfg = *cfg;
+  return u;
+}
+extern "C" void mx_mmdit_destroy(mx_mmdit* u) { delete u; }
+
+extern "C" int mx_mmdit_set_weights(mx_mmdit* u, const void* blob, uint64_t blob_bytes, const mx_weight_entry* table, int n) {
+  MX_CHECK(u && blob && table && n > 0, "mmdit_set_weights: bad arguments");
+  u->table.clear();
+  for (int i = 0; i < n; ++i) {
+    MX_CHECK(table[i].name != nullptr, "mmdit_set_weights: null name");
+    MX_CHECK(table[i].offset % 16 == 0, "mmdit_set_weights: tensor offsets must be 16-byte aligned");
+    MX_CHECK(table[i].offset + table[i].bytes <= blob_bytes, "mmdit_set_weights: entry exceeds blob");
+    u->table[table[i].name] = {table[i].offset, table[i].bytes};
+  }
+  u->blob = (const char*)blob;
+  u->blob_bytes = blob_bytes;
+  return 0;
+}
+
+extern "C" size_t mx_mmdit_workspace_bytes(const mx_mmdit* u, int batch, int H, int W, int ctx_len) {
+  if (!u) return 0;
+  size_t peak = 0;
+  if (forward_impl(const_cast<mx_mmdit*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, batch, H, W, ctx_len,
+                   nullptr, 0, nullptr, nullptr, 0, true, &peak))
+    return 0;
+  return peak + 4096;
+}
+
+extern "C" int mx_mmdit_validate(const mx_mmdit* u, int batch, int H, int W, int ctx_len) {
+  MX_CHECK(u && u->blob, "mmdit_validate: weights not set");
+  return forward_impl(const_cast<mx_mmdit*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, batch, H, W, ctx_len,
+                      nullptr, 0, nullptr, nullptr, 0, true, nullptr, true);
+}
+
+extern "C" int mx_mmdit_forward(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
+                                const void* ehs, const void* pooled, void* out, int batch, int H, int W, int ctx_len,
+                                void* workspace, size_t workspace_bytes) {
+  return forward_impl(u, stream, latents, io_dtype, timesteps, ehs, pooled, out, batch, H, W, ctx_len, workspace, workspace_bytes,
+                      nullptr, nullptr, 0, false, nullptr);
+}
+
+extern "C" int mx_mmdit_forward_trace(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
+                                      const void* ehs, const void* pooled, void* out, int batch, int H, int W, int ctx_len,
+                                      void* workspace, size_t workspace_bytes, const char* stage, void* stage_out,
+                                      size_t stage_out_bytes) {
+  MX_CHECK(stage && stage_out, "mmdit_forward_trace: stage and stage_out required");
+  return forward_impl(u, stream, latents, io_dtype, timesteps, ehs, pooled, out, batch, H, W, ctx_len, workspace, workspace_bytes,
+                      stage, stage_out, stage_out_bytes, false, nullptr);
+}

@@ -303,3 +303,157 @@ extern "C" int mx_layernorm(void* stream, const void* x, void* y, const float* g
   MX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// AdaLN modulate for the MMDiT blocks: y = LN(x) * (1 + scale[b]) + shift[b]  (LayerNorm without affine, eps 1e-6),
+// optionally a second output y2 with (scale2, shift2) sharing the normalisation (SD35AdaLayerNormZeroX).
+// Serves norm1 / norm1_context / norm2 / norm2_context / norm_out of PatchJointTransformerBlock
+// (modules/transformer.py:316-328, 359-360, 377-378; SD3Transformer.py:238).  scale/shift are fp32 rows of the one
+// AdaLN projection GEMM of the step (row stride ldmod).
+// ------------------------------------------------------------------------------------------
+namespace mx {
+
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                            bf16_t* __restrict__ y2, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ scale2,
+                                                            const float* __restrict__ shift2, int ldmod, int M, int C,
+                                                            int rows_per_batch, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C / 8;
+  const bf16_t* xr = x + (long)row * C;
+  float v[VPL][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const u32x4 u = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][2 * e] = bf16lo_to_f32(u[e]);
+        v[i][2 * e + 1] = bf16hi_to_f32(u[e]);
+        sum += v[i][2 * e] + v[i][2 * e + 1];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  const long mrow = (long)(row / rows_per_batch) * ldmod;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float n[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) n[e] = (v[i][e] - mean) * rstd;
+      {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + mrow + ch * 8);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + mrow + ch * 8 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + mrow + ch * 8);
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(shift + mrow + ch * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = n[e] * (1.f + s0[e]) + h0[e]; o[e + 4] = n[e + 4] * (1.f + s1[e]) + h1[e]; }
+        u32x4 u = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(y + (long)row * C + ch * 8) = u;
+      }
+      if (y2) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale2 + mrow + ch * 8);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale2 + mrow + ch * 8 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift2 + mrow + ch * 8);
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(shift2 + mrow + ch * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = n[e] * (1.f + s0[e]) + h0[e]; o[e + 4] = n[e + 4] * (1.f + s1[e]) + h1[e]; }
+        u32x4 u = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(y2 + (long)row * C + ch * 8) = u;
+      }
+    }
+  }
+}
+
+// RMSNorm over each 64-wide head of selected rows of a [rows, ld] bf16 matrix, in place:
+//   x[r, 64*h : 64*h+64] *= rsqrt(mean(x^2) + eps) * w[h < heads_q ? wq : wk]
+// 8 lanes x 16 bytes cover one head; a wave covers 8 heads of one row.  Serves norm_q / norm_k / norm_added_q /
+// norm_added_k (attention.py:332-346, 377-388; diffusers RMSNorm(64, eps 1e-6)).
+__global__ __launch_bounds__(256) void rmsnorm_heads_kernel(bf16_t* __restrict__ x, int ld, int nbatch, int rows_per_batch,
+                                                            int batch_rows, int row_off, int heads_total, int heads_q,
+                                                            const float* __restrict__ wq, const float* __restrict__ wk, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;       // 16-byte chunk inside the head
+  const int hl = lane >> 3;       // head inside the wave's group of 8
+  const int groups = (heads_total + 7) / 8;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)nbatch * rows_per_batch * groups;
+  if (wid >= total) return;
+  const int grp = (int)(wid % groups);
+  const long r = wid / groups;
+  const int b = (int)(r / rows_per_batch);
+  const long row = (long)b * batch_rows + row_off + (r - (long)b * rows_per_batch);
+  const int head = grp * 8 + hl;
+  const bool ok = head < heads_total;
+  bf16_t* p = x + row * ld + (ok ? head : 0) * 64 + sub * 8;
+  u32x4 u = *reinterpret_cast<const u32x4*>(p);
+  float v[8];
+  float sq = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[2 * e] = bf16lo_to_f32(u[e]); v[2 * e + 1] = bf16hi_to_f32(u[e]);
+    sq += v[2 * e] * v[2 * e] + v[2 * e + 1] * v[2 * e + 1];
+  }
+  sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+  const float rs = rsqrtf(sq * (1.0f / 64.0f) + eps);
+  const float* w = (head < heads_q ? wq : wk) + sub * 8;
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e] * rs * w[2 * e], v[2 * e + 1] * rs * w[2 * e + 1]);
+  if (ok) *reinterpret_cast<u32x4*>(p) = o;
+}
+
+}  // namespace mx
+
+extern "C" int mx_layernorm_mod(void* stream, const void* x, void* y, void* y2, const float* scale, const float* shift,
+                                const float* scale2, const float* shift2, int ldmod, int M, int C, int rows_per_batch, float eps) {
+  using namespace mx;
+  MX_CHECK(x && y && scale && shift, "layernorm_mod: null operand");
+  MX_CHECK(!y2 || (scale2 && shift2), "layernorm_mod: second output needs scale2/shift2");
+  MX_CHECK(C % 8 == 0 && C <= 64 * 8 * 8, "layernorm_mod: C must be a multiple of 8 and <= 4096");
+  MX_CHECK(rows_per_batch > 0 && M % rows_per_batch == 0 && ldmod % 4 == 0, "layernorm_mod: bad batch geometry");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(M, 4)), block(256);
+  const int vpl = cdiv(C / 8, 64);
+  const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y; bf16_t* y2p = (bf16_t*)y2;
+#define MX_LNMOD(V) hipLaunchKernelGGL((layernorm_mod_kernel<V>), grid, block, 0, s, xp, yp, y2p, scale, shift, scale2, shift2, ldmod, M, C, rows_per_batch, eps)
+  if (vpl <= 1) MX_LNMOD(1); else if (vpl <= 2) MX_LNMOD(2); else if (vpl <= 3) MX_LNMOD(3); else if (vpl <= 4) MX_LNMOD(4); else MX_LNMOD(8);
+#undef MX_LNMOD
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mx_rmsnorm_heads(void* stream, void* x, int ld, int nbatch, int rows_per_batch, int batch_rows, int row_off,
+                                int heads_total, int heads_q, const float* wq, const float* wk, float eps) {
+  using namespace mx;
+  MX_CHECK(x && wq && wk, "rmsnorm_heads: null operand");
+  MX_CHECK(ld % 8 == 0 && ld >= heads_total * 64, "rmsnorm_heads: bad row stride");
+  MX_CHECK(nbatch > 0 && rows_per_batch > 0 && batch_rows >= row_off + rows_per_batch && row_off >= 0, "rmsnorm_heads: bad rows");
+  const long waves = (long)nbatch * rows_per_batch * ((heads_total + 7) / 8);
+  hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((unsigned)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld,
+                     nbatch, rows_per_batch, batch_rows, row_off, heads_total, heads_q, wq, wk, eps);
+  MX_LAUNCH_CHECK();
+  return 0;
+}

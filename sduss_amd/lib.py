@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmxdenoise.so")
 
 MX_F32, MX_F16, MX_BF16 = 0, 1, 2
-EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV = 1, 2, 4, 8
+EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV, EPI_GELU_TANH, EPI_RES_BCAST = 1, 2, 4, 8, 16, 32
 
 
 class MxError(RuntimeError):
@@ -30,6 +30,8 @@ class GemmDesc(C.Structure):
         ("seg", C.c_int), ("period", C.c_int), ("ldvt", C.c_int),
         ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("corner_patch", C.c_int),
+        ("a_batch_rows", C.c_int), ("a_row_off", C.c_int), ("c_batch_rows", C.c_int), ("c_row_off", C.c_int),
+        ("gate", C.c_void_p), ("ldg", C.c_int),
     ]
 
 
@@ -41,6 +43,14 @@ class UNetConfigC(C.Structure):
         ("cross_attention_dim", C.c_int), ("addition_time_embed_dim", C.c_int),
         ("projection_class_embeddings_input_dim", C.c_int), ("norm_num_groups", C.c_int),
         ("norm_eps", C.c_float), ("transformer_norm_eps", C.c_float), ("layer_norm_eps", C.c_float),
+    ]
+
+
+class MMDiTConfigC(C.Structure):
+    _fields_ = [
+        ("patch_size", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int), ("num_layers", C.c_int),
+        ("num_attention_heads", C.c_int), ("joint_attention_dim", C.c_int), ("pooled_projection_dim", C.c_int),
+        ("pos_embed_max_size", C.c_int), ("dual_attention", C.c_int * 64), ("norm_eps", C.c_float),
     ]
 
 
@@ -73,6 +83,16 @@ SYMBOLS = {
     "mx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
     "mx_unet_forward_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz,
                                    C.c_char_p, _vp, _sz]),
+    "mx_layernorm_mod": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f]),
+    "mx_rmsnorm_heads": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f]),
+    "mx_mmdit_create": (_vp, [C.POINTER(MMDiTConfigC)]),
+    "mx_mmdit_destroy": (None, [_vp]),
+    "mx_mmdit_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),
+    "mx_mmdit_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "mx_mmdit_validate": (_i, [_vp, _i, _i, _i, _i]),
+    "mx_mmdit_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz]),
+    "mx_mmdit_forward_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, C.c_char_p, _vp, _sz]),
+    "mx_cfg_flow_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),
     "mx_euler_scale_input": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i]),
     "mx_cfg_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),
 }

@@ -141,3 +141,39 @@ def cfg_euler_step_(noise: torch.Tensor, latents: torch.Tensor, sigma: torch.Ten
                                    float(guidance_scale), n_lat, latents[0].numel(), _lib.torch_dtype_code(latents.dtype)),
                "mx_cfg_euler_step")
     return latents
+
+
+def layernorm_mod(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, rows_per_batch: int, eps: float = 1e-6,
+                  scale2: Optional[torch.Tensor] = None, shift2: Optional[torch.Tensor] = None):
+    """x bf16 [M, C]; scale/shift fp32 [B, C] (contiguous rows) -> y (and y2 when scale2/shift2 are given)."""
+    l = _lib.load()
+    _bf16(x)
+    m, c = x.shape
+    y = torch.empty_like(x)
+    y2 = torch.empty_like(x) if scale2 is not None else None
+    for t in (scale, shift, scale2, shift2):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.shape[1] == c)
+    _lib.check(l.mx_layernorm_mod(_lib.current_stream(), x.data_ptr(), y.data_ptr(), _p(y2), scale.data_ptr(), shift.data_ptr(),
+                                  _p(scale2), _p(shift2), c, m, c, rows_per_batch, eps), "mx_layernorm_mod")
+    return (y, y2) if y2 is not None else y
+
+
+def rmsnorm_heads_(x: torch.Tensor, nbatch: int, rows_per_batch: int, batch_rows: int, row_off: int, heads_total: int,
+                   heads_q: int, wq: torch.Tensor, wk: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    l = _lib.load()
+    _bf16(x)
+    _lib.check(l.mx_rmsnorm_heads(_lib.current_stream(), x.data_ptr(), x.shape[1], nbatch, rows_per_batch, batch_rows, row_off,
+                                  heads_total, heads_q, wq.data_ptr(), wk.data_ptr(), eps), "mx_rmsnorm_heads")
+    return x
+
+
+def cfg_flow_step_(noise: torch.Tensor, latents: torch.Tensor, sigma: torch.Tensor, sigma_next: torch.Tensor,
+                   guidance_scale: float) -> torch.Tensor:
+    l = _lib.load()
+    assert latents.is_contiguous() and noise.is_contiguous() and noise.dtype == latents.dtype
+    sg = sigma.to(device=latents.device, dtype=torch.float32).contiguous()
+    sn = sigma_next.to(device=latents.device, dtype=torch.float32).contiguous()
+    _lib.check(l.mx_cfg_flow_step(_lib.current_stream(), noise.data_ptr(), latents.data_ptr(), sg.data_ptr(), sn.data_ptr(),
+                                  float(guidance_scale), latents.shape[0], latents[0].numel(), _lib.torch_dtype_code(latents.dtype)),
+               "mx_cfg_flow_step")
+    return latents

@@ -1,0 +1,109 @@
+"""The model-slot adapter for SD3.5: presents ``PatchSD3Transformer2DModel.forward``'s signature
+(sduss/model_executor/modules/SD3Transformer.py:60-74, 262) over the MI355X MMDiT step plan in libmxdenoise.so.
+Installed where ``instantiate_pipeline`` wraps the transformer
+(pipelines/stable_diffusion_3/pipeline_stable_diffusion_3_esymred.py:24-36)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as _lib
+from .config import MMDiTConfig
+from .unet import _Config
+from .weights import PackedWeights, pack_mmdit
+
+
+class MxSD3Transformer:
+    """``forward(hidden_states: {str(res): [n,16,h,w]}, encoder_hidden_states [N,333,4096], pooled_projections [N,2048],
+    timestep [N], ..., return_dict=False, is_sliced, patch_size, input_indices) -> (dict,)``.  Unlike the reference it does
+    NOT mutate its input dict (the reference overwrites it with the patch embeddings, SD3Transformer.py:82-83)."""
+
+    def __init__(self, cfg: MMDiTConfig, params: Dict[str, torch.Tensor], device="cuda:0"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = torch.bfloat16
+        self._lib = _lib.load()
+        cc = _lib.MMDiTConfigC()
+        cc.patch_size, cc.in_channels, cc.out_channels = cfg.patch_size, cfg.in_channels, cfg.out_channels
+        cc.num_layers, cc.num_attention_heads = cfg.num_layers, cfg.num_attention_heads
+        cc.joint_attention_dim, cc.pooled_projection_dim = cfg.joint_attention_dim, cfg.pooled_projection_dim
+        cc.pos_embed_max_size, cc.norm_eps = cfg.pos_embed_max_size, cfg.norm_eps
+        assert cfg.attention_head_dim == 64, "the attention kernel is built for head_dim 64"
+        for i in range(cfg.num_layers):
+            cc.dual_attention[i] = int(i in cfg.dual_attention_layers)
+        self._handle = self._lib.mx_mmdit_create(C.byref(cc))
+        if not self._handle:
+            raise _lib.MxError("mx_mmdit_create: " + self._lib.mx_last_error().decode())
+        self.weights = PackedWeights(pack_mmdit(cfg, params), self.device)
+        _lib.check(self._lib.mx_mmdit_set_weights(self._handle, self.weights.blob.data_ptr(), self.weights.blob.numel(),
+                                                  self.weights.table, len(self.weights.names)), "mx_mmdit_set_weights")
+        self._ws: Optional[torch.Tensor] = None
+        self.config = _Config(in_channels=cfg.in_channels, patch_size=cfg.patch_size, sample_size=cfg.sample_size,
+                              joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            self._lib.mx_mmdit_destroy(h)
+            self._handle = None
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def forward_one(self, latents: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                    pooled: torch.Tensor, stage: Optional[str] = None, stage_shape=None) -> torch.Tensor:
+        assert latents.is_cuda and latents.ndim == 4
+        latents = latents.contiguous()
+        b, _c, h, w = latents.shape
+        lt = encoder_hidden_states.shape[1]
+        ts = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+        if ts.numel() == 1:
+            ts = ts.expand(b)
+        ts = ts.contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        pp = pooled.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        assert ts.shape[0] == b and ehs.shape[0] == b and pp.shape == (b, self.cfg.pooled_projection_dim)
+        assert ehs.shape[2] == self.cfg.joint_attention_dim
+        need = self._lib.mx_mmdit_workspace_bytes(self._handle, b, h, w, lt)
+        if need == 0:
+            raise _lib.MxError("mx_mmdit_workspace_bytes: " + self._lib.mx_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((b, self.cfg.out_channels, h, w), dtype=latents.dtype, device=self.device)
+        code = _lib.torch_dtype_code(latents.dtype)
+        stream = _lib.current_stream()
+        if stage is None:
+            _lib.check(self._lib.mx_mmdit_forward(self._handle, stream, latents.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
+                                                  pp.data_ptr(), out.data_ptr(), b, h, w, lt, self._ws.data_ptr(),
+                                                  self._ws.numel()), "mx_mmdit_forward")
+            return out
+        st = torch.empty(stage_shape, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self._lib.mx_mmdit_forward_trace(self._handle, stream, latents.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
+                                                    pp.data_ptr(), out.data_ptr(), b, h, w, lt, self._ws.data_ptr(),
+                                                    self._ws.numel(), stage.encode(), st.data_ptr(), st.numel() * 2),
+                   "mx_mmdit_forward_trace")
+        return st
+
+    def forward(self, hidden_states: Dict[str, torch.Tensor], encoder_hidden_states: torch.Tensor = None,
+                pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None, block_controlnet_hidden_states=None,
+                joint_attention_kwargs=None, return_dict: bool = True, skip_layers=None, patch_size: int = None,
+                is_sliced: bool = False, save_index: int = 0, input_indices: dict = None):
+        assert block_controlnet_hidden_states is None and skip_layers is None and not joint_attention_kwargs
+        out: Dict[str, torch.Tensor] = {}
+        row = 0
+        keys = [k for k in hidden_states if hidden_states[k] is not None and hidden_states[k].shape[0] > 0]
+        if not is_sliced:
+            keys = keys[:1]   # the reference's unsliced branch runs the first resolution only (SD3Transformer.py:105-109)
+        for key in keys:
+            x = hidden_states[key]
+            n = x.shape[0]
+            sl = slice(row, row + n)
+            ts = timestep if timestep.ndim == 0 else timestep[sl]
+            out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], pooled_projections[sl])
+            row += n
+        return (out,)
+
+    __call__ = forward

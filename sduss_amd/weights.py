@@ -167,3 +167,86 @@ class PackedWeights:
             arr[i].offset = off
             arr[i].bytes = nb
         self.table = arr
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SD3.5 MMDiT
+# ------------------------------------------------------------------------------------------------------------------
+def synthetic_mmdit_params(cfg, device="cpu", seed: int = 10086) -> Dict[str, torch.Tensor]:
+    """Random-init MMDiT weights (N(0,1)*fan_in^-1/2; AdaLN projections damped so activations stay O(1))."""
+    from .config import mmdit_param_shapes
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = {}
+    for name, shape in mmdit_param_shapes(cfg).items():
+        if name == "pos_embed.pos_embed":
+            t = 0.5 * torch.randn(shape, generator=g, device=device)
+        elif name.endswith(("norm_q.weight", "norm_k.weight", "norm_added_q.weight", "norm_added_k.weight")):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        elif name.endswith(".weight"):
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            gain = 0.3 if (".norm1" in name or "norm_out" in name) else 1.0
+            t = torch.randn(shape, generator=g, device=device) * gain * fan_in ** -0.5
+        else:
+            t = 0.05 * torch.randn(shape, generator=g, device=device)
+        out[name] = t.to(torch.bfloat16)
+    return out
+
+
+def pack_mmdit(cfg, P: Dict[str, torch.Tensor]) -> List[Tuple[str, torch.Tensor]]:
+    """HF-named MMDiT params -> packed tensors (fused q|k|v projections, one stacked AdaLN projection, conv as GEMM)."""
+    from .config import mmdit_param_shapes
+    missing = [k for k in mmdit_param_shapes(cfg) if k not in P]
+    if missing:
+        raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+    bf, f32 = torch.bfloat16, torch.float32
+    out: List[Tuple[str, torch.Tensor]] = []
+
+    def mat(name, t):
+        out.append((name, t.to(bf).contiguous()))
+
+    def vec(name, t):
+        out.append((name, t.to(f32).contiguous()))
+
+    def lin(dst, src):
+        mat(f"{dst}.weight", P[f"{src}.weight"]); vec(f"{dst}.bias", P[f"{src}.bias"])
+
+    d = cfg.dim
+    mat("pos_embed.table", P["pos_embed.pos_embed"].reshape(-1, d))
+    mat("pos_embed.proj.weight", _conv_pack(P["pos_embed.proj.weight"]))     # [d, (dy*ps+dx)*C + c]
+    vec("pos_embed.proj.bias", P["pos_embed.proj.bias"])
+    for n in ("time_text_embed.timestep_embedder.linear_1", "time_text_embed.timestep_embedder.linear_2",
+              "time_text_embed.text_embedder.linear_1", "time_text_embed.text_embedder.linear_2", "context_embedder"):
+        lin(n, n)
+    ada_w, ada_b = [], []
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}"
+        for n in (f"{b}.norm1.linear", f"{b}.norm1_context.linear"):
+            ada_w.append(P[f"{n}.weight"]); ada_b.append(P[f"{n}.bias"])
+    ada_w.append(P["norm_out.linear.weight"]); ada_b.append(P["norm_out.linear.bias"])
+    mat("adaln_all.weight", torch.cat(ada_w, dim=0)); vec("adaln_all.bias", torch.cat(ada_b, dim=0))
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}"
+        last = i == cfg.num_layers - 1
+        dual = i in cfg.dual_attention_layers
+        mat(f"{b}.attn.to_qkv.weight", torch.cat([P[f"{b}.attn.{n}.weight"] for n in ("to_q", "to_k", "to_v")], dim=0))
+        vec(f"{b}.attn.to_qkv.bias", torch.cat([P[f"{b}.attn.{n}.bias"] for n in ("to_q", "to_k", "to_v")], dim=0))
+        mat(f"{b}.attn.add_qkv.weight", torch.cat([P[f"{b}.attn.{n}.weight"] for n in ("add_q_proj", "add_k_proj", "add_v_proj")], dim=0))
+        vec(f"{b}.attn.add_qkv.bias", torch.cat([P[f"{b}.attn.{n}.bias"] for n in ("add_q_proj", "add_k_proj", "add_v_proj")], dim=0))
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            vec(f"{b}.attn.{n}.weight", P[f"{b}.attn.{n}.weight"])
+        lin(f"{b}.attn.to_out.0", f"{b}.attn.to_out.0")
+        if not last:
+            lin(f"{b}.attn.to_add_out", f"{b}.attn.to_add_out")
+        if dual:
+            mat(f"{b}.attn2.to_qkv.weight", torch.cat([P[f"{b}.attn2.{n}.weight"] for n in ("to_q", "to_k", "to_v")], dim=0))
+            vec(f"{b}.attn2.to_qkv.bias", torch.cat([P[f"{b}.attn2.{n}.bias"] for n in ("to_q", "to_k", "to_v")], dim=0))
+            for n in ("norm_q", "norm_k"):
+                vec(f"{b}.attn2.{n}.weight", P[f"{b}.attn2.{n}.weight"])
+            lin(f"{b}.attn2.to_out.0", f"{b}.attn2.to_out.0")
+        lin(f"{b}.ff.net.0.proj", f"{b}.ff.net.0.proj"); lin(f"{b}.ff.net.2", f"{b}.ff.net.2")
+        if not last:
+            lin(f"{b}.ff_context.net.0.proj", f"{b}.ff_context.net.0.proj"); lin(f"{b}.ff_context.net.2", f"{b}.ff_context.net.2")
+    lin("proj_out", "proj_out")
+    return out

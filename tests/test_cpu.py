@@ -124,6 +124,49 @@ def test_step_plan_resolves_packed_weights_on_host(tiny):
     l.mx_unet_destroy(h)
 
 
+def test_mmdit_inventory_and_plan_on_host():
+    """SD3.5 MMDiT: the product's tensor inventory equals the oracle's (2.47 B with the positional table at medium size)
+    and the C++ step plan resolves every packed tensor (no launches)."""
+    from oracle import sd3_mmdit_ref as mref
+    from sduss_amd import config, lib, weights
+    for a, b in ((config.MMDiTConfig.tiny(), mref.MMDiTConfig.tiny()), (config.MMDiTConfig.sd35_medium(), mref.MMDiTConfig.sd35_medium())):
+        assert set(config.mmdit_param_shapes(a).items()) == set(mref.param_shapes(b).items())
+    total = sum(torch.Size(v).numel() for v in config.mmdit_param_shapes(config.MMDiTConfig.sd35_medium()).values())
+    assert abs(total - 2.47e9) < 1e7
+    cfg = config.MMDiTConfig.tiny()
+    P = mref.init_params(mref.MMDiTConfig.tiny())
+    pw = weights.PackedWeights(weights.pack_mmdit(cfg, P), "cpu")
+    l = lib.load()
+    cc = lib.MMDiTConfigC()
+    cc.patch_size, cc.in_channels, cc.out_channels, cc.num_layers, cc.num_attention_heads = 2, 16, 16, cfg.num_layers, cfg.num_attention_heads
+    cc.joint_attention_dim, cc.pooled_projection_dim, cc.pos_embed_max_size, cc.norm_eps = 128, 64, cfg.pos_embed_max_size, 1e-6
+    for i in cfg.dual_attention_layers:
+        cc.dual_attention[i] = 1
+    h = l.mx_mmdit_create(C.byref(cc))
+    assert h and l.mx_mmdit_set_weights(h, pw.blob.data_ptr(), pw.blob.numel(), pw.table, len(pw.names)) == 0
+    assert l.mx_mmdit_validate(h, 2, 16, 16, 37) == 0, l.mx_last_error()
+    assert l.mx_mmdit_validate(h, 1, 64, 64, 37) != 0 and b"positional table" in l.mx_last_error()
+    assert l.mx_mmdit_workspace_bytes(h, 2, 16, 16, 37) > 0
+    l.mx_mmdit_destroy(h)
+
+
+def test_oracle_mmdit_token_order_invariance():
+    """the sliced branch of the reference only re-chunks the token axis; joint attention is permutation-equivariant over
+    image tokens, so shuffling patch positions (with their positional rows) must shuffle the output the same way."""
+    from oracle import sd3_mmdit_ref as mref
+    cfg = mref.MMDiTConfig.tiny()
+    P = mref.init_params(cfg)
+    lat, t, e, p = mref.make_inputs(cfg, 1, 16, ctx_len=9)
+    tr = {}
+    mref.mmdit_forward(P, cfg, lat, t, e, p, trace=tr)
+    x0 = tr["embed"]
+    perm = torch.randperm(x0.shape[1], generator=torch.Generator().manual_seed(0))
+    x, ctx = x0[:, perm], tr["context_embed"]
+    y, _ = mref.joint_block(P, "transformer_blocks.0", x, ctx, tr["temb"], cfg, False, True)
+    y0, _ = mref.joint_block(P, "transformer_blocks.0", x0, ctx, tr["temb"], cfg, False, True)
+    assert torch.allclose(y, y0[:, perm], atol=1e-4)
+
+
 def test_bad_arguments_raise():
     from sduss_amd import lib
     l = lib.load()

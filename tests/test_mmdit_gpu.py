@@ -1,0 +1,213 @@
+"""GPU parity of the SD3.5 MMDiT path (kernels added for it + the whole step plan) against the CPU oracle.
+Tolerances as in test_ops_gpu.py / test_unet_gpu.py (bf16 storage between fused kernels, fp32 accumulate)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import scheduler_ref, sd3_mmdit_ref as ref  # noqa: E402  (checker only)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rt(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _close(got, want, rel, what):
+    got = got.float().cpu()
+    scale = want.abs().max().item() + 1e-6
+    err = (got - want).abs().max().item()
+    assert math.isfinite(err), f"{what}: non-finite"
+    assert err <= rel * scale, f"{what}: max err {err:.5f} > {rel} * {scale:.4f}"
+
+
+@pytest.mark.parametrize("c,rows,dual", [(128, 64, True), (1536, 333, False), (1536, 256, True)])
+def test_layernorm_mod(cuda_device, c, rows, dual):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(c + rows)
+    b = 3
+    x = _rt(torch.randn(b * rows, c, generator=g) * 2 + 0.3)
+    sc, sh, sc2, sh2 = (0.5 * torch.randn(b, c, generator=g) for _ in range(4))
+    n = F.layer_norm(x, (c,), None, None, 1e-6).reshape(b, rows, c)
+    want = (n * (1 + sc[:, None]) + sh[:, None]).reshape(-1, c)
+    if dual:
+        got, got2 = ops.layernorm_mod(_bf(x).cuda(), sc.cuda(), sh.cuda(), rows, 1e-6, sc2.cuda(), sh2.cuda())
+        _close(got2, (n * (1 + sc2[:, None]) + sh2[:, None]).reshape(-1, c), 2.0 ** -7, "layernorm_mod second output")
+    else:
+        got = ops.layernorm_mod(_bf(x).cuda(), sc.cuda(), sh.cuda(), rows, 1e-6)
+    _close(got, want, 2.0 ** -7, "layernorm_mod")
+
+
+def test_rmsnorm_heads_joint_rows(cuda_device):
+    """normalises only the selected row range of every sample, q heads with wq and k heads with wk; other rows untouched."""
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, li, lt, heads = 2, 40, 13, 3
+    lj = li + lt
+    x = _rt(torch.randn(b * lj, 2 * heads * 64, generator=g) * 1.7)
+    wq = 1 + 0.2 * torch.randn(64, generator=g); wk = 1 + 0.2 * torch.randn(64, generator=g)
+    xg = _bf(x).cuda()
+    ops.rmsnorm_heads_(xg, b, lt, lj, li, 2 * heads, heads, wq.cuda(), wk.cuda(), 1e-6)
+    want = x.clone().reshape(b, lj, 2 * heads, 64)
+    sel = want[:, li:]
+    nrm = sel * torch.rsqrt(sel.pow(2).mean(-1, keepdim=True) + 1e-6)
+    nrm[:, :, :heads] *= wq
+    nrm[:, :, heads:] *= wk
+    want[:, li:] = nrm
+    _close(xg, want.reshape(b * lj, -1), 2.0 ** -7, "rmsnorm_heads")
+    assert torch.equal(xg.reshape(b, lj, -1)[:, :li].cpu(), _bf(x).reshape(b, lj, -1)[:, :li]), "rows outside the range changed"
+
+
+def _gemm_desc(lib, a, w, c, **kw):
+    d = lib.GemmDesc()
+    d.a, d.w, d.c = a.data_ptr(), w.data_ptr(), c.data_ptr()
+    d.M, d.K = a.shape[0] if "M" not in kw else kw.pop("M"), w.shape[1]
+    d.N, d.lda, d.ldc = w.shape[0], a.shape[1], c.shape[1]
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if torch.is_tensor(v) else v)
+    return d
+
+
+@pytest.mark.parametrize("m_rows,n,k", [(64, 128, 128), (333, 1536, 256)])
+def test_gemm_gate_residual_gelu_tanh(cuda_device, m_rows, n, k):
+    """x + gate[b] * (a W^T + bias) and gelu_tanh(a W^T + bias)  (transformer.py:344-345, 359-366)."""
+    from sduss_amd import lib
+    l = lib.load()
+    g = torch.Generator().manual_seed(m_rows + n)
+    b = 3
+    a = _rt(torch.randn(b * m_rows, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
+    bias = torch.randn(n, generator=g); gate = torch.randn(b, n + 64, generator=g); r = _rt(torch.randn(b * m_rows, n, generator=g))
+    ag, wg, rg = _bf(a).cuda(), _bf(w).cuda(), _bf(r).cuda()
+    out = torch.empty(b * m_rows, n, dtype=torch.bfloat16, device="cuda")
+    gg, bg = gate.cuda(), bias.cuda()
+    d = _gemm_desc(lib, ag, wg, out, bias=bg, residual=rg, ldr=n, gate=gg, ldg=n + 64, rows_per_batch=m_rows)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    want = r + gate[:, :n].repeat_interleave(m_rows, dim=0) * (a @ w.t() + bias)
+    _close(out, want, 2.0 ** -7, "gemm gated residual")
+    d = _gemm_desc(lib, ag, wg, out, bias=bg, flags=lib.EPI_GELU_TANH)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    _close(out, F.gelu(a @ w.t() + bias, approximate="tanh"), 2.0 ** -7, "gemm gelu-tanh")
+
+
+def test_gemm_joint_row_remap_and_pos_broadcast(cuda_device):
+    """QKV written into a joint [image ; text] sequence (rows and V^T keys offset), read back through the input remap,
+    and the positional-table residual broadcast over the batch."""
+    from sduss_amd import lib
+    l = lib.load()
+    g = torch.Generator().manual_seed(8)
+    b, li, lt, dm, k = 2, 256, 77, 128, 128
+    lj = li + lt
+    ldvt = (lj + 7) // 8 * 8
+    qk = torch.zeros(b * lj, 2 * dm, dtype=torch.bfloat16, device="cuda")
+    vt = torch.zeros(b, dm, ldvt, dtype=torch.bfloat16, device="cuda")
+    wants = []
+    for rows, off, seed in ((li, 0, 1), (lt, li, 2)):
+        gg = torch.Generator().manual_seed(seed)
+        a = _rt(torch.randn(b * rows, k, generator=gg)); w = _rt(torch.randn(3 * dm, k, generator=gg) * k ** -0.5)
+        bias = torch.randn(3 * dm, generator=gg)
+        ag, wg, bg = _bf(a).cuda(), _bf(w).cuda(), bias.cuda()
+        d = _gemm_desc(lib, ag, wg, qk, bias=bg, vt=vt, flags=lib.EPI_QKV, seg=dm, period=3, ldvt=ldvt, rows_per_batch=rows,
+                       c_batch_rows=lj, c_row_off=off)
+        lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+        wants.append(((a @ w.t() + bias).reshape(b, rows, 3 * dm), off, rows))
+    torch.cuda.synchronize()
+    qkc = qk.float().cpu().reshape(b, lj, 2 * dm); vtc = vt.float().cpu()
+    for full, off, rows in wants:
+        _close(qkc[:, off:off + rows], full[:, :, :2 * dm], 2.0 ** -7, "joint q|k rows")
+        _close(vtc[:, :, off:off + rows], full[:, :, 2 * dm:].permute(0, 2, 1), 2.0 ** -7, "joint V^T keys")
+    # read the text rows back through the loader remap
+    gg = torch.Generator().manual_seed(3)
+    w2 = _rt(torch.randn(64, 2 * dm, generator=gg) * (2 * dm) ** -0.5)
+    out = torch.empty(b * lt, 64, dtype=torch.bfloat16, device="cuda")
+    w2g = _bf(w2).cuda()
+    d = _gemm_desc(lib, qk, w2g, out, M=b * lt, rows_per_batch=lt, a_batch_rows=lj, a_row_off=li)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    _close(out, (qk.float().cpu().reshape(b, lj, -1)[:, li:] @ w2.t()).reshape(b * lt, 64), 2.0 ** -7, "input row remap")
+    # positional table broadcast
+    pos = _rt(torch.randn(li, 64, generator=gg))
+    a = _rt(torch.randn(b * li, 2 * dm, generator=gg))
+    ag, pg = _bf(a).cuda(), _bf(pos).cuda()
+    out = torch.empty(b * li, 64, dtype=torch.bfloat16, device="cuda")
+    d = _gemm_desc(lib, ag, w2g, out, residual=pg, ldr=64, flags=lib.EPI_RES_BCAST, rows_per_batch=li)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    _close(out, a @ w2.t() + pos.repeat(b, 1), 2.0 ** -7, "residual broadcast")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_flow_match_step(cuda_device, dtype):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(4)
+    n = 3
+    lat = torch.randn(n, 16, 8, 8, generator=g).to(dtype)
+    noise = torch.randn(2 * n, 16, 8, 8, generator=g).to(dtype)
+    sig = torch.tensor([1.0, 0.7, 0.2]); sig_next = torch.tensor([0.95, 0.6, 0.0])
+    want = scheduler_ref.flow_match_step(scheduler_ref.cfg_combine(noise, 7.0), lat, sig, sig_next)
+    got = ops.cfg_flow_step_(noise.cuda(), lat.cuda().clone(), sig, sig_next, 7.0).cpu()
+    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), "flow-match step must be bit-exact"
+
+
+@pytest.fixture(scope="module")
+def tiny(cuda_device):
+    from sduss_amd.config import MMDiTConfig
+    from sduss_amd.transformer_sd3 import MxSD3Transformer
+    ocfg = ref.MMDiTConfig.tiny()
+    P = ref.init_params(ocfg)
+    return ocfg, P, MxSD3Transformer(MMDiTConfig.tiny(), P, device="cuda:0")
+
+
+def _check(got, want, what, max_rel=0.04, l2_rel=0.02):
+    got = got.float().cpu()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    l2 = ((got - want).norm() / want.norm()).item()
+    print(f"{what}: max err {err:.4f} ({err / scale:.4f} of max), rel L2 {l2:.4f}")
+    assert err <= max_rel * scale and l2 <= l2_rel, f"{what}: max err {err} (scale {scale}), rel L2 {l2}"
+
+
+@pytest.mark.parametrize("batch,hw,lt", [(2, 16, 37), (1, 32, 333), (3, 24, 77)])
+def test_mmdit_forward(tiny, batch, hw, lt):
+    ocfg, P, net = tiny
+    lat, t, e, p = ref.make_inputs(ocfg, batch, hw, ctx_len=lt)
+    want = ref.mmdit_forward(P, ocfg, lat, t, e, p)
+    key = str(hw * 8)
+    out = net.forward({key: lat.cuda().to(torch.bfloat16)}, encoder_hidden_states=e.cuda(), pooled_projections=p.cuda(),
+                      timestep=t.cuda(), return_dict=False, is_sliced=True, patch_size=64,
+                      input_indices={key: [str(i) for i in range(batch)]})[0]
+    assert list(out.keys()) == [key] and out[key].shape == lat.shape
+    _check(out[key], want, f"mmdit b{batch} {hw}x{hw} ctx{lt}")
+
+
+def test_mmdit_mixed_resolutions(tiny):
+    ocfg, P, net = tiny
+    l1, t1, e1, p1 = ref.make_inputs(ocfg, 1, 16, seed=1, ctx_len=37)
+    l2, t2, e2, p2 = ref.make_inputs(ocfg, 2, 32, seed=2, ctx_len=37)
+    out = net.forward({"128": l1.cuda().to(torch.bfloat16), "256": l2.cuda().to(torch.bfloat16)},
+                      encoder_hidden_states=torch.cat([e1, e2]).cuda(), pooled_projections=torch.cat([p1, p2]).cuda(),
+                      timestep=torch.cat([t1, t2]).cuda(), return_dict=False, is_sliced=True, patch_size=64,
+                      input_indices={"128": ["0"], "256": ["1", "2"]})[0]
+    _check(out["128"], ref.mmdit_forward(P, ocfg, l1, t1, e1, p1), "mmdit mixed 128")
+    _check(out["256"], ref.mmdit_forward(P, ocfg, l2, t2, e2, p2), "mmdit mixed 256")
+
+
+def test_mmdit_medium_width_two_layers(cuda_device):
+    """SD3.5-medium widths (1536 = 24 heads, joint dim 4096, pooled 2048, 333 text tokens) with 3 layers (dual, plain, last)
+    on a 32x32 latent: exercises the BN=128 pipelined GEMM paths of the real model."""
+    from sduss_amd.config import MMDiTConfig
+    from sduss_amd.transformer_sd3 import MxSD3Transformer
+    kw = dict(num_layers=3, dual_attention_layers=(0,), pos_embed_max_size=32)
+    ocfg = ref.MMDiTConfig(**kw)
+    P = ref.init_params(ocfg)
+    lat, t, e, p = ref.make_inputs(ocfg, 2, 32, ctx_len=333)
+    with torch.inference_mode():
+        want = ref.mmdit_forward(P, ocfg, lat, t, e, p)
+    net = MxSD3Transformer(MMDiTConfig(**kw), P, device="cuda:0")
+    got = net.forward_one(lat.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), p.cuda())
+    _check(got, want, "mmdit medium width")
