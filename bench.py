@@ -27,8 +27,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MODELS = {   # steps per image, algorithmic FLOP per sample-forward at 1024^2, guidance
+    "sdxl": {"steps": 50, "flop": 6.76e12, "name": "SDXL-base-1.0 UNet", "sched": "Euler", "cfg": 5.0, "params": "2.57 B"},
+    "sd3": {"steps": 28, "flop": 11.25e12, "name": "SD3.5-medium MMDiT", "sched": "flow-match Euler", "cfg": 7.0, "params": "2.47 B"},
+}
 STEPS_PER_IMAGE = 50
-SDXL_FLOP_PER_SAMPLE_FORWARD = 6.76e12     # SURVEY.md section 8d (3.381 TMAC)
 MFMA_PEAK_BF16 = 2.5e15                    # dense, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<128,true> (conv3x3)",
@@ -43,6 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="requests per step (UNet batch is 2x under CFG)")
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--model", choices=["sdxl", "sd3"], default="sdxl", help="sdxl = BASELINE configs[1] (the headline metric); sd3 = configs[2]")
     ap.add_argument("--sliced", action="store_true", help="is_sliced=True, patch_size=256 (the reference's mixed-policy setting)")
     ap.add_argument("--stream-requests", type=int, default=12)
     ap.add_argument("--stream-load", type=float, default=0.9)
@@ -52,6 +56,9 @@ def parse():
 
 
 def make_batch(den, cfg, n, res, device, shared, base_id=0):
+    if hasattr(cfg, "joint_attention_dim"):
+        from sduss_amd.pipeline_sd3 import synthetic_sd3_request
+        return [synthetic_sd3_request(base_id + i, res, STEPS_PER_IMAGE, cfg, den, device, shared=shared) for i in range(n)]
     from sduss_amd.pipeline import synthetic_request
     return [synthetic_request(base_id + i, res, STEPS_PER_IMAGE, cfg, den, device, shared=shared) for i in range(n)]
 
@@ -90,25 +97,38 @@ def run_stream(den, cfg, args, device, shared, step_s, rank, world):
     return lat, (min(r.arrival for r in done), max(r.finish for r in done))
 
 
-def cpu_baseline(res):
-    """The oracle (kind 'port') on the host cores: one SDXL UNet sample-forward at full width."""
-    from oracle import sdxl_unet_ref as ref
-    cfg = ref.UNetConfig.sdxl_base()
-    P = ref.fast_params(cfg)      # timing-equivalent weights without 2.6e9 RNG draws
-    sample, t, ehs, text, tids = ref.make_inputs(cfg, 1, res // 8)
+def cpu_baseline(res, model):
+    """The oracle (kind 'port') on the host cores: one sample-forward of the denoiser at full width."""
     threads = torch.get_num_threads()
-    with torch.inference_mode():
-        t0 = time.perf_counter()
-        out = ref.unet_forward(P, cfg, sample, t, ehs, text, tids)
-        dt = time.perf_counter() - t0
+    if model == "sd3":
+        from oracle import sd3_mmdit_ref as mref
+        cfg = mref.MMDiTConfig.sd35_medium()
+        P = mref.init_params(cfg)
+        lat, t, ehs, pooled = mref.make_inputs(cfg, 1, res // 8)
+        with torch.inference_mode():
+            t0 = time.perf_counter()
+            out = mref.mmdit_forward(P, cfg, lat, t, ehs, pooled)
+            dt = time.perf_counter() - t0
+    else:
+        from oracle import sdxl_unet_ref as ref
+        cfg = ref.UNetConfig.sdxl_base()
+        P = ref.fast_params(cfg)      # timing-equivalent weights without 2.6e9 RNG draws
+        sample, t, ehs, text, tids = ref.make_inputs(cfg, 1, res // 8)
+        with torch.inference_mode():
+            t0 = time.perf_counter()
+            out = ref.unet_forward(P, cfg, sample, t, ehs, text, tids)
+            dt = time.perf_counter() - t0
     assert torch.isfinite(out).all()
     return {"value": 1.0 / (dt * 2 * STEPS_PER_IMAGE), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 UNet sample-forward (batch 1, {res}x{res}, fp32 torch oracle) = 1/{2 * STEPS_PER_IMAGE} image, "
+            "sample": f"1 {MODELS[model]['name']} sample-forward (batch 1, {res}x{res}, fp32 torch oracle) = 1/{2 * STEPS_PER_IMAGE} image, "
                       f"{dt:.1f} s on {threads} threads of {os.cpu_count()} host CPUs; extrapolated x{2 * STEPS_PER_IMAGE}"}
 
 
 def main():
+    global STEPS_PER_IMAGE
     args = parse()
+    mdl = MODELS[args.model]
+    STEPS_PER_IMAGE = mdl["steps"]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,14 +143,22 @@ def main():
         dist.init_process_group("nccl", device_id=device)   # RCCL; used for the barrier + max-over-ranks only: replicas share nothing
 
     from sduss_amd import lib
-    from sduss_amd.config import UNetConfig
-    from sduss_amd.pipeline import SDXLDenoiser
-    from sduss_amd.unet import MxUNet
-    from sduss_amd.weights import synthetic_params
-
-    cfg = UNetConfig.sdxl_base()
-    net = MxUNet(cfg, synthetic_params(cfg, device=device), device=device)
-    den = SDXLDenoiser(net, guidance_scale=5.0)
+    if args.model == "sd3":
+        from sduss_amd.config import MMDiTConfig
+        from sduss_amd.pipeline_sd3 import SD3Denoiser
+        from sduss_amd.transformer_sd3 import MxSD3Transformer
+        from sduss_amd.weights import synthetic_mmdit_params
+        cfg = MMDiTConfig.sd35_medium()
+        net = MxSD3Transformer(cfg, synthetic_mmdit_params(cfg, device=device), device=device)
+        den = SD3Denoiser(net, guidance_scale=mdl["cfg"])
+    else:
+        from sduss_amd.config import UNetConfig
+        from sduss_amd.pipeline import SDXLDenoiser
+        from sduss_amd.unet import MxUNet
+        from sduss_amd.weights import synthetic_params
+        cfg = UNetConfig.sdxl_base()
+        net = MxUNet(cfg, synthetic_params(cfg, device=device), device=device)
+        den = SDXLDenoiser(net, guidance_scale=mdl["cfg"])
     shared = {}
     reqs = make_batch(den, cfg, args.batch, args.res, device, shared)
     key = str(args.res)
@@ -163,16 +191,17 @@ def main():
     finite = all(torch.isfinite(r.latents.float()).all().item() for r in reqs)
 
     result = {
-        "metric": "images/sec (node), SDXL 1024^2 50-step, fixed prompt, CFG", "value": images_per_s, "unit": "images/s",
+        "metric": f"images/sec (node), {'SDXL' if args.model == 'sdxl' else 'SD3.5-medium'} {args.res}^2 {STEPS_PER_IMAGE}-step, fixed prompt, CFG",
+        "value": images_per_s, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"SDXL-base-1.0 UNet {args.res}x{args.res} 50-step Euler, CFG 5.0, {args.batch} requests/step "
-                               f"(UNet batch {2 * args.batch}) per GPU, is_sliced={args.sliced}, random-init weights of the "
-                               f"real architecture (2.57 B params), one data-parallel replica per GPU, no collective",
+        "config": {"workload": f"{mdl['name']} {args.res}x{args.res} {STEPS_PER_IMAGE}-step {mdl['sched']}, CFG {mdl['cfg']}, {args.batch} requests/step "
+                               f"(denoiser batch {2 * args.batch}) per GPU, is_sliced={args.sliced}, random-init weights of the "
+                               f"real architecture ({mdl['params']} params), one data-parallel replica per GPU, no collective",
                    "requests_per_step": args.batch, "resolution": args.res, "steps_per_image": STEPS_PER_IMAGE},
         "outputs_finite": finite,
-        "achieved_tflops_whole_step": 2 * args.batch * SDXL_FLOP_PER_SAMPLE_FORWARD / step_s / 1e12 if args.res == 1024 else None,
-        "frac_of_mfma_peak_whole_step": 2 * args.batch * SDXL_FLOP_PER_SAMPLE_FORWARD / step_s / MFMA_PEAK_BF16 if args.res == 1024 else None,
+        "achieved_tflops_whole_step": 2 * args.batch * mdl["flop"] / step_s / 1e12 if args.res == 1024 else None,
+        "frac_of_mfma_peak_whole_step": 2 * args.batch * mdl["flop"] / step_s / MFMA_PEAK_BF16 if args.res == 1024 else None,
     }
 
     # ---- roofline leg: per-launch hipEvents on the launch stream ----
@@ -217,7 +246,7 @@ def main():
 
     # ---- CPU baseline leg ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.res)
+        result["cpu_baseline"] = cpu_baseline(args.res, args.model)
 
     if rank == 0:
         print(json.dumps(result))

@@ -3,6 +3,10 @@
 #include "common.h"
 #include "../../include/mxdenoise.h"
 
+// The scheduler kernels reproduce torch's op-by-op IEEE evaluation bit for bit: no mul+add contraction into FMA in this
+// translation unit (HIP's __fmul_rn/__fadd_rn are plain operators and would otherwise be contracted).
+#pragma clang fp contract(off)
+
 namespace mx {
 
 template <typename T> __device__ __forceinline__ float load_as_f32(const T* p, long i);

@@ -1,0 +1,110 @@
+"""SD3.5 caller of the model slot: ``denoising_step`` mirroring ``ESyMReDStableDiffusion3Pipeline.denoising_step``
+(sduss/model_executor/diffusers/pipelines/stable_diffusion_3/pipeline_stable_diffusion_3_esymred.py:231-388) with the
+batched flow-match Euler step (schedulers/scheduling_flow_match_euler_discrete.py:159-202).  Host side = bookkeeping only."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .transformer_sd3 import MxSD3Transformer
+
+
+def flow_match_tables(num_inference_steps: int, num_train_timesteps: int = 1000, shift: float = 3.0):
+    """diffusers FlowMatchEulerDiscreteScheduler.set_timesteps (SD3.5 scheduler config: shift 3.0, no dynamic shifting).
+    Returns (timesteps f32[n], sigmas f32[n+1])."""
+    base = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy() / num_train_timesteps
+    base = shift * base / (1 + (shift - 1) * base)
+    sigma_max, sigma_min = float(base[0]), float(base[-1])
+    timesteps = np.linspace(sigma_max * num_train_timesteps, sigma_min * num_train_timesteps, num_inference_steps)
+    sigmas = timesteps / num_train_timesteps
+    sigmas = shift * sigmas / (1 + (shift - 1) * sigmas)
+    timesteps = (sigmas * num_train_timesteps).astype(np.float32)
+    sigmas = np.concatenate([sigmas, [0.0]]).astype(np.float32)
+    return timesteps, sigmas
+
+
+@dataclass
+class SD3Request:
+    request_id: int
+    resolution: int
+    num_inference_steps: int
+    latents: torch.Tensor                 # [1, 16, res/8, res/8]
+    prompt_embeds: torch.Tensor           # [1, 333, 4096]
+    negative_prompt_embeds: torch.Tensor
+    pooled_prompt_embeds: torch.Tensor    # [1, 2048]
+    negative_pooled_prompt_embeds: torch.Tensor
+    timesteps: np.ndarray = None
+    sigmas: np.ndarray = None
+    step_index: int = 0
+    arrival: float = 0.0
+    start: Optional[float] = None
+    finish: Optional[float] = None
+
+    def done(self) -> bool:
+        return self.step_index >= self.num_inference_steps
+
+
+class SD3Denoiser:
+    def __init__(self, transformer: MxSD3Transformer, guidance_scale: float = 7.0):
+        self.transformer = transformer
+        self.guidance_scale = guidance_scale     # reference default (pipeline_stable_diffusion_3_esymred.py:236)
+        self._tables: Dict[int, tuple] = {}
+
+    def set_timesteps(self, req: SD3Request) -> None:
+        if req.num_inference_steps not in self._tables:
+            self._tables[req.num_inference_steps] = flow_match_tables(req.num_inference_steps)
+        req.timesteps, req.sigmas = self._tables[req.num_inference_steps]
+        req.step_index = 0
+
+    @torch.inference_mode()
+    def denoising_step(self, runner_reqs: Dict[str, List[SD3Request]], do_classifier_free_guidance: bool = True,
+                       is_sliced: bool = False, patch_size: int = 256) -> None:
+        dev = self.transformer.device
+        for res in sorted(runner_reqs.keys(), key=lambda r: int(r)):            # :240-241
+            reqs = runner_reqs[res]
+            if not reqs:
+                continue
+            n = len(reqs)
+            lat = torch.cat([r.latents for r in reqs], dim=0).contiguous()
+            sig = torch.tensor([float(r.sigmas[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
+            sig_next = torch.tensor([float(r.sigmas[r.step_index + 1]) for r in reqs], dtype=torch.float32, device=dev)
+            ts = torch.tensor([float(r.timesteps[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
+            if do_classifier_free_guidance:                                      # :281-292 rows [uncond..., cond...]
+                ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+                ts2 = torch.cat([ts, ts], dim=0)
+                x_in = ops.euler_scale_input(lat, torch.zeros_like(sig), 2 * n)  # exact x/1 copy == torch.cat([latents] * 2)
+            else:
+                ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
+                ts2, x_in = ts, lat
+            noise = self.transformer.forward({res: x_in}, encoder_hidden_states=ehs, pooled_projections=pooled, timestep=ts2,
+                                             return_dict=False, is_sliced=is_sliced, patch_size=patch_size,
+                                             input_indices={res: [str(r.request_id) for r in reqs]})[0][res]   # :312-322
+            ops.cfg_flow_step_(noise, lat, sig, sig_next, self.guidance_scale if do_classifier_free_guidance else 0.0)  # :362-372
+            for i, r in enumerate(reqs):
+                r.step_index += 1
+                r.latents = lat[i:i + 1]
+
+
+def synthetic_sd3_request(rid: int, resolution: int, steps: int, cfg, denoiser: SD3Denoiser, device, dtype=torch.bfloat16,
+                          seed: int = 10086, shared: Optional[dict] = None, ctx_len: int = 333) -> SD3Request:
+    g = torch.Generator(device="cpu").manual_seed(seed + 17 * rid)
+    if shared is None or "pe" not in shared:
+        ge = torch.Generator(device="cpu").manual_seed(seed)
+        pe = torch.randn(1, ctx_len, cfg.joint_attention_dim, generator=ge).to(device=device, dtype=dtype)
+        ne = torch.randn(1, ctx_len, cfg.joint_attention_dim, generator=ge).to(device=device, dtype=dtype)
+        pp = torch.randn(1, cfg.pooled_projection_dim, generator=ge).to(device=device, dtype=dtype)
+        npp = torch.randn(1, cfg.pooled_projection_dim, generator=ge).to(device=device, dtype=dtype)
+        if shared is not None:
+            shared.update(pe=pe, ne=ne, pp=pp, npp=npp)
+    else:
+        pe, ne, pp, npp = shared["pe"], shared["ne"], shared["pp"], shared["npp"]
+    lat = torch.randn(1, cfg.in_channels, resolution // 8, resolution // 8, generator=g).to(device=device, dtype=dtype)
+    req = SD3Request(rid, resolution, steps, lat, pe, ne, pp, npp)
+    denoiser.set_timesteps(req)
+    return req

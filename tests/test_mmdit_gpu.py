@@ -211,3 +211,25 @@ def test_mmdit_medium_width_two_layers(cuda_device):
     net = MxSD3Transformer(MMDiTConfig(**kw), P, device="cuda:0")
     got = net.forward_one(lat.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), p.cuda())
     _check(got, want, "mmdit medium width")
+
+
+def test_sd3_denoising_step_two_steps(tiny):
+    """pipeline_sd3.denoising_step (CFG dup -> MMDiT -> CFG combine -> flow-match Euler) vs the oracle pieces."""
+    from sduss_amd.config import MMDiTConfig
+    from sduss_amd.pipeline_sd3 import SD3Denoiser, flow_match_tables, synthetic_sd3_request
+    ocfg, P, net = tiny
+    cfg = MMDiTConfig.tiny()
+    den = SD3Denoiser(net, guidance_scale=7.0)
+    reqs = [synthetic_sd3_request(i, 128, 4, cfg, den, "cuda:0", ctx_len=21) for i in range(2)]
+    lat = torch.cat([r.latents for r in reqs]).float().cpu()
+    pe, ne = reqs[0].prompt_embeds.float().cpu(), reqs[0].negative_prompt_embeds.float().cpu()
+    pp, npp = reqs[0].pooled_prompt_embeds.float().cpu(), reqs[0].negative_pooled_prompt_embeds.float().cpu()
+    ts, sig = flow_match_tables(4)
+    ts, sig = torch.from_numpy(ts), torch.from_numpy(sig)
+    for step in range(2):
+        den.denoising_step({"128": reqs})
+        v = ref.mmdit_forward(P, ocfg, torch.cat([lat, lat]), ts[[step] * 4], torch.cat([ne, ne, pe, pe]), torch.cat([npp, npp, pp, pp]))
+        lat = scheduler_ref.flow_match_step(scheduler_ref.cfg_combine(v, 7.0), lat, sig[[step] * 2], sig[[step + 1] * 2])
+        lat = lat.to(torch.bfloat16).float()
+    assert all(r.step_index == 2 for r in reqs)
+    _check(torch.cat([r.latents for r in reqs]), lat, "sd3 denoising_step x2", max_rel=0.06, l2_rel=0.04)

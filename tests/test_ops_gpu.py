@@ -225,5 +225,5 @@ def test_scheduler_steps(cuda_device, dtype):
     noise = torch.randn(2 * n, 4, 16, 16, generator=g).to(dtype)
     want = scheduler_ref.euler_step(scheduler_ref.cfg_combine(noise, 5.0), lat, sig, sig_next)
     got = ops.cfg_euler_step_(noise.cuda(), lat.cuda().clone(), sig, sig_next, 5.0).cpu()
-    # torch evaluates sigma*eps etc. with the same IEEE ops; allow 1 ulp of the storage dtype for pow/sqrt differences
-    _close(got, want.float(), {torch.float32: 1e-6, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype], "cfg+euler step")
+    # same IEEE op sequence as torch (no FMA contraction in the kernel): bit-exact
+    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), "CFG combine + Euler step must be bit-exact"
