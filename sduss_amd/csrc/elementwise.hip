@@ -4,7 +4,8 @@
 #include "../../include/mxdenoise.h"
 
 // The scheduler kernels reproduce torch's op-by-op IEEE evaluation bit for bit: no mul+add contraction into FMA in this
-// translation unit (HIP's __fmul_rn/__fadd_rn are plain operators and would otherwise be contracted).
+// translation unit (HIP's __fmul_rn/__fadd_rn are plain operators in inlined headers and do get contracted; so plain operators here, plus
+// -ffp-contract=off for this file in the Makefile).
 #pragma clang fp contract(off)
 
 namespace mx {
@@ -119,8 +120,8 @@ __global__ void euler_scale_input_kernel(const T* __restrict__ lat, T* __restric
   // the reference evaluates samples / ((sigmas ** 2 + 1) ** 0.5) with sigmas cast to the tensor dtype
   // (scheduling_euler_discrete.py:175-182): one rounding to T per op
   const float s = rnd<T>(sigma[src]);
-  const float denom = rnd<T>(__fsqrt_rn(rnd<T>(__fadd_rn(rnd<T>(__fmul_rn(s, s)), 1.0f))));
-  store_from_f32<T>(out, idx, __fdiv_rn(load_as_f32<T>(lat, (long)src * elems + e), denom));
+  const float denom = rnd<T>(__fsqrt_rn(rnd<T>(rnd<T>(s * s) + 1.0f)));   // correctly rounded sqrt, as torch.pow(x, 0.5) -> sqrt
+  store_from_f32<T>(out, idx, load_as_f32<T>(lat, (long)src * elems + e) / denom);
 }
 
 // CFG combine + epsilon Euler step, fp32 math (pipeline_..._esymred.py:382-385; scheduling_euler_discrete.py:210-268)
@@ -135,16 +136,17 @@ __global__ void cfg_euler_step_kernel(const T* __restrict__ noise, T* __restrict
     const float u = load_as_f32<T>(noise, idx);
     const float t = load_as_f32<T>(noise, (long)n_lat * elems + idx);
     // the combine runs in the model dtype (pipeline_..._esymred.py:383-385): one rounding per op
-    eps = rnd<T>(__fadd_rn(u, rnd<T>(__fmul_rn(g, rnd<T>(__fsub_rn(t, u))))));
+    eps = rnd<T>(u + rnd<T>(g * rnd<T>(t - u)));
   } else {
     eps = load_as_f32<T>(noise, idx);
   }
   const float x = load_as_f32<T>(lat, idx);
   const float s = sigma[row], sn = sigma_next[row];
   // separate IEEE ops (no fma contraction) so the fp32 chain matches torch's op-by-op evaluation
-  const float pred_x0 = __fsub_rn(x, __fmul_rn(s, eps));
-  const float d = __fdiv_rn(__fsub_rn(x, pred_x0), s);
-  store_from_f32<T>(lat, idx, __fadd_rn(x, __fmul_rn(d, __fsub_rn(sn, s))));
+  const float pred_x0 = (x - (s * eps));
+  const float d = ((x - pred_x0) / s);
+  const float step = d * (sn - s);
+  store_from_f32<T>(lat, idx, x + step);
 }
 
 }  // namespace mx
@@ -294,12 +296,13 @@ __global__ void cfg_flow_step_kernel(const T* __restrict__ noise, T* __restrict_
   if (g > 0.f) {
     const float u = load_as_f32<T>(noise, idx);
     const float t = load_as_f32<T>(noise, (long)n_lat * elems + idx);
-    v = rnd<T>(__fadd_rn(u, rnd<T>(__fmul_rn(g, rnd<T>(__fsub_rn(t, u))))));   // pipeline_stable_diffusion_3_esymred.py:365-367
+    v = rnd<T>(u + rnd<T>(g * rnd<T>(t - u)));   // pipeline_stable_diffusion_3_esymred.py:365-367
   } else {
     v = load_as_f32<T>(noise, idx);
   }
   const float x = load_as_f32<T>(lat, idx);
-  store_from_f32<T>(lat, idx, __fadd_rn(x, __fmul_rn(__fsub_rn(sigma_next[row], sigma[row]), v)));
+  const float step = (sigma_next[row] - sigma[row]) * v;
+  store_from_f32<T>(lat, idx, x + step);
 }
 
 int launch_patchify(hipStream_t s, const void* in, int dtype, void* out, int B, int C, int H, int W, int ps) {
