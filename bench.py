@@ -71,7 +71,8 @@ def run_stream(den, cfg, args, device, shared, step_s, rank, world):
     rate = args.stream_load * cap_per_gpu * world
     rng = np.random.RandomState(10086)                      # reference seed (arg_utils.py:20)
     arrivals = np.cumsum(rng.exponential(1.0 / rate, size=n_total))
-    mine = [(i, arrivals[i]) for i in range(n_total) if i % world == rank]
+    from sduss_amd import dp
+    mine = [(i, arrivals[i]) for i in dp.my_share(n_total, rank, world, [args.res] * n_total)]   # reference's greedy placement
     pending = make_batch(den, cfg, len(mine), args.res, device, shared, base_id=1000)
     for r, (_i, a) in zip(pending, mine):
         r.arrival = float(a)
@@ -182,10 +183,8 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from sduss_amd import dp
+    elapsed = dp.max_over_ranks(elapsed, dist, device)
     step_s = elapsed / args.steps
     images_per_s = world * args.batch / (STEPS_PER_IMAGE * step_s)
     finite = all(torch.isfinite(r.latents.float()).all().item() for r in reqs)
@@ -232,11 +231,7 @@ def main():
     # ---- stream leg: p50 request latency under Poisson arrivals ----
     if args.stream_requests > 0:
         lat, window = run_stream(den, cfg, args, device, shared, step_s, rank, world)
-        if dist is not None:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, (lat, window))
-            lat = [x for g in gathered for x in g[0]]
-            window = (min(g[1][0] for g in gathered), max(g[1][1] for g in gathered))
+        lat, window = dp.gather_stream_stats(lat, window, dist)
         if rank == 0:
             result["stream"] = {"requests": len(lat), "offered_load_frac_of_capacity": args.stream_load,
                                 "p50_latency_s": float(np.percentile(lat, 50)), "p90_latency_s": float(np.percentile(lat, 90)),

@@ -1,0 +1,52 @@
+"""Data-parallel placement of requests over replicas (one process + one full replica per GPU, no collective on the data path).
+
+The reference places each waiting request on the dp_rank with the least outstanding sum(resolution^2)
+(sduss/dispatcher/policy/greedy.py:16-36; workload = RequestPool.get_pixels_all_dp_rank, dispatcher/request_pool.py:95-102);
+for a fixed-resolution stream that degenerates to round-robin, which is what BASELINE.json's north_star names.  The only
+cross-rank traffic of the benchmark is bookkeeping: a barrier, the max of the timed region, and a gather of latencies
+(``torch.distributed`` over RCCL on GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+
+def greedy_assign(resolutions: Sequence[int], n_ranks: int, outstanding: Dict[int, int] = None) -> List[int]:
+    """dp_rank for every request, in arrival order: argmin of outstanding pixels, then add resolution^2 to it
+    (greedy.py:26-34; ties go to the lowest rank as ``min(dict, key=dict.get)`` does on an insertion-ordered dict)."""
+    load = {r: 0 for r in range(n_ranks)}
+    if outstanding:
+        load.update(outstanding)
+    out = []
+    for res in resolutions:
+        target = min(load, key=load.get)
+        load[target] += int(res) ** 2
+        out.append(target)
+    return out
+
+
+def my_share(n_requests: int, rank: int, world: int, resolutions: Sequence[int] = None) -> List[int]:
+    """indices of the requests this rank serves."""
+    res = list(resolutions) if resolutions is not None else [1024] * n_requests
+    assign = greedy_assign(res, world)
+    return [i for i, r in enumerate(assign) if r == rank]
+
+
+def max_over_ranks(value: float, dist=None, device=None) -> float:
+    """max of a host scalar over ranks (the timed region of bench.py)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_stream_stats(latencies: List[float], window: Tuple[float, float], dist=None):
+    """(all latencies, (first arrival, last finish)) over ranks."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(latencies), window
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, (list(latencies), tuple(window)))
+    lat = [x for g in gathered for x in g[0]]
+    return lat, (min(g[1][0] for g in gathered), max(g[1][1] for g in gathered))
