@@ -1,23 +1,23 @@
-// bf16 MFMA GEMM / implicit-GEMM conv3x3, large-tile pipelined variant for gfx950 (MI355X).
+// bf16 MFMA GEMM / implicit-GEMM conv3x3, large-tile persistent pipelined variant for gfx950 (MI355X).
 //
 // Same math, orientation, swizzle and epilogues as gemm_bf16.hip (the generic fallback); what changes is the
-// schedule, built for the SDXL step shapes (M = B*H*W in {8192, 32768, 131072}, N in multiples of 320):
+// schedule, built for the SDXL / SD3.5 step shapes (M = B*H*W in {8192, 32768, 131072}, N in multiples of 320 or 128):
 //   * tile 256 tokens x BN features (BN = 160 or 128) x BK 64, 512 threads = 8 waves as 4(m) x 2(n): every SDXL
-//     GEMM/conv at UNet batch 8 then decomposes into a multiple of 256 workgroups -- one full wave of the chip's
-//     256 CUs, no tail round (with 128x128 tiles the N=1280 layers ran 640 tiles = 2.5 rounds);
+//     GEMM/conv at UNet batch 8 then decomposes into a multiple of 256 tiles -- whole rounds of the chip's 256 CUs,
+//     no tail round (with 128x128 tiles the N=1280 layers ran 640 tiles = 2.5 rounds);
+//   * PERSISTENT: one workgroup per CU walks its tiles (t = id, id + grid, ...) and treats their K tiles as ONE stream:
+//     the LDS-DMA for stream position g+2 is issued in iteration g, so the first two K tiles of the next output tile are
+//     already in flight while the current tile runs its epilogue (bias / activation / residual / stores) -- the
+//     prologue fill and the epilogue of consecutive tiles overlap instead of serialising (the per-tile fixed cost
+//     measured at ~15 us of a 40 us tile for K = 1280);
 //   * operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no staging VGPRs / ds_write), XOR swizzle applied on
 //     the per-lane SOURCE address (the LDS image of an LDS-DMA is lane-linear; cdna guide rule 21);
-//   * 3-stage LDS ring, loads issued two K tiles ahead and left in flight across the barrier with a COUNTED
-//     s_waitcnt vmcnt(N) + raw s_barrier (one barrier per K tile; cdna guide "Pipelining across barriers").
-//     All LDS lives in ONE __shared__ array and the main loop contains no ordinary global load, so hipcc has no
-//     reason to drain the DMA queue early.  A K tile is issued EVERY iteration (past the end the source is clamped
-//     and the bytes land in a stage nobody reads any more), so one counted wait serves every iteration and the body
-//     is a single basic block.
-//   * schedule SCHED 1: barrier at the top of the iteration, fragment reads of k-step 1 and the DMA issue interleaved
-//     with the MFMAs of k-step 0 (sched_group_barrier).
-//     schedule SCHED 4: barrier BETWEEN the two MFMA blocks of an iteration, so the k-step-0 fragments of the NEXT
-//     tile are read while the k-step-1 MFMAs of the current tile run: no fragment-read latency is exposed after a
-//     barrier.
+//   * 3-stage LDS ring, counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per K tile (cdna guide "Pipelining
+//     across barriers").  All LDS lives in ONE __shared__ array and the K loop contains no ordinary global load.  A DMA
+//     group is issued in EVERY iteration (past the end of the stream it reads a zero page into a stage nobody reads), so
+//     one counted wait serves every iteration; epilogue stores only make that wait more conservative, never wrong
+//     (vmcnt retires in order).  Fragment reads of k-step 1 and the DMA issue are interleaved with the MFMAs of
+//     k-step 0 (sched_group_barrier);
 //   * conv3x3: per-row source pointers are recomputed only when the tap changes (every Cin/64 K tiles) and otherwise
 //     just advance by one K tile; out-of-image taps and rows beyond M walk a zero page instead of branching.
 #include <cstdlib>
@@ -28,7 +28,7 @@
 
 namespace mx {
 
-// zero page the conv loader walks for padding taps: as long as the widest input channel count (bytes = 2*Cin)
+// zero page the loaders read for padding taps / past-the-end DMAs: as long as the widest input channel count (2*Cin bytes)
 constexpr int kZeroPageBytes = 16384;
 __device__ __attribute__((aligned(64))) unsigned int g_zero_page[kZeroPageBytes / 4] = {0};
 
@@ -43,7 +43,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int BN, bool CONV, int SCHED>
+// SINGLE: one tile per workgroup (grid == tiles): no tile loop, and the residual of the plain epilogue is prefetched before the
+// K loop.  !SINGLE: persistent, one workgroup per CU walking its tiles; pays only for launches of many rounds (measured:
+// +8..11 % at 4-16 rounds, -2..0 % at 2-3 rounds in same-device A/B, gpurun_out gemm_bench8; default: persistent from 4 rounds).
+template <int BN, bool CONV, bool SINGLE>
 __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   constexpr int NI = BN / 32;                 // 16-wide feature blocks per wave (wave covers BN/2 features)
   constexpr int MI = 4;                       // 16-wide token blocks per wave (wave covers 64 tokens)
@@ -60,47 +63,57 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   const int wm = wave >> 1;
   const int wn = wave & 1;
   const int mt = (p.M + BM2 - 1) / BM2;
-  const int m0 = (blockIdx.x % mt) * BM2;     // m fastest: workgroups with equal id mod 8 (one XCD) share X panels
-  const int n0 = (blockIdx.x / mt) * BN;
+  const int total_tiles = mt * (p.N / BN);
   const int nk = p.K / BK2;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
-
-  // ---- per-thread source descriptors (thread -> LDS chunk slot q = i*512 + tid; row = q>>3, slot c' = q&7) ----
   const int cs = tid & 7;
-  unsigned xoff[XI];        // GEMM: byte offset of (row, swizzled chunk) from p.a; rows beyond M clamp to M-1
-  const char* xcur[XI];     // CONV: current source pointer of the row for the current tap (advances 128 B per K tile)
+  const int tiles_per_tap = CONV ? p.Cin / BK2 : 1;
+
+  // ---- issue-side state: the (tile, K tile) the NEXT DMA group belongs to, and that tile's per-thread sources ----
+  int is_tile = blockIdx.x;     // tile id the cursor is in (>= total_tiles: past the end)
+  int is_kt = 0;
+  unsigned xoff[XI];            // GEMM: byte offset of (row, swizzled chunk) from p.a; rows beyond M clamp to M-1
+  const char* xcur[XI];         // CONV: current source pointer of the row for the current tap (advances 128 B per K tile)
   int cb[XI], cy[XI], cx[XI];
-  unsigned xchb[XI];        // CONV: byte offset of the thread's swizzled chunk inside a K tile
-#pragma unroll
-  for (int i = 0; i < XI; ++i) {
-    const int row = (i * 512 + tid) >> 3;
-    const int ch = swz2(row, cs);             // logical k-chunk this thread fetches for its slot
-    const int m = m0 + row;
-    if constexpr (!CONV) {
-      const int mc = m < p.M ? m : p.M - 1;   // clamped rows are computed and discarded by the epilogue mask
-      xoff[i] = (unsigned)((gemm_in_row(p, mc) * p.lda + ch * 8) * 2);
-    } else {
-      xchb[i] = ch * 16;
-      if (m < p.M) {
-        const int hw = p.Hout * p.Wout;
-        const int b = m / hw;
-        const int r = m - b * hw;
-        const int oy = r / p.Wout;
-        cb[i] = b; cy[i] = oy * p.stride; cx[i] = (r - oy * p.Wout) * p.stride;
-      } else {
-        cb[i] = -1; cy[i] = 0; cx[i] = 0;
-      }
-      xcur[i] = zero;
-    }
-  }
+  unsigned xchb[XI];            // byte offset of the thread's swizzled chunk inside a K tile
   unsigned woff[WI];
+  int tap_next = 0, in_tap = 0;
+
+  // per-thread sources of tile `t` (m fastest: workgroups with equal id mod 8 -- one XCD -- share X panels)
+  auto setup_tile = [&](int t) {
+    const int m0 = (t % mt) * BM2;
+    const int n0 = (t / mt) * BN;
 #pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    int q = i * 512 + tid;
-    if (q >= WCH) q -= WCH;                   // BN=160: the last instruction re-fetches rows 0..31 (same bytes, same slot)
-    const int row = q >> 3;
-    woff[i] = (unsigned)(((long)(n0 + row) * p.K + swz2(row, cs) * 8) * 2);
-  }
+    for (int i = 0; i < XI; ++i) {
+      const int row = (i * 512 + tid) >> 3;
+      const int ch = swz2(row, cs);           // logical k-chunk this thread fetches for its slot
+      const int m = m0 + row;
+      if constexpr (CONV) xchb[i] = ch * 16;
+      if constexpr (!CONV) {
+        const int mc = m < p.M ? m : p.M - 1; // clamped rows are computed and discarded by the epilogue mask
+        xoff[i] = (unsigned)((gemm_in_row(p, mc) * p.lda + ch * 8) * 2);
+      } else {
+        if (m < p.M) {
+          const int hw = p.Hout * p.Wout;
+          const int b = m / hw;
+          const int r = m - b * hw;
+          const int oy = r / p.Wout;
+          cb[i] = b; cy[i] = oy * p.stride; cx[i] = (r - oy * p.Wout) * p.stride;
+        } else {
+          cb[i] = -1; cy[i] = 0; cx[i] = 0;
+        }
+        xcur[i] = zero;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      int q = i * 512 + tid;
+      if (q >= WCH) q -= WCH;                 // BN=160: the last instruction re-fetches rows 0..31 (same bytes, same slot)
+      const int row = q >> 3;
+      woff[i] = (unsigned)(((long)(n0 + row) * p.K + swz2(row, cs) * 8) * 2);
+    }
+    tap_next = 0; in_tap = 0;
+  };
 
   // CONV: (re)compute the row pointers for tap `tap` at channel offset 0
   auto conv_set_tap = [&](int tap) {
@@ -124,19 +137,16 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
     }
   };
 
-  const int tiles_per_tap = CONV ? p.Cin / BK2 : 1;
-  int tap_next = 0, in_tap = 0;   // CONV: issue cursor (tiles are issued strictly in order 0,1,2,...)
-
-  // issue K tile `kt` (clamped to the last one) into ring stage `stage`
-  auto issue_tile = [&](int kt, int stage) {
+  // issue the DMA group at the cursor into ring stage `stage`, then advance the cursor
+  auto issue_next = [&](int stage) {
     bf16_t* st = smem + stage * STAGE_ELEMS;
-    const int ktc = kt < nk ? kt : nk - 1;
-    if constexpr (!CONV) {
-      const char* xb = reinterpret_cast<const char*>(p.a) + (long)ktc * (BK2 * 2);
+    bf16_t* sw = st + BM2 * BK2;
+    if (is_tile < total_tiles) {               // wave-uniform
+      if constexpr (!CONV) {
+        const char* xb = reinterpret_cast<const char*>(p.a) + (long)is_kt * (BK2 * 2);
 #pragma unroll
-      for (int i = 0; i < XI; ++i) glds16(xb + xoff[i], st + (i * 512 + wave * 64) * 8);
-    } else {
-      if (kt < nk) {                           // wave-uniform; past the end the pointers simply stay where they are
+        for (int i = 0; i < XI; ++i) glds16(xb + xoff[i], st + (i * 512 + wave * 64) * 8);
+      } else {
         if (in_tap == 0) conv_set_tap(tap_next);
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
@@ -144,25 +154,32 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
           xcur[i] += BK2 * 2;
         }
         if (++in_tap == tiles_per_tap) { in_tap = 0; ++tap_next; }
-      } else {
+      }
+      const char* wb = reinterpret_cast<const char*>(p.w) + (long)is_kt * (BK2 * 2);
 #pragma unroll
-        for (int i = 0; i < XI; ++i) glds16(zero + xchb[i], st + (i * 512 + wave * 64) * 8);
+      for (int i = 0; i < WI; ++i) {
+        const int qb = (i * 512 + wave * 64 >= WCH) ? i * 512 + wave * 64 - WCH : i * 512 + wave * 64;  // wave-uniform slot base
+        glds16(wb + woff[i], sw + qb * 8);
+      }
+      if (++is_kt == nk) {                     // cursor moves on to this workgroup's next tile
+        is_kt = 0;
+        if constexpr (SINGLE) {
+          is_tile = total_tiles;
+        } else {
+          is_tile += gridDim.x;
+          if (is_tile < total_tiles) setup_tile(is_tile);
+        }
+      }
+    } else {                                   // past the end of the stream: same instruction count, harmless bytes
+#pragma unroll
+      for (int i = 0; i < XI; ++i) glds16(zero + lane * 16, st + (i * 512 + wave * 64) * 8);
+#pragma unroll
+      for (int i = 0; i < WI; ++i) {
+        const int qb = (i * 512 + wave * 64 >= WCH) ? i * 512 + wave * 64 - WCH : i * 512 + wave * 64;
+        glds16(zero + lane * 16, sw + qb * 8);
       }
     }
-    bf16_t* sw = st + BM2 * BK2;
-    const char* wb = reinterpret_cast<const char*>(p.w) + (long)ktc * (BK2 * 2);
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-      const int qb = (i * 512 + wave * 64 >= WCH) ? i * 512 + wave * 64 - WCH : i * 512 + wave * 64;  // wave-uniform slot base
-      glds16(wb + woff[i], sw + qb * 8);
-    }
   };
-
-  f32x4 acc[NI][MI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15;
   const int fq = lane >> 4;
@@ -181,108 +198,98 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       xf[j] = *reinterpret_cast<const bf16x8*>(&sx[row * BK2 + swz2(row, ks * 4 + fq) * 8]);
     }
   };
-  auto mfma_block = [&](const bf16x8 (&wf)[NI], const bf16x8 (&xf)[MI]) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-  };
-  auto wait_tile = [&]() {   // all but the youngest tile's DMA instructions of this thread have completed
-    if constexpr (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  };
   constexpr int NM = NI * MI;
   constexpr int NF = NI + MI;
 
-  // residual of the plain epilogue: issue its loads first (oldest in the vmcnt queue), consume them after the K loop
-  u32x2 rpre[NI][MI];
-  const bool use_pre = p.residual != nullptr && !(p.flags & (MX_EPI_GEGLU | MX_EPI_QKV));
-  if (use_pre) gemm_prefetch_residual<NI, MI>(p, rpre, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq);
+  // SINGLE: residual of the plain epilogue: issue its loads before any DMA (oldest in the vmcnt queue, so the counted waits
+  // cover them) and consume them after the K loop.  Persistent launches read the residual in the epilogue, under the next
+  // tile's DMA.
+  constexpr bool kPre = SINGLE;   // (the few VGPR spills this causes at BN=160 sit before/after the K loop, not inside it)
+  u32x2 rpre[kPre ? NI : 1][MI];
+  const bool use_pre = kPre && p.residual != nullptr && !(p.flags & (MX_EPI_GEGLU | MX_EPI_QKV));
+  if constexpr (kPre) {
+    if (use_pre) gemm_prefetch_residual<NI, MI>(p, rpre, (blockIdx.x % mt) * BM2 + wm * 64, (blockIdx.x / mt) * BN + wn * (BN / 2), fr, fq);
+  }
 
-  issue_tile(0, 0);
-  issue_tile(1, 1);
+  setup_tile(is_tile);
+  issue_next(0);
+  issue_next(1);
 
-  if constexpr (SCHED == 1) {
+  int stage = 0;   // ring stage of the K tile being computed (stream position modulo 3)
+  for (int tile = blockIdx.x; tile < total_tiles; tile += (SINGLE ? total_tiles : (int)gridDim.x)) {
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     for (int kt = 0; kt < nk; ++kt) {
-      wait_tile();
+      // all but the youngest DMA group (and anything younger) of this thread has completed => stream position g landed
+      if constexpr (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const int stage = kt % NSTAGE;
       bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
       load_frags(stage, 0, wf0, xf0);
-      issue_tile(kt + 2, (kt + 2) % NSTAGE);   // that stage was last read in iteration kt-1, which every wave has left
+      const int st2 = stage >= 1 ? stage - 1 : 2;   // (g + 2) % 3: last read in iteration g-1, which every wave has left
+      issue_next(st2);
       load_frags(stage, 1, wf1, xf1);
-      mfma_block(wf0, xf0);
-      mfma_block(wf1, xf1);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);                 // fragment reads of k-step 0
 #pragma unroll
-      for (int g = 0; g < LOADS; ++g) {
+      for (int s = 0; s < LOADS; ++s) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                // one LDS-DMA (VMEM read)
       }
 #pragma unroll
-      for (int g = 0; g < (NF + 1) / 2; ++g) {
+      for (int s = 0; s < (NF + 1) / 2; ++s) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // fragment reads of k-step 1
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - LOADS - (NF + 1) / 2, 0);
+      stage = stage == 2 ? 0 : stage + 1;
     }
-  } else {
-    // SCHED 4.  Invariant at the top of iteration kt: the k-step-0 fragments of tile kt are in (wf0, xf0), tile kt+1
-    // is in flight or landed in stage (kt+1)%3, stage (kt+2)%3 is free.
-    bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
-    wait_tile();
-    __builtin_amdgcn_s_barrier();
-    load_frags(0, 0, wf0, xf0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int stage = kt % NSTAGE;
-      load_frags(stage, 1, wf1, xf1);
-      mfma_block(wf0, xf0);                     // k-step 0 of tile kt, with the k-step-1 fragment reads in its shadow
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-      for (int g = 0; g < (NF - 1) / 2; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, NM - (NF - 1) / 2, 0);
-      issue_tile(kt + 2, (kt + 2) % NSTAGE);    // stage (kt+2)%3 == (kt-1)%3: every wave passed a barrier after reading it
-      wait_tile();                              // all but tile kt+2's DMAs of this thread done => tile kt+1 has landed
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the stage others will restage are retired
-      __builtin_amdgcn_s_barrier();
-      load_frags((kt + 1) % NSTAGE, 0, wf0, xf0);   // next tile's k-step-0 fragments (stale bytes past the end, never used)
-      mfma_block(wf1, xf1);                     // k-step 1 of tile kt covers those reads
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-      for (int g = 0; g < (NF - 1) / 2; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, NM - (NF - 1) / 2, 0);
+
+    const int m0 = (tile % mt) * BM2, n0 = (tile / mt) * BN;
+    if constexpr (kPre) {
+      if (use_pre) gemm_epilogue<NI, MI, BN, true>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq, rpre);
+      else gemm_epilogue<NI, MI, BN, false>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq);
+    } else {
+      gemm_epilogue<NI, MI, BN, false>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail DMAs before the kernel moves on
-
-  if (use_pre) gemm_epilogue<NI, MI, BN, true>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq, rpre);
-  else gemm_epilogue<NI, MI, BN, false>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq);
-}
-
-template <int SCHED>
-static void launch_sched(hipStream_t s, const GemmArgs& a, bool conv, int bn) {
-  const int mt = cdiv(a.M, BM2);
-  dim3 grid(mt * (a.N / bn)), block(512);
-  if (bn == 160) {
-    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<160, true, SCHED>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_v2_kernel<160, false, SCHED>), grid, block, 0, s, a);
-  } else {
-    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<128, true, SCHED>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_v2_kernel<128, false, SCHED>), grid, block, 0, s, a);
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end DMAs before the workgroup retires
 }
 
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn) {
-  static const int sched = [] { const char* e = getenv("MX_V2_SCHED"); return e ? atoi(e) : 1; }();
-  if (sched == 4) launch_sched<4>(s, a, conv, bn);
-  else launch_sched<1>(s, a, conv, bn);
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    }
+    return n;
+  }();
+  const int tiles = cdiv(a.M, BM2) * (a.N / bn);
+  static const int persist_rounds = [] { const char* e = getenv("MX_V2_PERSIST_ROUNDS"); return e ? atoi(e) : 4; }();
+  const bool single = tiles < persist_rounds * ncu || tiles <= ncu;
+  dim3 grid(single ? tiles : ncu), block(512);   // persistent: one workgroup per CU (the LDS ring fills the CU)
+#define MX_V2(BN_, CONV_) \
+  do { \
+    if (single) hipLaunchKernelGGL((gemm_v2_kernel<BN_, CONV_, true>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((gemm_v2_kernel<BN_, CONV_, false>), grid, block, 0, s, a); \
+  } while (0)
+  if (bn == 160) { if (conv) MX_V2(160, true); else MX_V2(160, false); }
+  else { if (conv) MX_V2(128, true); else MX_V2(128, false); }
+#undef MX_V2
   return 0;
 }
 
