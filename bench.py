@@ -39,6 +39,24 @@ KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<12
               "gemm_v2_kernel<160,true> (conv3x3)", "gemm_v2_kernel<128,false>", "gemm_v2_kernel<128,true> (conv3x3)"]
 
 
+def pmc_traffic_bytes(kernel_label):
+    """HBM bytes per launch of a kernel symbol from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*; FETCH_SIZE
+    doubled per the gfx950 correction + WRITE_SIZE, tools/pmc_traffic.py).  PMC cannot be collected inside the timed run."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.txt")))
+    if not files:
+        return None, None
+    m = re.match(r"(\w+)<(\d+),(\w+)>", kernel_label)
+    if not m:
+        return None, None
+    want = f"mx::{m.group(1)}<{m.group(2)}, {m.group(3)}, true>"       # the one-tile-per-workgroup instantiation dominates
+    for line in open(files[-1]):
+        if line.startswith(want):
+            return float(line.split()[-1]) * 1e6, os.path.basename(files[-1])
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,8 +240,11 @@ def main():
         mf = [k for k in kinds if k["tflops"]]
         if mf:
             dom = max(mf, key=lambda k: k["ms_total"])
+            traffic, src = pmc_traffic_bytes(dom["kernel"])
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_BF16 / 1e12,
-                                  "unit": "TFLOP/s", "frac": dom["tflops"] / (MFMA_PEAK_BF16 / 1e12), "traffic": None,
+                                  "unit": "TFLOP/s", "frac": dom["tflops"] / (MFMA_PEAK_BF16 / 1e12), "traffic": traffic,
+                                  "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,
+                                  "algorithmic_bytes_per_launch": dom["gbps"] * 1e9 * dom["avg_us"] * 1e-6,
                                   "launches_per_step": dom["launches"], "avg_launch_us": dom["avg_us"]}
     if dist is not None:
         dist.barrier()
