@@ -3,7 +3,8 @@
 //   O[b, i, h, :] = softmax_j(Q[b,i,h,:] . K[b,j,h,:] * scale) V[b,j,h,:]
 //
 // Serves the reference's xformers.ops.memory_efficient_attention(q, k, v) call sites
-// (sduss/model_executor/modules/attention.py:86, 172, 195, 214): no mask, no dropout, scale 1/sqrt(d).
+// (sduss/model_executor/modules/attention.py:86, 172, 195, 214) and the SD3 joint / dual attention
+// (F.scaled_dot_product_attention, attention.py:324, 350, 394): no mask, no dropout, scale 1/sqrt(d).
 //
 // MI355X-first structure (cdna guide section 3 "An accumulator tile as the next MFMA's operand"):
 //   * one wave = 32 query rows, 4 waves / workgroup, KV tiles of 64 keys staged in LDS and shared;
@@ -15,6 +16,10 @@
 //     (row = 16s + 8(j>>2) + 4h + (j&3));
 //   * LDS images are XOR-swizzled so both the ds_read_b128 K reads and the ds_read_b64 V^T reads are
 //     bank-conflict free (K: chunk ^= (row>>1)&7; V^T: 8-byte piece ^= ((row>>1)&7)<<1 | (row>>4)&1).
+//   * the kernel is VALU-bound at head_dim 64 (32 exp2 + ~90 other vector ops against 16 MFMAs per wave and tile), so the
+//     loop carries no avoidable vector work: every LDS address is a loop-invariant per-lane offset whose buffer bit is
+//     toggled by one XOR per tile, key/V^T masking exists only in a separate tail-tile path, P is packed with the
+//     two-operand v_cvt_pk_bf16_f32, and the first MFMA of each S^T block takes a zero accumulator literal.
 #include "common.h"
 #include "../../include/mxdenoise.h"
 
@@ -28,11 +33,17 @@ struct AttnArgs {
   float scale_log2;  // scale * log2(e)
 };
 
-constexpr int KT = 64;  // keys per tile
+constexpr int KT = 64;                 // keys per tile
+constexpr int kBufBytes = 16384;       // one ring buffer: K tile (8 KB) then V^T tile (8 KB)
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) bf16_t sK[2][KT * 64];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[2][64 * KT];
+  __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -53,35 +64,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
 
-  // ---- staging: 512 16-byte chunks per tile per operand, 2 per thread ----
-  const int srow = tid >> 3;  // + 32*i
+  // ---- staging: 512 16-byte chunks per tile per operand, 2 per thread (rows srow, srow+32; chunk sch) ----
+  const int srow = tid >> 3;
   const int sch = tid & 7;
   const bf16_t* kbase = p.k + (long)b * p.Lk * p.ldk + head * 64 + sch * 8;
   const bf16_t* vbase = p.vt + (long)b * p.vt_bstride + ((long)head * 64) * p.ldvt + sch * 8;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   u32x4 rk[2], rv[2];
+  // (row>>1)&7 and (row>>4)&1 are the same for rows srow and srow+32: one store offset, +4096 B for the second row
+  unsigned st_off = (unsigned)(srow * 128 + ((sch ^ ((srow >> 1) & 7)) * 16));     // byte offset inside the K image of buffer 0
+  const bool st_swap = ((srow >> 4) & 1) != 0;
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt) {               // full tile: no predicates
+    const int key0 = kt * KT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rk[i] = *reinterpret_cast<const u32x4*>(kbase + (long)(key0 + srow + 32 * i) * p.ldk);
+      rv[i] = *reinterpret_cast<const u32x4*>(vbase + (long)(srow + 32 * i) * p.ldvt + key0);
+    }
+  };
+  auto load_tile_tail = [&](int kt) {          // last, partial tile: keys >= Lk are zero-filled (0 * garbage must not be NaN)
     const int key0 = kt * KT;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int key = key0 + srow + 32 * i;
       rk[i] = (key < p.Lk) ? *reinterpret_cast<const u32x4*>(kbase + (long)key * p.ldk) : zero4;
     }
-    const int nvalid = p.Lk - (key0 + sch * 8);  // valid keys in this thread's V^T chunk
+    const int nvalid = p.Lk - (key0 + sch * 8);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int d = srow + 32 * i;
       u32x4 v = zero4;
       if (nvalid > 0) {
-        v = *reinterpret_cast<const u32x4*>(vbase + (long)d * p.ldvt + key0);
-        if (nvalid < 8) {  // zero the keys >= Lk so that 0 * garbage can never be NaN
+        v = *reinterpret_cast<const u32x4*>(vbase + (long)(srow + 32 * i) * p.ldvt + key0);
+        if (nvalid < 8) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int lo = 2 * e, hi = 2 * e + 1;
             unsigned w = v[e];
-            if (lo >= nvalid) w &= 0xffff0000u;
-            if (hi >= nvalid) w &= 0x0000ffffu;
+            if (2 * e >= nvalid) w &= 0xffff0000u;
+            if (2 * e + 1 >= nvalid) w &= 0x0000ffffu;
             v[e] = w;
           }
         }
@@ -89,17 +109,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
       rv[i] = v;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](unsigned off) {        // off = st_off with the destination buffer's bit set
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = srow + 32 * i;
-      *reinterpret_cast<u32x4*>(&sK[buf][row * 64 + ((sch ^ ((row >> 1) & 7)) * 8)]) = rk[i];
-      // V^T: chunk swizzle + swap the two 8-byte halves on rows with bit 4 set
+      *reinterpret_cast<u32x4*>(smem + off + i * 4096) = rk[i];
       u32x4 v = rv[i];
-      if ((row >> 4) & 1) v = u32x4{v[2], v[3], v[0], v[1]};
-      *reinterpret_cast<u32x4*>(&sV[buf][row * 64 + ((sch ^ ((row >> 1) & 7)) * 8)]) = v;
+      if (st_swap) v = u32x4{v[2], v[3], v[0], v[1]};   // V^T: swap the 8-byte halves on rows with bit 4 set
+      *reinterpret_cast<u32x4*>(smem + off + 8192 + i * 4096) = v;
     }
   };
+
+  // ---- per-lane LDS read offsets for buffer 0 (loop invariant; the buffer bit is XOR-toggled per tile) ----
+  unsigned koff[4], voff0[4], voff1[4];
+  {
+    const int swz = (r >> 1) & 7;
+    const int vf = (swz << 1) | ((r >> 4) & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(r * 128 + (((2 * ks + hh) ^ swz) * 16));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      voff0[s] = (unsigned)(8192 + r * 128 + (((4 * s + hh) ^ vf) * 8));
+      voff1[s] = (unsigned)(8192 + r * 128 + (((4 * s + 2 + hh) ^ vf) * 8));
+    }
+  }
 
   f32x16 oacc[2];
 #pragma unroll
@@ -110,33 +142,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   float l_run = 0.f;        // this half-wave's partial row sum
 
   const int ntiles = (p.Lk + KT - 1) / KT;
+  const bool ragged = (p.Lk % KT) != 0;
   const float c = p.scale_log2;
-  const int vf = (((r >> 1) & 7) << 1) | ((r >> 4) & 1);  // V^T piece swizzle of rows db*32 + r
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
-  store_tile(0);
+  if (ntiles == 1 && ragged) load_tile_tail(0); else load_tile(0);
+  store_tile(st_off);
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < ntiles) load_tile(kt + 1);
+    const bool has_next = kt + 1 < ntiles;
+    if (has_next) {
+      if (ragged && kt + 2 == ntiles) load_tile_tail(kt + 1); else load_tile(kt + 1);
+    }
 
     // ---- S^T = K Q^T : two 32-key blocks ----
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
-      const int row = kb * 32 + r;
-#pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int ch = (2 * ks + hh) ^ ((row >> 1) & 7);
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[buf][row * 64 + ch * 8]);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + koff[ks] + kb * 4096);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
       }
     }
-    // mask keys beyond Lk (last tile only)
-    if (kt * KT + KT > p.Lk) {
+    if (ragged && !has_next) {          // mask keys beyond Lk (tail tile only)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -178,22 +208,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
       for (int s2 = 0; s2 < 2; ++s2) {
         u32x4 pw;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pw[e] = pack_bf16x2(s[kb][8 * s2 + 2 * e], s[kb][8 * s2 + 2 * e + 1]);
+        for (int e = 0; e < 4; ++e) pw[e] = pack2(s[kb][8 * s2 + 2 * e], s[kb][8 * s2 + 2 * e + 1]);
         const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
         const int sidx = 2 * kb + s2;  // 16-key step inside the tile
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const int row = db * 32 + r;
-          const int p0 = (4 * sidx + hh) ^ vf;
-          const int p1 = (4 * sidx + 2 + hh) ^ vf;
-          const u32x2 a0 = *reinterpret_cast<const u32x2*>(&sV[buf][row * 64 + p0 * 4]);
-          const u32x2 a1 = *reinterpret_cast<const u32x2*>(&sV[buf][row * 64 + p1 * 4]);
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(smem + voff0[sidx] + db * 4096);
+          const u32x2 a1 = *reinterpret_cast<const u32x2*>(smem + voff1[sidx] + db * 4096);
           const u32x4 aw = {a0[0], a0[1], a1[0], a1[1]};
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw), pf, oacc[db], 0, 0, 0);
         }
       }
     }
-    if (kt + 1 < ntiles) store_tile(buf ^ 1);
+    // the next tile lives in the other buffer: toggle the buffer bit of every offset
+    st_off ^= kBufBytes;
+    if (has_next) store_tile(st_off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { koff[i] ^= kBufBytes; voff0[i] ^= kBufBytes; voff1[i] ^= kBufBytes; }
     __syncthreads();
   }
 
@@ -208,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * hh;
-        u32x2 o = {pack_bf16x2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv),
-                   pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
+        u32x2 o = {pack2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv),
+                   pack2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
         *reinterpret_cast<u32x2*>(op + d) = o;
       }
   }

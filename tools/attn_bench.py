@@ -1,0 +1,40 @@
+"""Attention microbenchmark over the step shapes (random bf16 data), through the C ABI.
+Usage on the GPU box: python tools/attn_bench.py"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sduss_amd import ops  # noqa: E402
+
+SHAPES = [(8, 10, 4096, 4096), (8, 20, 1024, 1024), (8, 24, 4429, 4429), (8, 20, 1024, 77)]   # (B, H, Lq, Lk)
+
+
+def main():
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    iters = int(os.environ.get("ITERS", "10"))
+    for b, h, lq, lk in SHAPES:
+        c = h * 64
+        q = torch.randn(b * lq, c, device=dev, generator=g).to(torch.bfloat16)
+        k = torch.randn(b * lk, c, device=dev, generator=g).to(torch.bfloat16)
+        ldvt = (lk + 7) // 8 * 8
+        vt = torch.randn(b, c, ldvt, device=dev, generator=g).to(torch.bfloat16)
+        for _ in range(2):
+            ops.attention(q, k, vt, h, lq, lk)
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            ops.attention(q, k, vt, h, lq, lk)
+        e.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(e) / iters * 1e-3
+        fl = 4.0 * b * h * lq * lk * 64
+        print(f"attn B{b} H{h} Lq{lq} Lk{lk}  {t * 1e6:9.1f} us  {fl / t / 1e12:7.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
