@@ -108,7 +108,7 @@ typedef struct mx_gemm_desc {
   /* joint-sequence support (MMDiT): rows live in per-sample blocks of a longer sequence.
    * input  row of m = (m / rows_per_batch) * a_batch_rows + a_row_off + m % rows_per_batch   (a_batch_rows > 0)
    * output row of m = (m / rows_per_batch) * c_batch_rows + c_row_off + m % rows_per_batch   (c_batch_rows > 0);
-   * it addresses C, the residual and, under MX_EPI_QKV, the key index of vt (then ldvt >= c_batch_rows). */
+   * it addresses C, the residual and, under MX_EPI_QKV, the key index of vt (then ldvt >= MX_VT_LD(c_batch_rows)). */
   int a_batch_rows, a_row_off, c_batch_rows, c_row_off;
   const float* gate;     /* fp32 [M / rows_per_batch, ldg] or NULL: v = gate * (acc + bias) before the residual add */
   int ldg;
@@ -117,9 +117,18 @@ typedef struct mx_gemm_desc {
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
 int mx_conv3x3(void* stream, const mx_gemm_desc* d);   /* implicit GEMM, pad 1 */
 
+/* V^T key order.  The attention kernel feeds its softmax accumulator straight back to the matrix core as the
+ * P operand, and that register layout interleaves keys in blocks of four (lane half h owns keys 4h..4h+3 and
+ * 8+4h..8+4h+3 of every 16).  V^T is therefore stored with bits 2 and 3 of the key index swapped, so that each
+ * lane's eight V^T values are one aligned 16-byte word.  MX_VT_POS is its own inverse; rows are MX_VT_LD(Lk) long.
+ * mx_gemm's MX_EPI_QKV epilogue writes this order; pad positions need not be initialised. */
+#define MX_VT_POS(key) (((key) & ~12) | (((key) & 4) << 1) | (((key) & 8) >> 1))
+#define MX_VT_LD(Lk) (((Lk) + 15) / 16 * 16)
+
 /* softmax(Q K^T * scale) V per (batch, head); head_dim 64.
  * q: bf16 rows (b*Lq + i), head h at columns [64h, 64h+64), row stride ldq; k likewise (Lk, ldk);
- * vt: bf16, V transposed: element (b, h, d, key) at vt[b*vt_batch_stride + (h*64 + d)*ldvt + key];
+ * vt: bf16, V transposed: element (b, h, d, key) at vt[b*vt_batch_stride + (h*64 + d)*ldvt + MX_VT_POS(key)],
+ *     ldvt >= MX_VT_LD(Lk) and a multiple of 8;
  * o: bf16 [B*Lq, ldo]. */
 int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                  int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale);

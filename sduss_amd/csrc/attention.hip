@@ -11,11 +11,11 @@
 //   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (K rows are the A operand, Q rows the B operand), so a
 //     lane owns ONE query column and 2x16 key rows: row max / sum are in-lane plus one cross-half shuffle;
 //   * the S^T accumulator, converted to bf16, IS the B operand of O^T += V^T P^T -- no LDS round trip for P;
-//     V arrives already transposed (V^T[d][key], written by the QKV GEMM epilogue), so its A fragments are
-//     plain 8-byte LDS reads in the permuted k order the accumulator layout dictates
-//     (row = 16s + 8(j>>2) + 4h + (j&3));
-//   * LDS images are XOR-swizzled so both the ds_read_b128 K reads and the ds_read_b64 V^T reads are
-//     bank-conflict free (K: chunk ^= (row>>1)&7; V^T: 8-byte piece ^= ((row>>1)&7)<<1 | (row>>4)&1).
+//     V arrives already transposed (V^T[d][key], written by the QKV GEMM epilogue) AND with bits 2/3 of the key index
+//     swapped (MX_VT_POS), which is exactly the k order the accumulator layout dictates
+//     (element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)): a V^T A fragment is one aligned ds_read_b128;
+//   * both LDS images share one XOR swizzle (16-byte chunk ^= (row>>1)&7 on 128-byte rows), so K and V^T reads use
+//     the same per-lane offsets and are bank-conflict free;
 //   * the kernel is VALU-bound at head_dim 64 (32 exp2 + ~90 other vector ops against 16 MFMAs per wave and tile), so the
 //     loop carries no avoidable vector work: every LDS address is a loop-invariant per-lane offset whose buffer bit is
 //     toggled by one XOR per tile, key/V^T masking exists only in a separate tail-tile path, P is packed with the
@@ -40,6 +40,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {   // one v_cvt_pk_bf16_f32
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+
+// max over the two half-waves (lane l and l^32) without the LDS crossbar: v_permlane32_swap exchanges the upper half
+// of a with the lower half of b.  Inline asm because the builtin folds its two results when both inputs are one value.
+__device__ __forceinline__ float max_across_halves(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
 }
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
@@ -71,9 +79,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   const bf16_t* vbase = p.vt + (long)b * p.vt_bstride + ((long)head * 64) * p.ldvt + sch * 8;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   u32x4 rk[2], rv[2];
-  // (row>>1)&7 and (row>>4)&1 are the same for rows srow and srow+32: one store offset, +4096 B for the second row
+  // (row>>1)&7 is the same for rows srow and srow+32: one store offset, +4096 B for the second row
   unsigned st_off = (unsigned)(srow * 128 + ((sch ^ ((srow >> 1) & 7)) * 16));     // byte offset inside the K image of buffer 0
-  const bool st_swap = ((srow >> 4) & 1) != 0;
 
   auto load_tile = [&](int kt) {               // full tile: no predicates
     const int key0 = kt * KT;
@@ -90,18 +97,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
       const int key = key0 + srow + 32 * i;
       rk[i] = (key < p.Lk) ? *reinterpret_cast<const u32x4*>(kbase + (long)key * p.ldk) : zero4;
     }
-    const int nvalid = p.Lk - (key0 + sch * 8);
+    // chunk sch holds positions 8*sch .. +7 = keys ka .. ka+3 then ka+8 .. ka+11 (MX_VT_POS), ka = 16*(sch>>1) + 4*(sch&1)
+    const int ka = key0 + 16 * (sch >> 1) + 4 * (sch & 1);
+    const int nvalid = p.Lk - ka;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       u32x4 v = zero4;
       if (nvalid > 0) {
         v = *reinterpret_cast<const u32x4*>(vbase + (long)(srow + 32 * i) * p.ldvt + key0);
-        if (nvalid < 8) {
+        if (nvalid < 12) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            const int kk = 2 * (e & 1) + 8 * (e >> 1);   // key offset of the word's low half
             unsigned w = v[e];
-            if (2 * e >= nvalid) w &= 0xffff0000u;
-            if (2 * e + 1 >= nvalid) w &= 0x0000ffffu;
+            if (kk >= nvalid) w &= 0xffff0000u;
+            if (kk + 1 >= nvalid) w &= 0x0000ffffu;
             v[e] = w;
           }
         }
@@ -113,24 +123,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<u32x4*>(smem + off + i * 4096) = rk[i];
-      u32x4 v = rv[i];
-      if (st_swap) v = u32x4{v[2], v[3], v[0], v[1]};   // V^T: swap the 8-byte halves on rows with bit 4 set
-      *reinterpret_cast<u32x4*>(smem + off + 8192 + i * 4096) = v;
+      *reinterpret_cast<u32x4*>(smem + off + 8192 + i * 4096) = rv[i];
     }
   };
 
   // ---- per-lane LDS read offsets for buffer 0 (loop invariant; the buffer bit is XOR-toggled per tile) ----
-  unsigned koff[4], voff0[4], voff1[4];
+  // row r, chunk 2*step + hh: the K fragment of k-step `step` and (at +8192) the V^T fragment of 16-key step `step`
+  unsigned koff[4];
   {
     const int swz = (r >> 1) & 7;
-    const int vf = (swz << 1) | ((r >> 4) & 1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(r * 128 + (((2 * ks + hh) ^ swz) * 16));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      voff0[s] = (unsigned)(8192 + r * 128 + (((4 * s + hh) ^ vf) * 8));
-      voff1[s] = (unsigned)(8192 + r * 128 + (((4 * s + 2 + hh) ^ vf) * 8));
-    }
   }
 
   f32x16 oacc[2];
@@ -156,16 +159,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
       if (ragged && kt + 2 == ntiles) load_tile_tail(kt + 1); else load_tile(kt + 1);
     }
 
-    // ---- S^T = K Q^T : two 32-key blocks ----
+    // ---- S^T = K Q^T : two 32-key blocks.  All eight K fragments are requested before the first MFMA and the two
+    //      accumulator chains alternate, so neither LDS latency nor the MFMA dependency sits between issues. ----
+    bf16x8 fr[8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fr[kb * 4 + ks] = *reinterpret_cast<const bf16x8*>(smem + koff[ks] + kb * 4096);
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + koff[ks] + kb * 4096);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
-      }
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
     }
+    // V^T fragments (same registers): in flight while the softmax runs on the vector ALU
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) fr[sidx * 2 + db] = *reinterpret_cast<const bf16x8*>(smem + koff[sidx] + 8192 + db * 4096);
+    __builtin_amdgcn_sched_barrier(0);
     if (ragged && !has_next) {          // mask keys beyond Lk (tail tile only)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx_ = fmaxf(mx_, s[kb][e]);
-    mx_ = fmaxf(mx_, __shfl_xor(mx_, 32, 64));
+    mx_ = max_across_halves(mx_);
     const float m_new = fmaxf(m_run, mx_ * c);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
@@ -212,19 +226,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
         const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
         const int sidx = 2 * kb + s2;  // 16-key step inside the tile
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const u32x2 a0 = *reinterpret_cast<const u32x2*>(smem + voff0[sidx] + db * 4096);
-          const u32x2 a1 = *reinterpret_cast<const u32x2*>(smem + voff1[sidx] + db * 4096);
-          const u32x4 aw = {a0[0], a0[1], a1[0], a1[1]};
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw), pf, oacc[db], 0, 0, 0);
-        }
+        for (int db = 0; db < 2; ++db)
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[sidx * 2 + db], pf, oacc[db], 0, 0, 0);
       }
     }
     // the next tile lives in the other buffer: toggle the buffer bit of every offset
     st_off ^= kBufBytes;
     if (has_next) store_tile(st_off);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { koff[i] ^= kBufBytes; voff0[i] ^= kBufBytes; voff1[i] ^= kBufBytes; }
+    for (int i = 0; i < 4; ++i) koff[i] ^= kBufBytes;
     __syncthreads();
   }
 
@@ -255,7 +265,7 @@ extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k,
   MX_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
   MX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: strides must be multiples of 8 elements");
   MX_CHECK(ldq >= H * 64 && ldk >= H * 64 && ldo >= H * 64, "attention: row stride smaller than H*64");
-  MX_CHECK(ldvt >= ((Lk + 7) / 8) * 8, "attention: ldvt must cover Lk rounded up to 8");
+  MX_CHECK(ldvt >= MX_VT_LD(Lk), "attention: ldvt must cover MX_VT_LD(Lk) (keys are stored in MX_VT_POS order)");
   MX_CHECK(vt_batch_stride % 8 == 0 && vt_batch_stride >= (int64_t)H * 64 * ldvt, "attention: bad vt_batch_stride");
   AttnArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.o = (bf16_t*)o;

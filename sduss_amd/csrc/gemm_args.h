@@ -141,7 +141,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
       if (qkv) {
         const int nin = n - seg_idx * p.seg;  // position inside the segment
         if (to_vt) {
-          const int key = (p.c_batch_rows > 0 ? p.c_row_off : 0) + m - bidx * p.rows_per_batch;
+          const int key0 = (p.c_batch_rows > 0 ? p.c_row_off : 0) + m - bidx * p.rows_per_batch;
+          const int key = MX_VT_POS(key0);      // attention's V^T key order (mxdenoise.h)
           const int nv = p.N / p.period;
           bf16_t* dst = p.vt + ((long)bidx * nv + (long)seg_grp * p.seg + nin) * p.ldvt + key;
 #pragma unroll

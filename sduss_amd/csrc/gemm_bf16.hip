@@ -249,7 +249,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(d->ldc >= d->N / 2 && d->ldc % 4 == 0, "gemm: bad ldc for GEGLU");
   } else if (d->flags & MX_EPI_QKV) {
     MX_CHECK(d->seg > 0 && d->seg % 64 == 0 && d->period >= 2 && d->N % (d->seg * d->period) == 0, "gemm: bad QKV segments");
-    MX_CHECK(d->vt != nullptr && d->ldvt >= (d->c_batch_rows > 0 ? d->c_batch_rows : d->rows_per_batch), "gemm: QKV needs vt and ldvt >= keys per batch");
+    MX_CHECK(d->vt != nullptr && d->ldvt >= MX_VT_LD(d->c_batch_rows > 0 ? d->c_batch_rows : d->rows_per_batch), "gemm: QKV needs vt and ldvt >= MX_VT_LD(keys per batch)");
     MX_CHECK(d->M % d->rows_per_batch == 0, "gemm: QKV needs M % rows_per_batch == 0");
     MX_CHECK(d->ldc >= d->N / d->period * (d->period - 1) && d->ldc % 4 == 0, "gemm: bad ldc for QKV");
     MX_CHECK(!(d->flags & MX_EPI_OUT_F32), "gemm: QKV output is bf16");

@@ -145,8 +145,8 @@ struct Plan {
     const int h = H / ps, wd = W / ps;
     const int L = h * wd;
     const int Lj = L + Lt;
-    const int ldvt_j = (Lj + 7) / 8 * 8;
-    const int ldvt_i = (L + 7) / 8 * 8;
+    const int ldvt_j = MX_VT_LD(Lj);
+    const int ldvt_i = MX_VT_LD(L);
     const int Kp = ps * ps * c.in_channels;
     const int MI = B * L, MT = B * Lt;
 

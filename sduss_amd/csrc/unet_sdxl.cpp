@@ -208,7 +208,7 @@ struct Plan {
     bf16_t* y = alloc<bf16_t>((size_t)M * C);
     linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C);
     bf16_t* ln = n;  // reuse
-    const int ldvt = (L + 7) / 8 * 8;
+    const int ldvt = MX_VT_LD(L);
     bf16_t* qk = alloc<bf16_t>((size_t)M * 2 * C);
     bf16_t* vt = alloc<bf16_t>((size_t)B * C * ldvt);
     bf16_t* ao = alloc<bf16_t>((size_t)M * C);
@@ -296,7 +296,7 @@ struct Plan {
       for (int i = 0; i < nlev; ++i) if (c.down_has_attn[i]) add(c.block_out_channels[i], c.layers_per_block * c.transformer_layers[i]);
       add(c.block_out_channels[nlev - 1], c.transformer_layers[nlev - 1]);
       for (int i = 0; i < nlev; ++i) { const int lv = nlev - 1 - i; if (c.down_has_attn[lv]) add(c.block_out_channels[lv], (c.layers_per_block + 1) * c.transformer_layers[lv]); }
-      const int ldvt = (ctx_len + 7) / 8 * 8;
+      const int ldvt = MX_VT_LD(ctx_len);
       for (auto& wv : widths) {
         const int dim = wv.first, nl = wv.second;
         KV e; e.dim = dim; e.next = 0; e.ldk = nl * dim; e.ldvt = ldvt; e.vt_bstride = (long)nl * dim * ldvt;

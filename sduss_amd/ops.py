@@ -43,15 +43,39 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return c
 
 
+def vt_ld(lk: int) -> int:
+    """MX_VT_LD: row length of a V^T image for lk keys."""
+    return (lk + 15) // 16 * 16
+
+
+def vt_pos(lk: int) -> torch.Tensor:
+    """MX_VT_POS for keys 0..lk-1 (bits 2 and 3 of the key index swapped; its own inverse)."""
+    k = torch.arange(lk)
+    return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)
+
+
+def pack_vt(v: torch.Tensor, pad: float = 0.0) -> torch.Tensor:
+    """v [B, Lk, C] -> V^T image [B, C, MX_VT_LD(Lk)] in the attention kernel's key order (include/mxdenoise.h)."""
+    b, lk, c = v.shape
+    vt = torch.full((b, c, vt_ld(lk)), pad, dtype=v.dtype, device=v.device)
+    vt[:, :, vt_pos(lk).to(v.device)] = v.permute(0, 2, 1)
+    return vt
+
+
+def unpack_vt(vt: torch.Tensor, lk: int) -> torch.Tensor:
+    """inverse of pack_vt: [B, C, ld] -> [B, Lk, C]."""
+    return vt[:, :, vt_pos(lk).to(vt.device)].permute(0, 2, 1)
+
+
 def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_batch: int):
     """Fused projection with the V segments written transposed.  Returns (c [M, N/period*(period-1)],
-    vt [M/rows_per_batch, N/period, ldvt])."""
+    vt [M/rows_per_batch, N/period, ldvt] in MX_VT_POS key order; see unpack_vt)."""
     l = _lib.load()
     _bf16(a); _bf16(w)
     m, k = a.shape
     n = w.shape[0]
     nb = m // rows_per_batch
-    ldvt = (rows_per_batch + 7) // 8 * 8
+    ldvt = vt_ld(rows_per_batch)
     c = torch.empty((m, n // period * (period - 1)), dtype=torch.bfloat16, device=a.device)
     vt = torch.zeros((nb, n // period, ldvt), dtype=torch.bfloat16, device=a.device)
     d = _lib.GemmDesc()

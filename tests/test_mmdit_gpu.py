@@ -104,7 +104,8 @@ def test_gemm_joint_row_remap_and_pos_broadcast(cuda_device):
     g = torch.Generator().manual_seed(8)
     b, li, lt, dm, k = 2, 256, 77, 128, 128
     lj = li + lt
-    ldvt = (lj + 7) // 8 * 8
+    from sduss_amd import ops
+    ldvt = ops.vt_ld(lj)
     qk = torch.zeros(b * lj, 2 * dm, dtype=torch.bfloat16, device="cuda")
     vt = torch.zeros(b, dm, ldvt, dtype=torch.bfloat16, device="cuda")
     wants = []
@@ -121,7 +122,7 @@ def test_gemm_joint_row_remap_and_pos_broadcast(cuda_device):
     qkc = qk.float().cpu().reshape(b, lj, 2 * dm); vtc = vt.float().cpu()
     for full, off, rows in wants:
         _close(qkc[:, off:off + rows], full[:, :, :2 * dm], 2.0 ** -7, "joint q|k rows")
-        _close(vtc[:, :, off:off + rows], full[:, :, 2 * dm:].permute(0, 2, 1), 2.0 ** -7, "joint V^T keys")
+        _close(ops.unpack_vt(vtc, lj)[:, off:off + rows], full[:, :, 2 * dm:], 2.0 ** -7, "joint V^T keys")
     # read the text rows back through the loader remap
     gg = torch.Generator().manual_seed(3)
     w2 = _rt(torch.randn(64, 2 * dm, generator=gg) * (2 * dm) ** -0.5)

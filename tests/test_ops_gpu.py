@@ -94,9 +94,10 @@ def test_gemm_qkv_split(cuda_device, period, rows, dim):
     c, vt = ops.gemm_qkv(_bf(a).cuda(), _bf(w).cuda(), dim, period, rows)
     segs = full.reshape(nb * rows, groups, period, dim)
     want_c = segs[:, :, :period - 1].reshape(nb * rows, -1)
-    want_v = segs[:, :, period - 1].reshape(nb, rows, groups * dim).permute(0, 2, 1)   # [nb, V cols, key]
+    want_v = segs[:, :, period - 1].reshape(nb, rows, groups * dim)                    # [nb, key, V cols]
     _close(c, want_c, 2.0 ** -7, "qkv row-major part")
-    _close(vt[:, :, :rows], want_v, 2.0 ** -7, "qkv transposed V")
+    assert vt.shape[2] == ops.vt_ld(rows)
+    _close(ops.unpack_vt(vt, rows), want_v, 2.0 ** -7, "qkv transposed V (MX_VT_POS key order)")
 
 
 @pytest.mark.parametrize("stride,up,corner,hw,cin,cout", [(1, 0, 0, 16, 64, 128), (2, 0, 0, 16, 128, 64), (1, 1, 0, 8, 64, 64),
@@ -134,9 +135,7 @@ def test_attention(cuda_device, lq, lk, heads):
     b, c = 2, heads * 64
     q = _rt(torch.randn(b, lq, c, generator=g)); k = _rt(torch.randn(b, lk, c, generator=g)); v = _rt(torch.randn(b, lk, c, generator=g))
     want = ref.attention(q, k, v, heads)
-    ldvt = (lk + 7) // 8 * 8
-    vt = torch.full((b, c, ldvt), float("nan"))       # the pad must never leak
-    vt[:, :, :lk] = v.permute(0, 2, 1)
+    vt = ops.pack_vt(v, pad=float("nan"))             # the pad must never leak
     got = ops.attention(_bf(q.reshape(-1, c)).cuda(), _bf(k.reshape(-1, c)).cuda(), _bf(vt).cuda(), heads, lq, lk)
     _close(got.reshape(b, lq, c), want, 2.0 ** -6, f"attention {lq}x{lk}")
 
@@ -150,7 +149,7 @@ def test_attention_spiked_max(cuda_device):
     k[0, 300] = q[0, 5] * 4.0   # one key aligned with one query: the max jumps in tile 4
     k[0, 450] = q[0, 77] * 6.0
     want = ref.attention(q, k, v, 1)
-    got = ops.attention(_bf(q.reshape(-1, c)).cuda(), _bf(k.reshape(-1, c)).cuda(), _bf(v.permute(0, 2, 1).contiguous()).cuda(), 1, l, l)
+    got = ops.attention(_bf(q.reshape(-1, c)).cuda(), _bf(k.reshape(-1, c)).cuda(), _bf(ops.pack_vt(v)).cuda(), 1, l, l)
     _close(got.reshape(b, l, c), want, 2.0 ** -6, "attention spiked")
 
 

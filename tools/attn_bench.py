@@ -20,7 +20,7 @@ def main():
         c = h * 64
         q = torch.randn(b * lq, c, device=dev, generator=g).to(torch.bfloat16)
         k = torch.randn(b * lk, c, device=dev, generator=g).to(torch.bfloat16)
-        ldvt = (lk + 7) // 8 * 8
+        ldvt = ops.vt_ld(lk)
         vt = torch.randn(b, c, ldvt, device=dev, generator=g).to(torch.bfloat16)
         for _ in range(2):
             ops.attention(q, k, vt, h, lq, lk)
