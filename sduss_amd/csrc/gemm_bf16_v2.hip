@@ -26,6 +26,10 @@
 #include "../../include/mxdenoise.h"
 #include "gemm_args.h"
 
+#ifndef MX_EXP
+#define MX_EXP 0   // tools/exp_build.sh: 1 = no MFMA, 2 = no LDS-DMA in the K loop, 3 = no fragment reads (diagnostics only)
+#endif
+
 namespace mx {
 
 // zero page the loaders read for padding taps / past-the-end DMAs: as long as the widest input channel count (2*Cin bytes)
@@ -229,10 +233,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
+#if MX_EXP == 3
+      for (int i = 0; i < NI; ++i) { wf0[i] = __builtin_bit_cast(bf16x8, acc[i][0]); wf1[i] = __builtin_bit_cast(bf16x8, acc[i][1]); }
+      for (int j = 0; j < MI; ++j) { xf0[j] = __builtin_bit_cast(bf16x8, acc[0][j]); xf1[j] = __builtin_bit_cast(bf16x8, acc[1][j]); }
+#else
       load_frags(stage, 0, wf0, xf0);
+#endif
       const int st2 = stage >= 1 ? stage - 1 : 2;   // (g + 2) % 3: last read in iteration g-1, which every wave has left
+#if MX_EXP != 2
       issue_next(st2);
+#endif
+#if MX_EXP != 3
       load_frags(stage, 1, wf1, xf1);
+#endif
+#if MX_EXP != 1
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -243,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+#endif
       __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);                 // fragment reads of k-step 0
 #pragma unroll
       for (int s = 0; s < LOADS; ++s) {

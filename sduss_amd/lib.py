@@ -105,10 +105,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MxError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("MXDENOISE_LIB", LIB_PATH)      # override: an out-of-tree or diagnostic build of the same ABI
+    if not os.path.exists(path):
+        raise MxError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       f"(or `make -C sduss_amd/csrc`). There is no CPU fallback for the product path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
