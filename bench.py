@@ -36,7 +36,8 @@ MFMA_PEAK_BF16 = 2.5e15                    # dense, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<128,true> (conv3x3)",
               "gemm_kernel<64,true> (conv3x3)", "attn_fwd_kernel", "groupnorm (3 kernels)", "gemm_v2_kernel<160,false>",
-              "gemm_v2_kernel<160,true> (conv3x3)", "gemm_v2_kernel<128,false>", "gemm_v2_kernel<128,true> (conv3x3)"]
+              "gemm_v2_kernel<160,true> (conv3x3)", "gemm_v2_kernel<128,false>", "gemm_v2_kernel<128,true> (conv3x3)",
+              "gemm_v3_kernel (256x256)"]
 
 
 def pmc_traffic_bytes(kernel_label):
@@ -227,7 +228,7 @@ def main():
         l.mx_profile_enable(1)
         step()
         torch.cuda.synchronize()
-        buf = (C.c_double * 40)()
+        buf = (C.c_double * 64)()
         lib.check(l.mx_profile_collect(buf), "mx_profile_collect")
         l.mx_profile_enable(0)
         kinds = []

@@ -34,9 +34,10 @@ const char* mx_last_error(void);
 int mx_version(void);
 /* Optional per-launch timing for bench.py's roofline leg: while enabled, every GEMM / conv / attention / norm launch
  * is bracketed by hipEvents on its own stream.  mx_profile_collect (after the stream is synchronised) fills
- * out[40] = for kind in {gemm<128>, gemm<64>, conv3x3<128>, conv3x3<64>, attention, groupnorm, gemm_v2<160>,
- *           conv3x3_v2<160>, gemm_v2<128>, conv3x3_v2<128>}:
+ * out[4 * MX_PROF_KINDS] = for kind in {gemm<128>, gemm<64>, conv3x3<128>, conv3x3<64>, attention, groupnorm,
+ *           gemm_v2<160>, conv3x3_v2<160>, gemm_v2<128>, conv3x3_v2<128>, gemm_v3 (256x256)}:
  *           {launches, milliseconds, algorithmic flops, algorithmic bytes}. */
+#define MX_PROF_KINDS 11
 int mx_profile_enable(int on);
 int mx_profile_collect(double* out);
 /* per-launch records of the last collect: out[6*i..] = {kind, M, N, K, ms, flops}; returns the number written */

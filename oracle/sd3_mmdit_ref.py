@@ -127,7 +127,7 @@ def init_params(cfg: MMDiTConfig, seed: int = 10086) -> Dict[str, torch.Tensor]:
     pool = torch.randn(1 << 22, generator=g)
     off = 0
     out: Dict[str, torch.Tensor] = {}
-    for name, shape in param_shapes(cfg).items():
+    for name, shape in sorted(param_shapes(cfg).items()):
         n = 1
         for x in shape:
             n *= x

@@ -217,7 +217,7 @@ def init_params(cfg: UNetConfig, seed: int = 10086, bf16_round: bool = True) -> 
     """
     g = torch.Generator().manual_seed(seed)
     out: Dict[str, torch.Tensor] = {}
-    for name, shape in param_shapes(cfg).items():
+    for name, shape in sorted(param_shapes(cfg).items()):
         if name.endswith(".weight") and len(shape) >= 2:
             fan_in = 1
             for d in shape[1:]:

@@ -177,26 +177,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 }
 
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn);
+int launch_v3(hipStream_t s, const GemmArgs& a);
 
-// Tile choice for the pipelined 256-row kernel: the feature tile (160 or 128) that needs the fewest full-chip rounds
-// of 256 workgroups (one per CU); 0 = use the generic 128-row kernel.
-static int pick_v2_bn(const mx_gemm_desc* d) {
+// Tile choice for the pipelined 256-row kernels: the feature tile (256, 160 or 128) with the lowest estimated cost =
+// full-chip rounds of 256 workgroups (one per CU) x tile width, the 256-wide tile (gemm_bf16_v3.hip) discounted by its
+// measured per-FLOP advantage; 0 = use the generic 128-row kernel.
+static int pick_v2_bn(const mx_gemm_desc* d, bool conv) {
   static const bool disabled = [] { const char* e = getenv("MX_GEMM_V2"); return e && e[0] == '0'; }();
+  static const bool v3_disabled = [] { const char* e = getenv("MX_GEMM_V3"); return e && e[0] == '0'; }();
+  static const double v3_discount = [] { const char* e = getenv("MX_V3_DISCOUNT"); return e ? atof(e) : 0.87; }();
   if (disabled || d->M < 256 || d->K < 128) return 0;
-  // the pipelined kernel addresses its operands with 32-bit byte offsets from a uniform base
+  // the pipelined kernels address their operands with 32-bit byte offsets from a uniform base
   const long in_rows = d->a_batch_rows > 0 ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
   if (in_rows * d->lda * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
   const bool geglu = (d->flags & MX_EPI_GEGLU) != 0, qkv = (d->flags & MX_EPI_QKV) != 0;
   int best = 0;
-  long best_cost = 0;
-  const int cands[2] = {160, 128};
-  for (int c = 0; c < 2; ++c) {
+  double best_cost = 0;
+  const int cands[3] = {256, 160, 128};
+  for (int c = 0; c < 3; ++c) {
     const int bn = cands[c];
     if (d->N % bn != 0) continue;
-    if (geglu && bn != 128) continue;
-    if (qkv && d->seg % (bn / 2) != 0) continue;
+    if (bn == 256 && (conv || v3_disabled)) continue;
+    if (geglu && bn == 160) continue;
+    if (qkv && d->seg % 64 != 0) continue;
+    if (qkv && bn != 256 && d->seg % (bn / 2) != 0) continue;
     const long tiles = (long)cdiv(d->M, 256) * (d->N / bn);
-    const long cost = ((tiles + 255) / 256) * bn;
+    const double cost = (double)((tiles + 255) / 256) * bn * (bn == 256 ? v3_discount : 1.0);
     if (best == 0 || cost < best_cost) { best = bn; best_cost = cost; }
   }
   return best;
@@ -242,7 +248,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   }
   if (d->residual) MX_CHECK(d->ldr >= d->N && d->ldr % 4 == 0, "gemm: bad ldr");
   const bool use128 = (d->N % 128 == 0);
-  const int v2bn = pick_v2_bn(d);
+  const int v2bn = pick_v2_bn(d, conv);
   if (d->flags & MX_EPI_GEGLU) {
     MX_CHECK(use128, "gemm: GEGLU needs N % 128 == 0");
     MX_CHECK(!(d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32)) && !d->residual && !d->rowbias, "gemm: GEGLU excludes other epilogues");
@@ -264,10 +270,12 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     const double flops = 2.0 * d->M * (double)d->N * kk;
     const double in_elems = conv ? (double)d->B * d->Hin * d->Win * d->Cin : (double)d->M * d->K;
     const double bytes = 2.0 * (in_elems + (double)d->N * d->K + (double)d->M * d->N);
-    const int kind = v2bn ? (conv ? PROF_CONV_V2_160 : PROF_GEMM_V2_160) + (v2bn == 160 ? 0 : 2) : (conv ? PROF_CONV128 : PROF_GEMM128) + (use128 ? 0 : 1);
+    const int kind = v2bn == 256 ? PROF_GEMM_V3_256 : v2bn ? (conv ? PROF_CONV_V2_160 : PROF_GEMM_V2_160) + (v2bn == 160 ? 0 : 2) : (conv ? PROF_CONV128 : PROF_GEMM128) + (use128 ? 0 : 1);
     prof_begin(s, kind, flops, bytes, d->M, d->N, (int)kk);
   }
-  if (v2bn) {
+  if (v2bn == 256) {
+    launch_v3(s, a);
+  } else if (v2bn) {
     launch_v2(s, a, conv, v2bn);
   } else if (use128) {
     dim3 grid(cdiv(d->M, BM), d->N / 128);

@@ -73,54 +73,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   const int cs = tid & 7;
   const int tiles_per_tap = CONV ? p.Cin / BK2 : 1;
 
-  // ---- issue-side state: the (tile, K tile) the NEXT DMA group belongs to, and that tile's per-thread sources ----
+  // ---- issue-side state: the (tile, K tile) the NEXT DMA group belongs to, and ready-made per-thread source pointers for
+  //      it.  issue_group() is branch-free so that it shares a basic block with the MFMAs (the scheduler can then place each
+  //      LDS-DMA in an MFMA shadow); everything with control flow -- moving to the next K tile, tap or output tile, or off the
+  //      end of the stream -- happens in advance_cursor(), after the MFMAs. ----
   int is_tile = blockIdx.x;     // tile id the cursor is in (>= total_tiles: past the end)
   int is_kt = 0;
-  unsigned xoff[XI];            // GEMM: byte offset of (row, swizzled chunk) from p.a; rows beyond M clamp to M-1
-  const char* xcur[XI];         // CONV: current source pointer of the row for the current tap (advances 128 B per K tile)
-  int cb[XI], cy[XI], cx[XI];
-  unsigned xchb[XI];            // byte offset of the thread's swizzled chunk inside a K tile
-  unsigned woff[WI];
+  const char* xsrc[XI];         // source of the thread's X chunks for the next group
+  const char* wsrc[WI];
+  int cb[XI], cy[XI], cx[XI];   // CONV: image, y, x of the row's output pixel (input coordinates of the centre tap)
+  unsigned xchb[XI];            // CONV: byte offset of the thread's swizzled chunk inside a K tile
   int tap_next = 0, in_tap = 0;
 
-  // per-thread sources of tile `t` (m fastest: workgroups with equal id mod 8 -- one XCD -- share X panels)
-  auto setup_tile = [&](int t) {
-    const int m0 = (t % mt) * BM2;
-    const int n0 = (t / mt) * BN;
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int row = (i * 512 + tid) >> 3;
-      const int ch = swz2(row, cs);           // logical k-chunk this thread fetches for its slot
-      const int m = m0 + row;
-      if constexpr (CONV) xchb[i] = ch * 16;
-      if constexpr (!CONV) {
-        const int mc = m < p.M ? m : p.M - 1; // clamped rows are computed and discarded by the epilogue mask
-        xoff[i] = (unsigned)((gemm_in_row(p, mc) * p.lda + ch * 8) * 2);
-      } else {
-        if (m < p.M) {
-          const int hw = p.Hout * p.Wout;
-          const int b = m / hw;
-          const int r = m - b * hw;
-          const int oy = r / p.Wout;
-          cb[i] = b; cy[i] = oy * p.stride; cx[i] = (r - oy * p.Wout) * p.stride;
-        } else {
-          cb[i] = -1; cy[i] = 0; cx[i] = 0;
-        }
-        xcur[i] = zero;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-      int q = i * 512 + tid;
-      if (q >= WCH) q -= WCH;                 // BN=160: the last instruction re-fetches rows 0..31 (same bytes, same slot)
-      const int row = q >> 3;
-      woff[i] = (unsigned)(((long)(n0 + row) * p.K + swz2(row, cs) * 8) * 2);
-    }
-    tap_next = 0; in_tap = 0;
-  };
-
   // CONV: (re)compute the row pointers for tap `tap` at channel offset 0
-  auto conv_set_tap = [&](int tap) {
+  auto conv_set_tap = [&](int tap) __attribute__((always_inline)) {
     const int dy = tap / 3 - 1;
     const int dx = tap - (tap / 3) * 3 - 1;
     const int Hv = p.Hin << p.up, Wv = p.Win << p.up;
@@ -137,53 +103,89 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       }
       const bool ok = (cb[i] >= 0) && (iy >= 0) && (iy < Hv) && (ix >= 0) && (ix < Wv);
       const long off = ((((long)cb[i] * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up)) * p.Cin) * 2;
-      xcur[i] = (ok ? reinterpret_cast<const char*>(p.a) + off : zero) + xchb[i];
+      xsrc[i] = (ok ? reinterpret_cast<const char*>(p.a) + off : zero) + xchb[i];
     }
   };
 
-  // issue the DMA group at the cursor into ring stage `stage`, then advance the cursor
-  auto issue_next = [&](int stage) {
+  // per-thread sources of K tile 0 of tile `t` (m fastest: workgroups with equal id mod 8 -- one XCD -- share X panels)
+  auto setup_tile = [&](int t) __attribute__((always_inline)) {
+    const int m0 = (t % mt) * BM2;
+    const int n0 = (t / mt) * BN;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int row = (i * 512 + tid) >> 3;
+      const int ch = swz2(row, cs);           // logical k-chunk this thread fetches for its slot
+      const int m = m0 + row;
+      if constexpr (!CONV) {
+        const int mc = m < p.M ? m : p.M - 1; // clamped rows are computed and discarded by the epilogue mask
+        xsrc[i] = reinterpret_cast<const char*>(p.a) + (gemm_in_row(p, mc) * p.lda + ch * 8) * 2;
+      } else {
+        xchb[i] = ch * 16;
+        if (m < p.M) {
+          const int hw = p.Hout * p.Wout;
+          const int b = m / hw;
+          const int r = m - b * hw;
+          const int oy = r / p.Wout;
+          cb[i] = b; cy[i] = oy * p.stride; cx[i] = (r - oy * p.Wout) * p.stride;
+        } else {
+          cb[i] = -1; cy[i] = 0; cx[i] = 0;
+        }
+      }
+    }
+    if constexpr (CONV) conv_set_tap(0);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      int q = i * 512 + tid;
+      if (q >= WCH) q -= WCH;                 // BN=160: the last instruction re-fetches rows 0..31 (same bytes, same slot)
+      const int row = q >> 3;
+      wsrc[i] = reinterpret_cast<const char*>(p.w) + ((long)(n0 + row) * p.K + swz2(row, cs) * 8) * 2;
+    }
+    tap_next = 0; in_tap = 0;
+  };
+  auto park_on_zero_page = [&]() __attribute__((always_inline)) {            // past the end of the stream: same instruction count, harmless bytes
+#pragma unroll
+    for (int i = 0; i < XI; ++i) xsrc[i] = zero + lane * 16;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wsrc[i] = zero + lane * 16;
+  };
+
+  // issue the DMA group at the cursor into ring stage `stage` (no control flow)
+  auto issue_group = [&](int stage) __attribute__((always_inline)) {
     bf16_t* st = smem + stage * STAGE_ELEMS;
     bf16_t* sw = st + BM2 * BK2;
-    if (is_tile < total_tiles) {               // wave-uniform
-      if constexpr (!CONV) {
-        const char* xb = reinterpret_cast<const char*>(p.a) + (long)is_kt * (BK2 * 2);
 #pragma unroll
-        for (int i = 0; i < XI; ++i) glds16(xb + xoff[i], st + (i * 512 + wave * 64) * 8);
+    for (int i = 0; i < XI; ++i) glds16(xsrc[i], st + (i * 512 + wave * 64) * 8);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int qb = (i * 512 + wave * 64 >= WCH) ? i * 512 + wave * 64 - WCH : i * 512 + wave * 64;  // wave-uniform slot base
+      glds16(wsrc[i], sw + qb * 8);
+    }
+  };
+  // move the cursor (and the source pointers) to the next K tile of the stream
+  auto advance_cursor = [&]() __attribute__((always_inline)) {
+    if (is_tile >= total_tiles) return;       // parked
+    if (++is_kt == nk) {                      // on to this workgroup's next output tile
+      is_kt = 0;
+      if constexpr (SINGLE) is_tile = total_tiles; else is_tile += gridDim.x;
+      if (is_tile < total_tiles) setup_tile(is_tile); else park_on_zero_page();
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wsrc[i] += BK2 * 2;
+    if constexpr (!CONV) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) xsrc[i] += BK2 * 2;
+    } else {
+      if (++in_tap == tiles_per_tap) {
+        in_tap = 0;
+        conv_set_tap(++tap_next);
       } else {
-        if (in_tap == 0) conv_set_tap(tap_next);
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-          glds16(xcur[i], st + (i * 512 + wave * 64) * 8);
-          xcur[i] += BK2 * 2;
-        }
-        if (++in_tap == tiles_per_tap) { in_tap = 0; ++tap_next; }
-      }
-      const char* wb = reinterpret_cast<const char*>(p.w) + (long)is_kt * (BK2 * 2);
-#pragma unroll
-      for (int i = 0; i < WI; ++i) {
-        const int qb = (i * 512 + wave * 64 >= WCH) ? i * 512 + wave * 64 - WCH : i * 512 + wave * 64;  // wave-uniform slot base
-        glds16(wb + woff[i], sw + qb * 8);
-      }
-      if (++is_kt == nk) {                     // cursor moves on to this workgroup's next tile
-        is_kt = 0;
-        if constexpr (SINGLE) {
-          is_tile = total_tiles;
-        } else {
-          is_tile += gridDim.x;
-          if (is_tile < total_tiles) setup_tile(is_tile);
-        }
-      }
-    } else {                                   // past the end of the stream: same instruction count, harmless bytes
-#pragma unroll
-      for (int i = 0; i < XI; ++i) glds16(zero + lane * 16, st + (i * 512 + wave * 64) * 8);
-#pragma unroll
-      for (int i = 0; i < WI; ++i) {
-        const int qb = (i * 512 + wave * 64 >= WCH) ? i * 512 + wave * 64 - WCH : i * 512 + wave * 64;
-        glds16(zero + lane * 16, sw + qb * 8);
+        for (int i = 0; i < XI; ++i) xsrc[i] += BK2 * 2;
       }
     }
   };
+  auto issue_next = [&](int stage) __attribute__((always_inline)) { issue_group(stage); advance_cursor(); };   // prologue form
 
   const int fr = lane & 15;
   const int fq = lane >> 4;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
 #endif
       const int st2 = stage >= 1 ? stage - 1 : 2;   // (g + 2) % 3: last read in iteration g-1, which every wave has left
 #if MX_EXP != 2
-      issue_next(st2);
+      issue_group(st2);
 #endif
 #if MX_EXP != 3
       load_frags(stage, 1, wf1, xf1);
@@ -270,6 +272,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // fragment reads of k-step 1
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - LOADS - (NF + 1) / 2, 0);
+#if MX_EXP != 2
+      advance_cursor();
+#endif
       stage = stage == 2 ? 0 : stage + 1;
     }
 

@@ -33,7 +33,7 @@ def synthetic_params(cfg: UNetConfig, device="cpu", seed: int = 10086) -> Dict[s
     gains ~1, small biases; seed 10086 = the reference's default (sduss/engine/arg_utils.py:20)."""
     g = torch.Generator(device=device).manual_seed(seed)
     out = {}
-    for name, shape in param_shapes(cfg).items():
+    for name, shape in sorted(param_shapes(cfg).items()):
         if name.endswith(".weight") and len(shape) >= 2:
             fan_in = 1
             for d in shape[1:]:
@@ -177,7 +177,7 @@ def synthetic_mmdit_params(cfg, device="cpu", seed: int = 10086) -> Dict[str, to
     from .config import mmdit_param_shapes
     g = torch.Generator(device=device).manual_seed(seed)
     out = {}
-    for name, shape in mmdit_param_shapes(cfg).items():
+    for name, shape in sorted(mmdit_param_shapes(cfg).items()):
         if name == "pos_embed.pos_embed":
             t = 0.5 * torch.randn(shape, generator=g, device=device)
         elif name.endswith(("norm_q.weight", "norm_k.weight", "norm_added_q.weight", "norm_added_k.weight")):

@@ -15,7 +15,7 @@ from sduss_amd.pipeline import SDXLDenoiser, synthetic_request  # noqa: E402
 from sduss_amd.unet import MxUNet  # noqa: E402
 from sduss_amd.weights import synthetic_params  # noqa: E402
 
-KINDS = ["gemm128", "gemm64", "conv128", "conv64", "attn", "gnorm", "gemm_v2_160", "conv_v2_160", "gemm_v2_128", "conv_v2_128"]
+KINDS = ["gemm128", "gemm64", "conv128", "conv64", "attn", "gnorm", "gemm_v2_160", "conv_v2_160", "gemm_v2_128", "conv_v2_128", "gemm_v3_256"]
 
 
 def main():
@@ -33,7 +33,7 @@ def main():
     l.mx_profile_enable(1)
     den.denoising_step({"1024": reqs})
     torch.cuda.synchronize()
-    buf = (C.c_double * 40)()
+    buf = (C.c_double * 64)()
     lib.check(l.mx_profile_collect(buf))
     l.mx_profile_enable(0)
     rec = (C.c_double * (6 * 4096))()
