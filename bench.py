@@ -40,22 +40,28 @@ KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<12
               "gemm_v3_kernel (256x256)"]
 
 
-def pmc_traffic_bytes(kernel_label):
-    """HBM bytes per launch of a kernel symbol from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*; FETCH_SIZE
-    doubled per the gfx950 correction + WRITE_SIZE, tools/pmc_traffic.py).  PMC cannot be collected inside the timed run."""
+KIND_SYMBOLS = {  # bench kernel label -> symbol prefix in the rocprofv3 summaries (all instantiations of the kind)
+    "gemm_v2_kernel<160,false>": "mx::gemm_v2_kernel<160, false,", "gemm_v2_kernel<160,true> (conv3x3)": "mx::gemm_v2_kernel<160, true,",
+    "gemm_v2_kernel<128,false>": "mx::gemm_v2_kernel<128, false,", "gemm_v2_kernel<128,true> (conv3x3)": "mx::gemm_v2_kernel<128, true,",
+    "gemm_v3_kernel (256x256)": "mx::gemm_v3_kernel<", "attn_fwd_kernel": "mx::attn_fwd_kernel",
+}
+
+
+def pmc_traffic_bytes(kernel_label, model):
+    """HBM bytes per launch of a kernel kind from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic_<model>*;
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, tools/pmc_traffic.py), launch-weighted over the kind's
+    instantiations.  PMC cannot be collected inside the timed run."""
     import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.txt")))
-    if not files:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_{model}*.txt")))
+    prefix = KIND_SYMBOLS.get(kernel_label)
+    if not files or not prefix:
         return None, None
-    m = re.match(r"(\w+)<(\d+),(\w+)>", kernel_label)
-    if not m:
-        return None, None
-    want = f"mx::{m.group(1)}<{m.group(2)}, {m.group(3)}, true>"       # the one-tile-per-workgroup instantiation dominates
+    n, mb = 0, 0.0
     for line in open(files[-1]):
-        if line.startswith(want):
-            return float(line.split()[-1]) * 1e6, os.path.basename(files[-1])
-    return None, None
+        if line.startswith(prefix):
+            f = line.split()
+            n += int(f[-4]); mb += int(f[-4]) * float(f[-1])
+    return (mb / n * 1e6, os.path.basename(files[-1])) if n else (None, None)
 
 
 def parse():
@@ -241,7 +247,7 @@ def main():
         mf = [k for k in kinds if k["tflops"]]
         if mf:
             dom = max(mf, key=lambda k: k["ms_total"])
-            traffic, src = pmc_traffic_bytes(dom["kernel"])
+            traffic, src = pmc_traffic_bytes(dom["kernel"], args.model)
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_BF16 / 1e12,
                                   "unit": "TFLOP/s", "frac": dom["tflops"] / (MFMA_PEAK_BF16 / 1e12), "traffic": traffic,
                                   "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     const float m_new = fmaxf(m_run, mx_ * c);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
+    // (packed v_pk_fma_f32 / v_pk_add_f32 forms of this loop measured 0-3 % SLOWER in same-run A/B: scalar kept)
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)

@@ -190,6 +190,9 @@ static int pick_v2_bn(const mx_gemm_desc* d, bool conv) {
   // the pipelined kernels address their operands with 32-bit byte offsets from a uniform base
   const long in_rows = d->a_batch_rows > 0 ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
   if (in_rows * d->lda * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
+  // their LDS-staged epilogue moves 16-byte pieces of C and of the residual
+  if (d->ldc % 8 != 0 || ((uintptr_t)d->c & 15) != 0) return 0;
+  if (d->residual && (d->ldr % 8 != 0 || ((uintptr_t)d->residual & 15) != 0)) return 0;
   const bool geglu = (d->flags & MX_EPI_GEGLU) != 0, qkv = (d->flags & MX_EPI_QKV) != 0;
   int best = 0;
   double best_cost = 0;

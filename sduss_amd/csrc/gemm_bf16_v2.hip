@@ -1,25 +1,24 @@
-// bf16 MFMA GEMM / implicit-GEMM conv3x3, large-tile persistent pipelined variant for gfx950 (MI355X).
+// bf16 MFMA GEMM / implicit-GEMM conv3x3, large-tile pipelined variant for gfx950 (MI355X).
 //
-// Same math, orientation, swizzle and epilogues as gemm_bf16.hip (the generic fallback); what changes is the
+// Same math, orientation, swizzle and epilogue semantics as gemm_bf16.hip (the generic fallback); what changes is the
 // schedule, built for the SDXL / SD3.5 step shapes (M = B*H*W in {8192, 32768, 131072}, N in multiples of 320 or 128):
 //   * tile 256 tokens x BN features (BN = 160 or 128) x BK 64, 512 threads = 8 waves as 4(m) x 2(n): every SDXL
 //     GEMM/conv at UNet batch 8 then decomposes into a multiple of 256 tiles -- whole rounds of the chip's 256 CUs,
-//     no tail round (with 128x128 tiles the N=1280 layers ran 640 tiles = 2.5 rounds);
-//   * PERSISTENT: one workgroup per CU walks its tiles (t = id, id + grid, ...) and treats their K tiles as ONE stream:
-//     the LDS-DMA for stream position g+2 is issued in iteration g, so the first two K tiles of the next output tile are
-//     already in flight while the current tile runs its epilogue (bias / activation / residual / stores) -- the
-//     prologue fill and the epilogue of consecutive tiles overlap instead of serialising (the per-tile fixed cost
-//     measured at ~15 us of a 40 us tile for K = 1280);
+//     no tail round (with 128x128 tiles the N=1280 layers ran 640 tiles = 2.5 rounds); one tile per workgroup;
 //   * operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no staging VGPRs / ds_write), XOR swizzle applied on
 //     the per-lane SOURCE address (the LDS image of an LDS-DMA is lane-linear; cdna guide rule 21);
 //   * 3-stage LDS ring, counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per K tile (cdna guide "Pipelining
 //     across barriers").  All LDS lives in ONE __shared__ array and the K loop contains no ordinary global load.  A DMA
-//     group is issued in EVERY iteration (past the end of the stream it reads a zero page into a stage nobody reads), so
-//     one counted wait serves every iteration; epilogue stores only make that wait more conservative, never wrong
-//     (vmcnt retires in order).  Fragment reads of k-step 1 and the DMA issue are interleaved with the MFMAs of
-//     k-step 0 (sched_group_barrier);
+//     group is issued in EVERY iteration (past the end of the K range it reads a zero page into a stage nobody reads), so
+//     one counted wait serves every iteration.  The DMA issue is branch-free and shares a basic block with the MFMAs:
+//     each LDS-DMA and the fragment reads of k-step 1 sit in MFMA shadows (sched_group_barrier); all control flow of the
+//     loader (next K tile / next conv tap) runs after the MFMAs;
 //   * conv3x3: per-row source pointers are recomputed only when the tap changes (every Cin/64 K tiles) and otherwise
-//     just advance by one K tile; out-of-image taps and rows beyond M walk a zero page instead of branching.
+//     just advance by one K tile; out-of-image taps and rows beyond M walk a zero page instead of branching;
+//   * epilogue: the ring is drained and reused as the transpose buffer of gemm_epilogue_staged (gemm_args.h), so global
+//     stores and residual loads move whole tile rows.  (An earlier persistent form that prefetched the next tile's K tiles
+//     under a register-layout epilogue was 8-11 % faster than one tile per workgroup; the staged epilogue is worth 20-40 %
+//     and needs the ring, so it replaced it.)
 #include <cstdlib>
 
 #include "common.h"
@@ -47,10 +46,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// SINGLE: one tile per workgroup (grid == tiles): no tile loop, and the residual of the plain epilogue is prefetched before the
-// K loop.  !SINGLE: persistent, one workgroup per CU walking its tiles; pays only for launches of many rounds (measured:
-// +8..11 % at 4-16 rounds, -2..0 % at 2-3 rounds in same-device A/B, gpurun_out gemm_bench8; default: persistent from 4 rounds).
-template <int BN, bool CONV, bool SINGLE>
+template <int BN, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   constexpr int NI = BN / 32;                 // 16-wide feature blocks per wave (wave covers BN/2 features)
   constexpr int MI = 4;                       // 16-wide token blocks per wave (wave covers 64 tokens)
@@ -166,8 +162,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
     if (is_tile >= total_tiles) return;       // parked
     if (++is_kt == nk) {                      // on to this workgroup's next output tile
       is_kt = 0;
-      if constexpr (SINGLE) is_tile = total_tiles; else is_tile += gridDim.x;
-      if (is_tile < total_tiles) setup_tile(is_tile); else park_on_zero_page();
+      is_tile = total_tiles;                  // one tile per workgroup: the rest of the ring slots get harmless bytes
+      park_on_zero_page();
       return;
     }
 #pragma unroll
@@ -207,22 +203,13 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   constexpr int NM = NI * MI;
   constexpr int NF = NI + MI;
 
-  // SINGLE: residual of the plain epilogue: issue its loads before any DMA (oldest in the vmcnt queue, so the counted waits
-  // cover them) and consume them after the K loop.  Persistent launches read the residual in the epilogue, under the next
-  // tile's DMA.
-  constexpr bool kPre = SINGLE;   // (the few VGPR spills this causes at BN=160 sit before/after the K loop, not inside it)
-  u32x2 rpre[kPre ? NI : 1][MI];
-  const bool use_pre = kPre && p.residual != nullptr && !(p.flags & (MX_EPI_GEGLU | MX_EPI_QKV));
-  if constexpr (kPre) {
-    if (use_pre) gemm_prefetch_residual<NI, MI>(p, rpre, (blockIdx.x % mt) * BM2 + wm * 64, (blockIdx.x / mt) * BN + wn * (BN / 2), fr, fq);
-  }
-
   setup_tile(is_tile);
   issue_next(0);
   issue_next(1);
 
   int stage = 0;   // ring stage of the K tile being computed (stream position modulo 3)
-  for (int tile = blockIdx.x; tile < total_tiles; tile += (SINGLE ? total_tiles : (int)gridDim.x)) {
+  const int tile = blockIdx.x;
+  {
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -279,37 +266,36 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
     }
 
     const int m0 = (tile % mt) * BM2, n0 = (tile / mt) * BN;
-    if constexpr (kPre) {
-      if (use_pre) gemm_epilogue<NI, MI, BN, true>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq, rpre);
-      else gemm_epilogue<NI, MI, BN, false>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq);
-    } else {
-      gemm_epilogue<NI, MI, BN, false>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq);
+#if MX_EXP == 4   // no epilogue: keep the accumulators alive with a store that never executes on real data
+    {
+      float t = 0.f;
+      for (int i = 0; i < NI; ++i) for (int j = 0; j < MI; ++j) for (int q = 0; q < 4; ++q) t += acc[i][j][q];
+      if (t == 12345.678f) reinterpret_cast<bf16_t*>(p.c)[m0 + n0] = f32_to_bf16(t);
     }
+#else
+    // every DMA has landed and every wave has left the K loop: the ring becomes the epilogue's transpose buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* slab = reinterpret_cast<float*>(smem);
+    if (p.flags & MX_EPI_GEGLU) {
+      if constexpr (BN % 64 == 0 && !CONV) gemm_epilogue_staged<NI, MI, 4, 2, true>(p, acc, slab, m0, n0, wm, wn, fr, fq, tid);
+    } else {
+      gemm_epilogue_staged<NI, MI, 4, 2, false>(p, acc, slab, m0, n0, wm, wn, fr, fq, tid);
+    }
+#endif
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end DMAs before the workgroup retires
 }
 
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn) {
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-    }
-    return n;
-  }();
   const int tiles = cdiv(a.M, BM2) * (a.N / bn);
-  static const int persist_rounds = [] { const char* e = getenv("MX_V2_PERSIST_ROUNDS"); return e ? atoi(e) : 4; }();
-  const bool single = tiles < persist_rounds * ncu || tiles <= ncu;
-  dim3 grid(single ? tiles : ncu), block(512);   // persistent: one workgroup per CU (the LDS ring fills the CU)
-#define MX_V2(BN_, CONV_) \
-  do { \
-    if (single) hipLaunchKernelGGL((gemm_v2_kernel<BN_, CONV_, true>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((gemm_v2_kernel<BN_, CONV_, false>), grid, block, 0, s, a); \
-  } while (0)
-  if (bn == 160) { if (conv) MX_V2(160, true); else MX_V2(160, false); }
-  else { if (conv) MX_V2(128, true); else MX_V2(128, false); }
-#undef MX_V2
+  dim3 grid(tiles), block(512);
+  if (bn == 160) {
+    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<160, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_v2_kernel<160, false>), grid, block, 0, s, a);
+  } else {
+    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<128, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_v2_kernel<128, false>), grid, block, 0, s, a);
+  }
   return 0;
 }
 

@@ -6,9 +6,10 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/exp
 OBJ=build/obj
-for v in 1 2 3; do
+for v in 1 2 3 4; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMX_EXP=$v -c sduss_amd/csrc/gemm_bf16_v2.hip -o build/exp/gemm_v2_exp$v.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMX_EXP=$v -c sduss_amd/csrc/gemm_bf16_v3.hip -o build/exp/gemm_v3_exp$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/libmx_exp$v.so build/exp/gemm_v2_exp$v.o \
-    $OBJ/gemm_bf16.o $OBJ/attention.o $OBJ/norm.o $OBJ/elementwise.o $OBJ/gn_halo_nchw.o $OBJ/unet_sdxl.o $OBJ/mmdit_sd3.o $OBJ/capi.o
+    $OBJ/gemm_bf16.o build/exp/gemm_v3_exp$v.o $OBJ/attention.o $OBJ/norm.o $OBJ/elementwise.o $OBJ/gn_halo_nchw.o $OBJ/unet_sdxl.o $OBJ/mmdit_sd3.o $OBJ/capi.o
 done
 ls -la build/exp/*.so
