@@ -25,6 +25,7 @@ struct GemmArgs {
   int a_batch_rows, a_row_off, c_batch_rows, c_row_off;
   const float* gate;
   int ldg;
+  int xcd_map;   // 1: XCD-aware workgroup -> tile map (gemm_tile_of_block)
 };
 
 // row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)
@@ -163,6 +164,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
       }
     }
   }
+}
+
+
+// XCD-aware workgroup -> tile map of the one-tile-per-workgroup kernels.  Consecutive workgroup ids are dealt round-robin to
+// the 8 XCDs, each with its own 4 MB L2 and 32 CUs.  With the plain map (m fastest) the 32 tiles an XCD runs at one time
+// are 16-32 different token panels x 1-2 feature panels, so its L2 takes in ~18 operand tiles per K step and every token
+// panel is also fetched by other XCDs (rocprofv3 FETCH_SIZE: 3x the algorithmic bytes).  Here XCD x owns the token panels
+// m = 8 i + x and walks them in bands of MB panels x all feature panels, features slowest inside a band: the 32 concurrent
+// tiles form a ~4 x 8 block (12 operand tiles per K step) and a token panel enters exactly one L2.
+// Needs mt % 8 == 0 (else the plain map).  Returns (m tile, n tile) of workgroup b.
+__device__ __forceinline__ void gemm_tile_of_block(const int b, const int mt, const int nt, const int xcd_map, int& tm, int& tn) {
+  constexpr int MB = 4;
+  if (!xcd_map || (mt & 7) != 0) { tm = b % mt; tn = b / mt; return; }
+  const int xcd = b & 7;
+  const int local = b >> 3;                   // index inside the XCD's sequence
+  const int mloc = mt >> 3;                   // token panels owned by one XCD
+  const int band_tiles = MB * nt;
+  const int band = local / band_tiles;
+  const int r = local - band * band_tiles;
+  const int rows = (mloc - band * MB) < MB ? (mloc - band * MB) : MB;   // the last band may be short
+  tn = r / rows;
+  tm = ((band * MB + (r - tn * rows)) << 3) + xcd;
 }
 
 // ----------------------------------------------------------------------------------------------------------------------

@@ -226,6 +226,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   a.stride = d->stride; a.up = d->up; a.corner_patch = d->corner_patch;
   a.a_batch_rows = d->a_batch_rows; a.a_row_off = d->a_row_off; a.c_batch_rows = d->c_batch_rows; a.c_row_off = d->c_row_off;
   a.gate = d->gate; a.ldg = d->ldg;
+  static const int xcd_map = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
+  a.xcd_map = xcd_map;
 
   if (!conv) {
     MX_CHECK(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda must be >= K and a multiple of 8");

@@ -105,8 +105,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
 
   // per-thread sources of K tile 0 of tile `t` (m fastest: workgroups with equal id mod 8 -- one XCD -- share X panels)
   auto setup_tile = [&](int t) __attribute__((always_inline)) {
-    const int m0 = (t % mt) * BM2;
-    const int n0 = (t / mt) * BN;
+    int tm, tn;
+    gemm_tile_of_block(t, mt, p.N / BN, p.xcd_map, tm, tn);
+    const int m0 = tm * BM2;
+    const int n0 = tn * BN;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int row = (i * 512 + tid) >> 3;
@@ -265,7 +267,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       stage = stage == 2 ? 0 : stage + 1;
     }
 
-    const int m0 = (tile % mt) * BM2, n0 = (tile / mt) * BN;
+    int tm, tn;
+    gemm_tile_of_block(tile, mt, p.N / BN, p.xcd_map, tm, tn);
+    const int m0 = tm * BM2, n0 = tn * BN;
 #if MX_EXP == 4   // no epilogue: keep the accumulators alive with a store that never executes on real data
     {
       float t = 0.f;

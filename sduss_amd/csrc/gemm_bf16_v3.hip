@@ -9,13 +9,15 @@
 // other (1.03 us of DMA, 0.89 us of MFMA per K tile), and the 128 x 64 wave tile reads 0.375 KB of LDS per MFMA instead
 // of 0.45.
 //
-//   * tile 256 tokens x 256 features x BK 64: 64 KB per stage, TWO stages (the LDS-DMA of K tile g+1 runs under the MFMAs
-//     of K tile g).  A first version used five 32-KB stages of BK 32: its 64-byte LDS rows made every DMA row piece half a
-//     cache line and the DMA stream ran at half the rate (34 GB/s per CU) -- full 128-byte lines matter more than depth;
+//   * tile 256 tokens x 256 features x BK 64.  The X tile and the W tile of a K tile (32 KB each, 128-byte rows) are
+//     separate slots of a FIVE-slot ring = the CU's whole 160 KB: two slots are being read, three are in flight
+//     (W of K tile g+1 and X of K tile g+2 are issued during K tile g), so the DMA queue never runs dry at the barrier.
+//     Earlier forms: five 32-KB stages of BK 32 (64-byte LDS rows made every DMA row piece half a cache line: the stream
+//     ran at half rate, 34 GB/s per CU) and two 64-KB stages of BK 64 (one K tile in flight: 46 GB/s per CU);
 //   * 512 threads = 8 waves as 2 (tokens) x 4 (features); a wave owns 128 tokens x 64 features = 32 accumulator blocks of
 //     v_mfma_f32_16x16x32_bf16 (128 VGPRs);
 //   * same XOR swizzle and source-side application as v2 (16-byte chunk ^= (row >> 1) & 7 on 128-byte rows);
-//   * one s_waitcnt vmcnt(0) + one raw s_barrier per K tile; the DMA issue is branch-free and interleaved with the MFMAs of
+//   * one counted s_waitcnt vmcnt(4) + one raw s_barrier per K tile; the DMA issue is branch-free and interleaved with the MFMAs of
 //     k-step 0 (sched_group_barrier), the fragment reads of k-step 1 with its second half; one tile per workgroup; the
 //     drained ring is the transpose buffer of the LDS-staged epilogue (gemm_args.h).
 #include <cstdlib>
@@ -36,7 +38,11 @@ constexpr int BM3 = 256;
 constexpr int BN3 = 256;
 constexpr int BK3 = 64;
 
+#if MX_EXP == 5 || MX_EXP == 6   // diagnostic: LDS-DMA source without the in-line chunk permutation (results wrong; timing only)
+__device__ __forceinline__ int swz3(int row, int chunk) { return chunk; }
+#else
 __device__ __forceinline__ int swz3(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+#endif
 
 __device__ __forceinline__ void glds16_3(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -49,8 +55,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
   constexpr int XI = BM3 * 8 / 512;            // X DMA instructions per thread per K tile (4)
   constexpr int WI = BN3 * 8 / 512;            // W DMA instructions per thread per K tile (4)
   constexpr int LOADS = XI + WI;
-  constexpr int STAGE_ELEMS = (BM3 + BN3) * BK3;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_ELEMS];
+  constexpr int SLOT_ELEMS = 256 * BK3;        // one X tile or one W tile: 32 KB
+  constexpr int NSLOT = 5;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NSLOT * SLOT_ELEMS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -60,13 +67,15 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
   const int mt = (p.M + BM3 - 1) / BM3;
   const int nk = p.K / BK3;
   const char* zero = reinterpret_cast<const char*>(g_zero_page3);
-  const int tile = blockIdx.x;
-  const int m0 = (tile % mt) * BM3, n0 = (tile / mt) * BN3;
+  int tm, tn;
+  gemm_tile_of_block(blockIdx.x, mt, p.N / BN3, p.xcd_map, tm, tn);
+  const int m0 = tm * BM3, n0 = tn * BN3;
 
   // ---- issue side: ready-made per-thread source pointers for the next DMA group.  issue_group() is branch-free (it shares
   //      a basic block with the MFMAs so each LDS-DMA can sit in an MFMA shadow); advance_cursor() holds the control flow
   //      and runs after the MFMAs. ----
-  int is_kt = 0;
+  // half-tile h = 2g (X of K tile g) or 2g+1 (W of K tile g) lives in slot h % 5
+  int x_kt = 0, w_kt = 0;                      // K tile the next X / W group belongs to (>= nk: parked on the zero page)
   const char* xsrc[XI];
   const char* wsrc[WI];
   {
@@ -84,25 +93,33 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
       wsrc[i] = reinterpret_cast<const char*>(p.w) + ((long)(n0 + row) * p.K + swz3(row, cs) * 8) * 2;
     }
   }
-  auto issue_group = [&](int stage) __attribute__((always_inline)) {
-    bf16_t* st = smem + stage * STAGE_ELEMS;
-    bf16_t* sw = st + BM3 * BK3;
+  auto issue_x = [&](int slot) __attribute__((always_inline)) {
+    bf16_t* st = smem + slot * SLOT_ELEMS;
 #pragma unroll
     for (int i = 0; i < XI; ++i) glds16_3(xsrc[i], st + (i * 512 + wave * 64) * 8);
-#pragma unroll
-    for (int i = 0; i < WI; ++i) glds16_3(wsrc[i], sw + (i * 512 + wave * 64) * 8);
   };
-  auto advance_cursor = [&]() __attribute__((always_inline)) {
-    if (is_kt >= nk) return;                   // parked on the zero page
-    if (++is_kt == nk) {                       // past the end of the K range: same instruction count, harmless bytes
+  auto issue_w = [&](int slot) __attribute__((always_inline)) {
+    bf16_t* st = smem + slot * SLOT_ELEMS;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) glds16_3(wsrc[i], st + (i * 512 + wave * 64) * 8);
+  };
+  auto advance_x = [&]() __attribute__((always_inline)) {
+    if (x_kt >= nk) return;                    // parked
+    if (++x_kt == nk) {                        // past the end of the K range: same instruction count, harmless bytes
 #pragma unroll
       for (int i = 0; i < XI; ++i) xsrc[i] = zero + lane * 16;
-#pragma unroll
-      for (int i = 0; i < WI; ++i) wsrc[i] = zero + lane * 16;
       return;
     }
 #pragma unroll
     for (int i = 0; i < XI; ++i) xsrc[i] += BK3 * 2;
+  };
+  auto advance_w = [&]() __attribute__((always_inline)) {
+    if (w_kt >= nk) return;
+    if (++w_kt == nk) {
+#pragma unroll
+      for (int i = 0; i < WI; ++i) wsrc[i] = zero + lane * 16;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < WI; ++i) wsrc[i] += BK3 * 2;
   };
@@ -116,8 +133,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
 #pragma unroll                                 // block of 16 rows: the swizzle depends on (row >> 1) & 7 = (fr >> 1) & 7
   for (int ks = 0; ks < 2; ++ks) koff[ks] = swz3(fr, ks * 4 + fq) * 8;
 
-  issue_group(0);
-  advance_cursor();
+  issue_x(0); advance_x();                     // X(0) -> slot 0, W(0) -> slot 1, X(1) -> slot 2
+  issue_w(1); advance_w();
+  issue_x(2); advance_x();
 
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -125,25 +143,31 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int stage = 0;
+  int xs = 0;                                  // slot of X(kt) = (2 kt) % 5; W(kt) is in the next slot
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K tile kt (the only group in flight) has landed
+    // all but the youngest group (X of K tile kt+1) has landed => X(kt) and W(kt) are in LDS
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const bf16_t* sx = smem + stage * STAGE_ELEMS;
-    const bf16_t* sw = sx + BM3 * BK3;
+    const int ws = xs == NSLOT - 1 ? 0 : xs + 1;
+    const int f0 = ws == NSLOT - 1 ? 0 : ws + 1;           // slot of X(kt+1), in flight
+    const int f1 = f0 == NSLOT - 1 ? 0 : f0 + 1;           // the two slots read in the previous iteration, which every
+    const int f2 = f1 == NSLOT - 1 ? 0 : f1 + 1;           // wave has left: W(kt+1) and X(kt+2) go there
+    const bf16_t* sx = smem + xs * SLOT_ELEMS;
+    const bf16_t* sw = smem + ws * SLOT_ELEMS;
     bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(sw + (w_row + 16 * i) * BK3 + koff[0]);
 #pragma unroll
     for (int j = 0; j < MI; ++j) xf0[j] = *reinterpret_cast<const bf16x8*>(sx + (x_row + 16 * j) * BK3 + koff[0]);
 #if MX_EXP != 2
-    issue_group(stage ^ 1);                               // the stage read in the previous iteration, which every wave has left
+    issue_w(f1);
+    issue_x(f2);
 #endif
 #pragma unroll
     for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(sw + (w_row + 16 * i) * BK3 + koff[1]);
 #pragma unroll
     for (int j = 0; j < MI; ++j) xf1[j] = *reinterpret_cast<const bf16x8*>(sx + (x_row + 16 * j) * BK3 + koff[1]);
-#if MX_EXP != 1
+#if MX_EXP != 1 && MX_EXP != 5
 #pragma unroll
     for (int j = 0; j < MI; ++j)
 #pragma unroll
@@ -170,9 +194,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI * MI - 2 * LOADS - (NI + MI), 0);
 #if MX_EXP != 2
-    advance_cursor();
+    advance_w();
+    advance_x();
 #endif
-    stage ^= 1;
+    xs = f0;
   }
 
 #if MX_EXP == 4   // no epilogue: keep the accumulators alive with a store that never executes on real data

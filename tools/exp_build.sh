@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/exp
 OBJ=build/obj
-for v in 1 2 3 4; do
+for v in 1 2 4 5 6; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMX_EXP=$v -c sduss_amd/csrc/gemm_bf16_v2.hip -o build/exp/gemm_v2_exp$v.o
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMX_EXP=$v -c sduss_amd/csrc/gemm_bf16_v3.hip -o build/exp/gemm_v3_exp$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/libmx_exp$v.so build/exp/gemm_v2_exp$v.o \
