@@ -41,9 +41,9 @@ KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<12
 
 
 KIND_SYMBOLS = {  # bench kernel label -> symbol prefix in the rocprofv3 summaries (all instantiations of the kind)
-    "gemm_v2_kernel<160,false>": "mx::gemm_v2_kernel<160, false,", "gemm_v2_kernel<160,true> (conv3x3)": "mx::gemm_v2_kernel<160, true,",
-    "gemm_v2_kernel<128,false>": "mx::gemm_v2_kernel<128, false,", "gemm_v2_kernel<128,true> (conv3x3)": "mx::gemm_v2_kernel<128, true,",
-    "gemm_v3_kernel (256x256)": "mx::gemm_v3_kernel<", "attn_fwd_kernel": "mx::attn_fwd_kernel",
+    "gemm_v2_kernel<160,false>": "mx::gemm_v2_kernel<160, false>", "gemm_v2_kernel<160,true> (conv3x3)": "mx::gemm_v2_kernel<160, true>",
+    "gemm_v2_kernel<128,false>": "mx::gemm_v2_kernel<128, false>", "gemm_v2_kernel<128,true> (conv3x3)": "mx::gemm_v2_kernel<128, true>",
+    "gemm_v3_kernel (256x256)": "mx::gemm_v3_kernel(", "attn_fwd_kernel": "mx::attn_fwd_kernel",
 }
 
 

@@ -20,6 +20,8 @@
 //     loop carries no avoidable vector work: every LDS address is a loop-invariant per-lane offset whose buffer bit is
 //     toggled by one XOR per tile, key/V^T masking exists only in a separate tail-tile path, P is packed with the
 //     two-operand v_cvt_pk_bf16_f32, and the first MFMA of each S^T block takes a zero accumulator literal.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/mxdenoise.h"
 
@@ -31,6 +33,7 @@ struct AttnArgs {
   long vt_bstride;
   int B, H, Lq, Lk;
   float scale_log2;  // scale * log2(e)
+  int xcd_map;       // 1: XCD-aware workgroup order (needs B*H % 8 == 0)
 };
 
 constexpr int KT = 64;                 // keys per tile
@@ -58,9 +61,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   const int wave = tid >> 6;
   const int r = lane & 31;   // query column owned by this lane (and fragment row)
   const int hh = lane >> 5;  // half-wave
-  const int head = blockIdx.y;
-  const int b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // workgroup -> (query block, head, batch).  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (one L2 each):
+  // with the plain x-fastest order the query blocks of one head land on all 8 XCDs and each L2 fetches that head's K / V^T
+  // (rocprofv3 FETCH_SIZE: 4.4x the algorithmic bytes at Lk = 4429).  When the number of (batch, head) pairs is a multiple
+  // of 8, XCD x instead owns the pairs == x (mod 8) and walks their query blocks consecutively.
+  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
+  if (p.xcd_map) {
+    const int lin = blockIdx.x + gridDim.x * bh;
+    const int local = lin >> 3;
+    qb = local % (int)gridDim.x;
+    bh = ((local / (int)gridDim.x) << 3) + (lin & 7);
+  }
+  const int head = bh % p.H;
+  const int b = bh / p.H;
+  const int q0 = qb * 128 + wave * 32;
 
   // ---- Q fragments (B operand of S^T = K Q^T): Q[q0 + r][16*ks + 8*hh .. +7] ----
   bf16x8 qf[4];
@@ -273,6 +287,8 @@ extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k,
   a.vt_bstride = (long)vt_batch_stride;
   a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale_log2 = scale * 1.4426950408889634f;
+  static const int xcd_env = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
+  a.xcd_map = (xcd_env && ((B * H) % 8 == 0)) ? 1 : 0;
   dim3 grid(cdiv(Lq, 128), H, B);
   prof_begin((hipStream_t)stream, PROF_ATTN, 4.0 * B * H * (double)Lq * Lk * 64.0,
              2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
