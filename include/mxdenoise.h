@@ -113,6 +113,8 @@ typedef struct mx_gemm_desc {
   int a_batch_rows, a_row_off, c_batch_rows, c_row_off;
   const float* gate;     /* fp32 [M / rows_per_batch, ldg] or NULL: v = gate * (acc + bias) before the residual add */
   int ldg;
+  float out_scale;       /* != 0: v = (acc + bias) * out_scale, before row bias / gate / residual.  Under MX_EPI_QKV only the
+                          * first segment of every group (q) is scaled -- for mx_attention_prescaled */
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -133,6 +135,12 @@ int mx_conv3x3(void* stream, const mx_gemm_desc* d);   /* implicit GEMM, pad 1 *
  * o: bf16 [B*Lq, ldo]. */
 int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                  int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale);
+/* Same, for q that the producer already multiplied by MX_ATTN_QSCALE(scale) = scale * log2(e) (mx_gemm's out_scale, or
+ * mx_rmsnorm_heads' q_scale, do it in fp32 before their single rounding): the kernel then subtracts the softmax reference
+ * inside the matrix core and runs ~35 % fewer vector instructions per key tile (attention.hip).  What the step plans use. */
+#define MX_ATTN_QSCALE(scale) ((scale) * 1.4426950408889634f)
+int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                           int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim C; x,y bf16 [M, C]; gamma/beta fp32 [C] */
 int mx_layernorm(void* stream, const void* x, void* y, const float* gamma, const float* beta,
@@ -145,7 +153,8 @@ int mx_layernorm_mod(void* stream, const void* x, void* y, void* y2, const float
 /* in-place RMSNorm over every 64-wide head of rows (b*batch_rows + row_off + i), i < rows_per_batch, of a bf16 [*, ld] matrix;
  * heads [0, heads_q) use weight wq[64], heads [heads_q, heads_total) use wk[64] (fp32) */
 int mx_rmsnorm_heads(void* stream, void* x, int ld, int nbatch, int rows_per_batch, int batch_rows, int row_off,
-                     int heads_total, int heads_q, const float* wq, const float* wk, float eps);
+                     int heads_total, int heads_q, const float* wq, const float* wk, float eps, float q_scale);
+/* q_scale multiplies the q heads after normalisation (1 = none; MX_ATTN_QSCALE(1/8) for mx_attention_prescaled) */
 
 /* NHWC GroupNorm (+ optional SiLU): x,y bf16 [B, H, W, C]; gamma/beta fp32 [C].
  * patch > 0 selects the reference's sliced statistics (average over patch x patch tiles of

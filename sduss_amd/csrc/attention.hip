@@ -20,6 +20,14 @@
 //     loop carries no avoidable vector work: every LDS address is a loop-invariant per-lane offset whose buffer bit is
 //     toggled by one XOR per tile, key/V^T masking exists only in a separate tail-tile path, P is packed with the
 //     two-operand v_cvt_pk_bf16_f32, and the first MFMA of each S^T block takes a zero accumulator literal.
+//   * PRE variant (mx_attention_prescaled; what the step plans use): Q arrives already multiplied by scale*log2(e) (the
+//     producing GEMM epilogue / RMSNorm does it in fp32 before its single rounding), and the softmax reference m is
+//     subtracted BY THE MATRIX CORE: a fifth k-step multiplies a constant K column of ones with a Q column holding -m, so
+//     S' = s*c - m leaves the MFMA and p = exp2(S') needs no per-element vector op.  m is a lazy reference, not the
+//     running max: it is set from the first tile and raised only when a tile's maximum exceeds it by more than 8 (then
+//     that tile, O and l are rescaled -- exact, softmax is invariant to the reference; p <= 256 and l >= 1 always hold).
+//     Per 64-key tile and lane this removes 32 v_fma, the alpha exp2 and 16 v_pk_mul for two extra MFMAs on a matrix pipe
+//     that was 41 % busy while the vector ALU was 72 % busy (rocprofv3 SQ_ACTIVE_INST_VALU).
 #include <cstdlib>
 
 #include "common.h"
@@ -53,6 +61,7 @@ __device__ __forceinline__ float max_across_halves(float x) {
   return fmaxf(a, b);
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes];
 
@@ -155,8 +164,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
-  float m_run = -INFINITY;  // running max of s*scale_log2 for query column r (identical in both halves)
+  float m_run = -INFINITY;  // !PRE: running max of s*scale_log2 for query column r (identical in both halves)
   float l_run = 0.f;        // this half-wave's partial row sum
+  // PRE: the reference k-step.  A operand: K column of ones = element k == 0 of the step (held by the hh == 0 lanes);
+  // B operand: -m_ref (bf16-representable) in the same element of query column r.
+  const unsigned one_lo = hh == 0 ? 0x3F80u : 0u;
+  const bf16x8 kone = __builtin_bit_cast(bf16x8, u32x4{one_lo, 0u, 0u, 0u});
+  u32x4 qm = {0u, 0u, 0u, 0u};
+  float m_ref = 0.f;
 
   const int ntiles = (p.Lk + KT - 1) / KT;
   const bool ragged = (p.Lk % KT) != 0;
@@ -188,6 +203,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
       for (int kb = 0; kb < 2; ++kb)
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
     }
+    if constexpr (PRE) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm), s[kb], 0, 0, 0);
+    }
     // V^T fragments (same registers): in flight while the softmax runs on the vector ALU
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx)
@@ -210,25 +230,60 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx_ = fmaxf(mx_, s[kb][e]);
     mx_ = max_across_halves(mx_);
-    const float m_new = fmaxf(m_run, mx_ * c);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    // (packed v_pk_fma_f32 / v_pk_add_f32 forms of this loop measured 0-3 % SLOWER in same-run A/B: scalar kept)
     float psum = 0.f;
+    if constexpr (PRE) {
+      // s already holds s*c - m_ref.  Move the reference only on the first tile or when a row ran more than 8 above it.
+      const bool first = kt == 0;
+      if (first || __any(mx_ > 8.0f)) {
+        float delta = 0.f;
+        if (first || mx_ > 8.0f) {
+          const float nr = bf16lo_to_f32(pack2(m_ref + mx_, 0.f));        // new reference, bf16-representable
+          delta = nr - m_ref;
+          m_ref = nr;
+        }
+        qm[0] = hh == 0 ? (pack2(-m_ref, 0.f) & 0xffffu) : 0u;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(s[kb][e] * c - m_new);
-        s[kb][e] = pe;
-        psum += pe;
+          for (int e = 0; e < 16; ++e) s[kb][e] -= delta;
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+        }
       }
-    l_run = l_run * alpha + psum;
-    if (!__all(alpha == 1.0f)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(s[kb][e]);
+          s[kb][e] = pe;
+          psum += pe;
+        }
+      l_run += psum;
+    } else {
+      const float m_new = fmaxf(m_run, mx_ * c);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      // (packed v_pk_fma_f32 / v_pk_add_f32 forms of this loop measured 0-3 % SLOWER in same-run A/B: scalar kept)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(s[kb][e] * c - m_new);
+          s[kb][e] = pe;
+          psum += pe;
+        }
+      l_run = l_run * alpha + psum;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+      }
     }
     // ---- O^T += V^T P^T : P fragments straight from the S^T accumulators ----
 #pragma unroll
@@ -273,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 
 }  // namespace mx
 
-extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
-                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale) {
+static int launch_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale, bool pre) {
   using namespace mx;
   MX_CHECK(q && k && vt && o, "attention: null operand");
   MX_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
@@ -292,8 +347,19 @@ extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k,
   dim3 grid(cdiv(Lq, 128), H, B);
   prof_begin((hipStream_t)stream, PROF_ATTN, 4.0 * B * H * (double)Lq * Lk * 64.0,
              2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
   prof_end((hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale) {
+  return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, scale, false);
+}
+
+extern "C" int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                      int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk) {
+  return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, 1.0f, true);
 }

@@ -26,6 +26,7 @@ struct GemmArgs {
   const float* gate;
   int ldg;
   int xcd_map;   // 1: XCD-aware workgroup -> tile map (gemm_tile_of_block)
+  float out_scale;   // != 0: (acc + bias) * out_scale (QKV: q segments only)
 };
 
 // row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)
@@ -96,6 +97,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += b4[q];
+      }
+      if (p.out_scale != 0.f && (!qkv || seg_pos == 0)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= p.out_scale;
       }
       if (geglu) {
         float g[4];
@@ -231,6 +236,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
     w_seg_grp = w_seg_idx / p.period;
     w_to_vt = (w_seg_idx - w_seg_grp * p.period) == p.period - 1;
   }
+  // output scale of this wave's features (QKV: the q segment only)
+  const float w_scale = (p.out_scale != 0.f && (!qkv || (w_seg_idx - w_seg_grp * p.period) == 0)) ? p.out_scale : 1.0f;
   // read-out assignment of this thread (the same for every slab): chunk c = tid + 512 k -> slab row, feature chunk, C column
   int ro_row[KC], ro_oc[KC], ro_col[KC];       // ro_col < 0: nothing to do (past the slab, or a V^T column)
 #pragma unroll
@@ -314,6 +321,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = v[q] * gelu_fast(g[q]);
         } else {
+          v *= w_scale;
           if (has_rb) v += rb_r[i];
           if (has_gate) v *= gate_r[i];
         }

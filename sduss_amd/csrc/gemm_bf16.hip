@@ -225,7 +225,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout;
   a.stride = d->stride; a.up = d->up; a.corner_patch = d->corner_patch;
   a.a_batch_rows = d->a_batch_rows; a.a_row_off = d->a_row_off; a.c_batch_rows = d->c_batch_rows; a.c_row_off = d->c_row_off;
-  a.gate = d->gate; a.ldg = d->ldg;
+  a.gate = d->gate; a.ldg = d->ldg; a.out_scale = d->out_scale;
   static const int xcd_map = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
   a.xcd_map = xcd_map;
 
@@ -256,7 +256,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   const int v2bn = pick_v2_bn(d, conv);
   if (d->flags & MX_EPI_GEGLU) {
     MX_CHECK(use128, "gemm: GEGLU needs N % 128 == 0");
-    MX_CHECK(!(d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32)) && !d->residual && !d->rowbias, "gemm: GEGLU excludes other epilogues");
+    MX_CHECK(!(d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32)) && !d->residual && !d->rowbias && d->out_scale == 0.f, "gemm: GEGLU excludes other epilogues");
     MX_CHECK(d->ldc >= d->N / 2 && d->ldc % 4 == 0, "gemm: bad ldc for GEGLU");
   } else if (d->flags & MX_EPI_QKV) {
     MX_CHECK(d->seg > 0 && d->seg % 64 == 0 && d->period >= 2 && d->N % (d->seg * d->period) == 0, "gemm: bad QKV segments");

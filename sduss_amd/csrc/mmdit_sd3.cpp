@@ -118,14 +118,15 @@ struct Plan {
     if (!ok()) return false;
     const float* wq = wf(qname, 64); const float* wk = wf(kname, 64);
     if (!ok() || dry) return ok();
-    if (mx_rmsnorm_heads(stream, x, ld, B, rows_per_batch, batch_rows, row_off, 2 * heads, heads, wq, wk, u->cfg.norm_eps))
+    if (mx_rmsnorm_heads(stream, x, ld, B, rows_per_batch, batch_rows, row_off, 2 * heads, heads, wq, wk, u->cfg.norm_eps, MX_ATTN_QSCALE(0.125f)))
       return fail(std::string("rmsnorm_heads: ") + mx_last_error());
     return true;
   }
   bool attention(const bf16_t* qk, int d_model, const bf16_t* vt, int ldvt, bf16_t* o, int heads, int L) {
     if (!ok()) return false;
     if (dry) return true;
-    if (mx_attention(stream, qk, 2 * d_model, qk + d_model, 2 * d_model, vt, ldvt, (int64_t)d_model * ldvt, o, d_model, B, heads, L, L, 0.125f))
+    // q carries MX_ATTN_QSCALE(1/8) from the RMSNorm kernel (q_scale)
+    if (mx_attention_prescaled(stream, qk, 2 * d_model, qk + d_model, 2 * d_model, vt, ldvt, (int64_t)d_model * ldvt, o, d_model, B, heads, L, L))
       return fail(std::string("attention: ") + mx_last_error());
     return true;
   }

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const bf16_t* __rest
 // norm_added_k (attention.py:332-346, 377-388; diffusers RMSNorm(64, eps 1e-6)).
 __global__ __launch_bounds__(256) void rmsnorm_heads_kernel(bf16_t* __restrict__ x, int ld, int nbatch, int rows_per_batch,
                                                             int batch_rows, int row_off, int heads_total, int heads_q,
-                                                            const float* __restrict__ wq, const float* __restrict__ wk, float eps) {
+                                                            const float* __restrict__ wq, const float* __restrict__ wk, float eps, float q_scale) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7;       // 16-byte chunk inside the head
   const int hl = lane >> 3;       // head inside the wave's group of 8
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void rmsnorm_heads_kernel(bf16_t* __restrict__
     sq += v[2 * e] * v[2 * e] + v[2 * e + 1] * v[2 * e + 1];
   }
   sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-  const float rs = rsqrtf(sq * (1.0f / 64.0f) + eps);
+  const float rs = rsqrtf(sq * (1.0f / 64.0f) + eps) * (head < heads_q ? q_scale : 1.0f);
   const float* w = (head < heads_q ? wq : wk) + sub * 8;
   u32x4 o;
 #pragma unroll
@@ -446,14 +446,14 @@ extern "C" int mx_layernorm_mod(void* stream, const void* x, void* y, void* y2, 
 }
 
 extern "C" int mx_rmsnorm_heads(void* stream, void* x, int ld, int nbatch, int rows_per_batch, int batch_rows, int row_off,
-                                int heads_total, int heads_q, const float* wq, const float* wk, float eps) {
+                                int heads_total, int heads_q, const float* wq, const float* wk, float eps, float q_scale) {
   using namespace mx;
   MX_CHECK(x && wq && wk, "rmsnorm_heads: null operand");
   MX_CHECK(ld % 8 == 0 && ld >= heads_total * 64, "rmsnorm_heads: bad row stride");
   MX_CHECK(nbatch > 0 && rows_per_batch > 0 && batch_rows >= row_off + rows_per_batch && row_off >= 0, "rmsnorm_heads: bad rows");
   const long waves = (long)nbatch * rows_per_batch * ((heads_total + 7) / 8);
   hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((unsigned)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld,
-                     nbatch, rows_per_batch, batch_rows, row_off, heads_total, heads_q, wq, wk, eps);
+                     nbatch, rows_per_batch, batch_rows, row_off, heads_total, heads_q, wq, wk, eps, q_scale);
   MX_LAUNCH_CHECK();
   return 0;
 }

@@ -106,8 +106,9 @@ struct Plan {
     return true;
   }
   bool linear(const bf16_t* a, int lda, const std::string& wname, const std::string& bname, void* c, int ldc, int M, int N,
-              int K, const void* residual = nullptr, int ldr = 0, int flags = 0) {
+              int K, const void* residual = nullptr, int ldr = 0, int flags = 0, float out_scale = 0.f) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+    d.out_scale = out_scale;
     d.a = a; d.lda = lda; d.w = wb(wname, (size_t)N * K); d.bias = bname.empty() ? nullptr : wf(bname, N);
     d.c = c; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.residual = residual; d.ldr = ldr; d.flags = flags;
     return gemm(d, false);
@@ -151,7 +152,8 @@ struct Plan {
                  int ldo, int heads, int Lq, int Lk) {
     if (!ok()) return false;
     if (dry) return true;
-    if (mx_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_bstride, o, ldo, B, heads, Lq, Lk, 0.125f))
+    // q carries MX_ATTN_QSCALE(1/8) from the producing GEMM's epilogue (out_scale)
+    if (mx_attention_prescaled(stream, q, ldq, k, ldk, vt, ldvt, vt_bstride, o, ldo, B, heads, Lq, Lk))
       return fail(std::string("attention: ") + mx_last_error());
     return true;
   }
@@ -224,14 +226,14 @@ struct Plan {
         mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
         d.a = ln; d.lda = C; d.w = wb(b + ".attn1.to_qkv.weight", (size_t)3 * C * C); d.c = qk; d.ldc = 2 * C;
         d.M = M; d.N = 3 * C; d.K = C; d.flags = MX_EPI_QKV; d.seg = C; d.period = 3; d.vt = vt; d.ldvt = ldvt;
-        d.rows_per_batch = L;
+        d.rows_per_batch = L; d.out_scale = MX_ATTN_QSCALE(0.125f);   // q segment only
         gemm(d, false);
       }
       attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
       linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", y, C, M, C, C, y, C);
       // cross-attention (K/V of encoder_hidden_states precomputed for all layers of this width)
       layernorm(y, ln, b + ".norm2", M, C);
-      linear(ln, C, b + ".attn2.to_q.weight", "", q2, C, M, C, C);
+      linear(ln, C, b + ".attn2.to_q.weight", "", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f));
       if (ok()) {
         const int li = kvp->next++;
         attention(q2, C, kvp->k + (size_t)li * C, kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, kvp->ldvt, kvp->vt_bstride,

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("corner_patch", C.c_int),
         ("a_batch_rows", C.c_int), ("a_row_off", C.c_int), ("c_batch_rows", C.c_int), ("c_row_off", C.c_int),
-        ("gate", C.c_void_p), ("ldg", C.c_int),
+        ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float),
     ]
 
 
@@ -72,6 +72,7 @@ SYMBOLS = {
     "mx_gemm": (_i, [_vp, C.POINTER(GemmDesc)]),
     "mx_conv3x3": (_i, [_vp, C.POINTER(GemmDesc)]),
     "mx_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _f]),
+    "mx_attention_prescaled": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i]),
     "mx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "mx_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mx_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
@@ -84,7 +85,7 @@ SYMBOLS = {
     "mx_unet_forward_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz,
                                    C.c_char_p, _vp, _sz]),
     "mx_layernorm_mod": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f]),
-    "mx_rmsnorm_heads": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f]),
+    "mx_rmsnorm_heads": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _f]),
     "mx_mmdit_create": (_vp, [C.POINTER(MMDiTConfigC)]),
     "mx_mmdit_destroy": (None, [_vp]),
     "mx_mmdit_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),

@@ -22,8 +22,8 @@ def _bf16(t):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, silu: bool = False, geglu: bool = False,
-         out_f32: bool = False) -> torch.Tensor:
-    """C[M,N] = A[M,K] W[N,K]^T (+bias +rowbias +residual, silu | geglu).  With ``geglu`` the weight/bias rows must be
+         out_f32: bool = False, out_scale: float = 0.0) -> torch.Tensor:
+    """C[M,N] = (A[M,K] W[N,K]^T + bias) * out_scale (+rowbias +residual, silu | geglu).  With ``geglu`` the weight/bias rows must be
     interleaved as weights._geglu_interleave does; the output is [M, N/2]."""
     l = _lib.load()
     _bf16(a); _bf16(w)
@@ -38,7 +38,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     d.M, d.N, d.K, d.lda, d.ldc = m, n, k, k, nout
     d.ldr = residual.shape[1] if residual is not None else 0
     d.ldrb = rowbias.shape[1] if rowbias is not None else 0
-    d.rows_per_batch, d.flags = rows_per_batch, flags
+    d.rows_per_batch, d.flags, d.out_scale = rows_per_batch, flags, out_scale
     _lib.check(l.mx_gemm(_lib.current_stream(), C.byref(d)), "mx_gemm")
     return c
 
@@ -67,7 +67,7 @@ def unpack_vt(vt: torch.Tensor, lk: int) -> torch.Tensor:
     return vt[:, :, vt_pos(lk).to(vt.device)].permute(0, 2, 1)
 
 
-def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_batch: int):
+def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_batch: int, q_scale: float = 0.0):
     """Fused projection with the V segments written transposed.  Returns (c [M, N/period*(period-1)],
     vt [M/rows_per_batch, N/period, ldvt] in MX_VT_POS key order; see unpack_vt)."""
     l = _lib.load()
@@ -82,6 +82,7 @@ def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_b
     d.a, d.w, d.c, d.vt = a.data_ptr(), w.data_ptr(), c.data_ptr(), vt.data_ptr()
     d.M, d.N, d.K, d.lda, d.ldc = m, n, k, k, c.shape[1]
     d.rows_per_batch, d.flags, d.seg, d.period, d.ldvt = rows_per_batch, _lib.EPI_QKV, seg, period, ldvt
+    d.out_scale = q_scale                       # scales the q segment only (mx_attention_prescaled)
     _lib.check(l.mx_gemm(_lib.current_stream(), C.byref(d)), "mx_gemm(qkv)")
     return c, vt
 
@@ -106,12 +107,21 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stri
     return c
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, lq: int, lk: int) -> torch.Tensor:
-    """q [B*Lq, H*64], k [B*Lk, H*64], vt [B, H*64, ldvt] (all bf16) -> o [B*Lq, H*64]."""
+ATTN_QSCALE = 0.125 * 1.4426950408889634     # MX_ATTN_QSCALE(1/sqrt(64))
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, lq: int, lk: int, prescaled: bool = False) -> torch.Tensor:
+    """q [B*Lq, H*64], k [B*Lk, H*64], vt [B, H*64, ldvt] (all bf16) -> o [B*Lq, H*64].  ``prescaled``: q already carries
+    the factor ATTN_QSCALE (mx_attention_prescaled)."""
     l = _lib.load()
     _bf16(q); _bf16(k); _bf16(vt)
     b = vt.shape[0]
     o = torch.empty_like(q)
+    if prescaled:
+        _lib.check(l.mx_attention_prescaled(_lib.current_stream(), q.data_ptr(), q.shape[1], k.data_ptr(), k.shape[1], vt.data_ptr(),
+                                            vt.shape[2], vt.shape[1] * vt.shape[2], o.data_ptr(), o.shape[1], b, heads, lq, lk),
+                   "mx_attention_prescaled")
+        return o
     _lib.check(l.mx_attention(_lib.current_stream(), q.data_ptr(), q.shape[1], k.data_ptr(), k.shape[1], vt.data_ptr(),
                               vt.shape[2], vt.shape[1] * vt.shape[2], o.data_ptr(), o.shape[1], b, heads, lq, lk,
                               0.125), "mx_attention")
@@ -183,11 +193,11 @@ def layernorm_mod(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, row
 
 
 def rmsnorm_heads_(x: torch.Tensor, nbatch: int, rows_per_batch: int, batch_rows: int, row_off: int, heads_total: int,
-                   heads_q: int, wq: torch.Tensor, wk: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+                   heads_q: int, wq: torch.Tensor, wk: torch.Tensor, eps: float = 1e-6, q_scale: float = 1.0) -> torch.Tensor:
     l = _lib.load()
     _bf16(x)
     _lib.check(l.mx_rmsnorm_heads(_lib.current_stream(), x.data_ptr(), x.shape[1], nbatch, rows_per_batch, batch_rows, row_off,
-                                  heads_total, heads_q, wq.data_ptr(), wk.data_ptr(), eps), "mx_rmsnorm_heads")
+                                  heads_total, heads_q, wq.data_ptr(), wk.data_ptr(), eps, q_scale), "mx_rmsnorm_heads")
     return x
 
 

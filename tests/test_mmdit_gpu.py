@@ -54,11 +54,11 @@ def test_rmsnorm_heads_joint_rows(cuda_device):
     x = _rt(torch.randn(b * lj, 2 * heads * 64, generator=g) * 1.7)
     wq = 1 + 0.2 * torch.randn(64, generator=g); wk = 1 + 0.2 * torch.randn(64, generator=g)
     xg = _bf(x).cuda()
-    ops.rmsnorm_heads_(xg, b, lt, lj, li, 2 * heads, heads, wq.cuda(), wk.cuda(), 1e-6)
+    ops.rmsnorm_heads_(xg, b, lt, lj, li, 2 * heads, heads, wq.cuda(), wk.cuda(), 1e-6, q_scale=0.18)
     want = x.clone().reshape(b, lj, 2 * heads, 64)
     sel = want[:, li:]
     nrm = sel * torch.rsqrt(sel.pow(2).mean(-1, keepdim=True) + 1e-6)
-    nrm[:, :, :heads] *= wq
+    nrm[:, :, :heads] *= wq * 0.18           # q_scale applies to the q heads only
     nrm[:, :, heads:] *= wk
     want[:, li:] = nrm
     _close(xg, want.reshape(b * lj, -1), 2.0 ** -7, "rmsnorm_heads")

@@ -289,3 +289,63 @@ def test_gemm_tile256_qkv(cuda_device):
         c, vt = ops.gemm_qkv(_bf(a).cuda(), _bf(w).cuda(), dim, 3, rows)
     _close(c, full[:, :2].reshape(nb * rows, -1), 2.0 ** -7, "tile256 qkv row-major part")
     _close(ops.unpack_vt(vt, rows), full[:, 2].reshape(nb, rows, dim), 2.0 ** -7, "tile256 qkv V^T")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# mx_attention_prescaled: q carries scale*log2(e); the softmax reference is subtracted inside the matrix core
+# ----------------------------------------------------------------------------------------------------------------------
+def _prescaled_case(q, k, v, heads, what, tol=2.0 ** -6):
+    """q, k, v fp32 [b, l, c].  The kernel sees qs = bf16(q * QSCALE); the reference is computed from that same qs
+    (softmax_j exp2(qs . k_j) == attention with q' = qs * 8 ln2 at scale 1/8)."""
+    from sduss_amd import ops
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    qs = _rt(q * ops.ATTN_QSCALE)
+    want = ref.attention(qs * (8.0 * math.log(2.0)), k, v, heads)
+    got = ops.attention(_bf(qs.reshape(-1, c)).cuda(), _bf(k.reshape(-1, c)).cuda(), _bf(ops.pack_vt(v, pad=float("nan"))).cuda(),
+                        heads, lq, lk, prescaled=True)
+    _close(got.reshape(b, lq, c), want, tol, what)
+
+
+@pytest.mark.parametrize("lq,lk,heads", [(256, 256, 2), (1024, 1024, 1), (64, 77, 4), (200, 77, 1), (4096, 4096, 1), (333, 4429, 1)])
+def test_attention_prescaled(cuda_device, lq, lk, heads):
+    g = torch.Generator().manual_seed(lq * 3 + lk + heads)
+    b, c = 2, heads * 64
+    q = _rt(torch.randn(b, lq, c, generator=g)); k = _rt(torch.randn(b, lk, c, generator=g)); v = _rt(torch.randn(b, lk, c, generator=g))
+    _prescaled_case(q, k, v, heads, f"attention prescaled {lq}x{lk}")
+
+
+@pytest.mark.parametrize("case", ["late_spikes", "first_tile_max", "very_negative_start", "huge_logits"])
+def test_attention_prescaled_reference_moves(cuda_device, case):
+    """the lazy softmax reference: raised at late tiles, never needed again, started far below zero, and logits whose
+    exp2 would overflow fp32 without a reference."""
+    g = torch.Generator().manual_seed(17)
+    b, l, c = 1, 512, 64
+    q = _rt(torch.randn(b, l, c, generator=g)); k = _rt(torch.randn(b, l, c, generator=g)); v = _rt(torch.randn(b, l, c, generator=g))
+    if case == "late_spikes":
+        k[0, 300] = q[0, 5] * 4.0; k[0, 450] = q[0, 77] * 6.0; k[0, 451] = q[0, 77] * 9.0
+    elif case == "first_tile_max":
+        k[0, 3] = q[0, 9] * 8.0
+    elif case == "very_negative_start":
+        k[0, :64] = -q[0, 11] * 6.0            # row 11 sees strongly negative logits in the whole first tile
+    elif case == "huge_logits":
+        q = q * 6.0; k = k * 6.0               # |logit| * log2(e) well beyond 128
+    _prescaled_case(_rt(q), _rt(k), v, 1, f"attention prescaled {case}")
+
+
+def test_gemm_out_scale(cuda_device):
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(91)
+    for m, n, k in ((300, 192, 128), (4096, 4096, 128)):        # generic kernel / 256x256 kernel
+        a = _rt(torch.randn(m, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5); bias = torch.randn(n, generator=g)
+        r = _rt(torch.randn(m, n, generator=g))
+        got = ops.gemm(_bf(a).cuda(), _bf(w).cuda(), bias.cuda(), residual=_bf(r).cuda(), out_scale=0.18)
+        _close(got, (a @ w.t() + bias) * 0.18 + r, 2.0 ** -7, f"gemm out_scale {m}x{n}")
+    # QKV: only the q segment is scaled
+    for nb, rows, dim, k in ((2, 64, 128, 128), (4, 1024, 1024, 128)):
+        a = _rt(torch.randn(nb * rows, k, generator=g)); w = _rt(torch.randn(3 * dim, k, generator=g) * k ** -0.5)
+        full = (a @ w.t()).reshape(nb * rows, 3, dim)
+        c, vt = ops.gemm_qkv(_bf(a).cuda(), _bf(w).cuda(), dim, 3, rows, q_scale=0.18)
+        want = torch.cat([full[:, 0] * 0.18, full[:, 1]], dim=1)
+        _close(c, want, 2.0 ** -7, f"qkv q_scale {dim}")
+        _close(ops.unpack_vt(vt, rows), full[:, 2].reshape(nb, rows, dim), 2.0 ** -7, "qkv q_scale leaves V alone")

@@ -22,18 +22,19 @@ def main():
         k = torch.randn(b * lk, c, device=dev, generator=g).to(torch.bfloat16)
         ldvt = ops.vt_ld(lk)
         vt = torch.randn(b, c, ldvt, device=dev, generator=g).to(torch.bfloat16)
-        for _ in range(2):
-            ops.attention(q, k, vt, h, lq, lk)
-        torch.cuda.synchronize()
-        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(iters):
-            ops.attention(q, k, vt, h, lq, lk)
-        e.record()
-        torch.cuda.synchronize()
-        t = a.elapsed_time(e) / iters * 1e-3
-        fl = 4.0 * b * h * lq * lk * 64
-        print(f"attn B{b} H{h} Lq{lq} Lk{lk}  {t * 1e6:9.1f} us  {fl / t / 1e12:7.1f} TFLOP/s")
+        for pre in (False, True):
+            for _ in range(2):
+                ops.attention(q, k, vt, h, lq, lk, prescaled=pre)
+            torch.cuda.synchronize()
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                ops.attention(q, k, vt, h, lq, lk, prescaled=pre)
+            e.record()
+            torch.cuda.synchronize()
+            t = a.elapsed_time(e) / iters * 1e-3
+            fl = 4.0 * b * h * lq * lk * 64
+            print(f"attn{' prescaled' if pre else '          '} B{b} H{h} Lq{lq} Lk{lk}  {t * 1e6:9.1f} us  {fl / t / 1e12:7.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
