@@ -234,3 +234,95 @@ def test_sd3_denoising_step_two_steps(tiny):
         lat = lat.to(torch.bfloat16).float()
     assert all(r.step_index == 2 for r in reqs)
     _check(torch.cat([r.latents for r in reqs]), lat, "sd3 denoising_step x2", max_rel=0.06, l2_rel=0.04)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the same epilogues at shapes that run the 256-row kernels with the LDS-staged epilogue (checked through the profiler)
+# ----------------------------------------------------------------------------------------------------------------------
+def _kinds_launched(fn):
+    """runs fn() under mx_profile and returns {profiler kind: launches} (6-9 = 256x{160,128} kernel, 10 = 256x256)"""
+    from sduss_amd import lib
+    l = lib.load()
+    l.mx_profile_enable(1)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        buf = (C.c_double * 64)()
+        lib.check(l.mx_profile_collect(buf), "mx_profile_collect")
+    finally:
+        l.mx_profile_enable(0)
+    return {k: int(buf[4 * k]) for k in range(11) if buf[4 * k] > 0}
+
+
+@pytest.mark.parametrize("rows,n,k,kinds", [(1024, 1600, 128, {6}), (1024, 640, 192, {6, 8}), (8192, 1536, 128, {10}), (1000, 1024, 128, {8, 10})])
+def test_large_tile_gemm_gate_residual_rowbias_gelu(cuda_device, rows, n, k, kinds):
+    """gated residual (AdaLN-Zero), per-sample row bias (time embedding), GELU-tanh and fp32 output through the staged
+    epilogue, incl. a rows_per_batch that is not a multiple of the tile and a row stride wider than N."""
+    from sduss_amd import lib
+    l = lib.load()
+    g = torch.Generator().manual_seed(rows + n)
+    b = 4
+    m = b * rows
+    a = _rt(torch.randn(m, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
+    bias = torch.randn(n, generator=g); gate = torch.randn(b, n + 64, generator=g); rb = torch.randn(b, n + 32, generator=g)
+    r = _rt(torch.randn(m, n + 16, generator=g))
+    ag, wg, rg, gg, bg, rbg = _bf(a).cuda(), _bf(w).cuda(), _bf(r).cuda(), gate.cuda(), bias.cuda(), rb.cuda()
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    base = a @ w.t() + bias
+
+    def gated():
+        d = _gemm_desc(lib, ag, wg, out, bias=bg, residual=rg, ldr=n + 16, gate=gg, ldg=n + 64, rows_per_batch=rows)
+        lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    seen = _kinds_launched(gated)
+    assert set(seen) <= kinds and seen, f"expected kernel kinds {kinds}, profiler saw {seen}"
+    _close(out, r[:, :n] + gate[:, :n].repeat_interleave(rows, dim=0) * base, 2.0 ** -7, "large-tile gated residual")
+
+    d = _gemm_desc(lib, ag, wg, out, bias=bg, rowbias=rbg, ldrb=n + 32, rows_per_batch=rows, flags=lib.EPI_SILU)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    _close(out, F.silu(base + rb[:, :n].repeat_interleave(rows, dim=0)), 2.0 ** -7, "large-tile row bias + silu")
+
+    d = _gemm_desc(lib, ag, wg, out, bias=bg, flags=lib.EPI_GELU_TANH)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    _close(out, F.gelu(base, approximate="tanh"), 2.0 ** -7, "large-tile gelu-tanh")
+
+    out32 = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    d = _gemm_desc(lib, ag, wg, out32, bias=bg, flags=lib.EPI_OUT_F32)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    _close(out32, base, 2.0 ** -12, "large-tile fp32 out")
+
+
+@pytest.mark.parametrize("li,lt,dm", [(1024, 333, 256), (4096, 77, 128)])
+def test_large_tile_joint_rows(cuda_device, li, lt, dm):
+    """QKV of the image rows written into a joint [image ; text] sequence by the 256-row kernels (row remap, V^T key offset),
+    the out-projection reading the image rows back through the input remap, and the broadcast residual (positional table)."""
+    from sduss_amd import lib, ops
+    l = lib.load()
+    g = torch.Generator().manual_seed(li + lt)
+    b, k = 4, 128
+    lj = li + lt
+    ldvt = ops.vt_ld(lj)
+    qk = torch.zeros(b * lj, 2 * dm, dtype=torch.bfloat16, device="cuda")
+    vt = torch.zeros(b, dm, ldvt, dtype=torch.bfloat16, device="cuda")
+    a = _rt(torch.randn(b * li, k, generator=g)); w = _rt(torch.randn(3 * dm, k, generator=g) * k ** -0.5); bias = torch.randn(3 * dm, generator=g)
+    ag, wg, bg = _bf(a).cuda(), _bf(w).cuda(), bias.cuda()
+
+    def run():
+        d = _gemm_desc(lib, ag, wg, qk, bias=bg, vt=vt, flags=lib.EPI_QKV, seg=dm, period=3, ldvt=ldvt, rows_per_batch=li,
+                       c_batch_rows=lj, c_row_off=0, out_scale=0.18)
+        lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    seen = _kinds_launched(run)
+    assert set(seen) <= {6, 8, 10} and seen, f"expected a 256-row kernel, profiler saw {seen}"
+    full = (a @ w.t() + bias).reshape(b, li, 3, dm)
+    qkc = qk.float().cpu().reshape(b, lj, 2 * dm)
+    _close(qkc[:, :li, :dm], full[:, :, 0] * 0.18, 2.0 ** -7, "joint q rows (scaled)")
+    _close(qkc[:, :li, dm:], full[:, :, 1], 2.0 ** -7, "joint k rows")
+    assert qkc[:, li:].abs().max() == 0, "text rows of the joint buffer were touched"
+    _close(ops.unpack_vt(vt.float().cpu(), lj)[:, :li], full[:, :, 2], 2.0 ** -7, "joint V^T keys")
+    # read the image rows back through the loader remap, add a positional table broadcast over the batch
+    w2 = _rt(torch.randn(256, 2 * dm, generator=g) * (2 * dm) ** -0.5); pos = _rt(torch.randn(li, 256, generator=g))
+    w2g, pg = _bf(w2).cuda(), _bf(pos).cuda()
+    out = torch.empty(b * li, 256, dtype=torch.bfloat16, device="cuda")
+    d = _gemm_desc(lib, qk, w2g, out, M=b * li, rows_per_batch=li, a_batch_rows=lj, a_row_off=0, residual=pg, ldr=256,
+                   flags=lib.EPI_RES_BCAST)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    _close(out, (qkc[:, :li] @ w2.t() + pos).reshape(b * li, 256), 2.0 ** -7, "input row remap + broadcast residual")
