@@ -24,6 +24,7 @@
 
 #include "../../include/mxdenoise.h"
 #include "common.h"
+#include "graph_cache.h"
 
 namespace mx {
 int launch_prep_latent(hipStream_t s, const void* in, int dtype, void* out, int B, int Cin, int HW, int CP);
@@ -41,6 +42,7 @@ struct mx_unet {
   const char* blob = nullptr;
   uint64_t blob_bytes = 0;
   std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> table;
+  mx::GraphCache graphs;   // hipGraph replay of the forward, keyed by its arguments (graph_cache.h)
 };
 
 namespace {
@@ -433,14 +435,31 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
     MX_CHECK(u->blob != nullptr, "unet: weights not set");
     MX_CHECK(io_dtype == MX_F32 || io_dtype == MX_F16 || io_dtype == MX_BF16, "unet: bad io dtype");
   }
-  Plan p;
-  p.u = u; p.stream = (hipStream_t)stream; p.B = batch; p.H = H; p.W = W; p.ctx_len = ctx_len;
-  p.gn_patch = (gn_patch >= H && gn_patch >= W) ? 0 : gn_patch;
-  p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
-  p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
-  const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
-  if (peak) *peak = p.ar.peak;
-  if (!okr) { mx::set_error(p.err); return 1; }
+  std::string err;
+  size_t plan_peak = 0;
+  auto enqueue = [&](hipStream_t s) {
+    Plan p;
+    p.u = u; p.stream = s; p.B = batch; p.H = H; p.W = W; p.ctx_len = ctx_len;
+    p.gn_patch = (gn_patch >= H && gn_patch >= W) ? 0 : gn_patch;
+    p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
+    p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
+    const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
+    plan_peak = p.ar.peak;
+    if (!okr) err = p.err;
+    return okr;
+  };
+  bool okr;
+  if (dry || stage) {
+    okr = enqueue((hipStream_t)stream);
+  } else {
+    const std::vector<uint64_t> key = {(uint64_t)batch, (uint64_t)H, (uint64_t)W, (uint64_t)ctx_len, (uint64_t)gn_patch, (uint64_t)io_dtype,
+                                       (uint64_t)(uintptr_t)latents, (uint64_t)(uintptr_t)timesteps, (uint64_t)(uintptr_t)ehs,
+                                       (uint64_t)(uintptr_t)text_embeds, (uint64_t)(uintptr_t)time_ids, (uint64_t)(uintptr_t)out,
+                                       (uint64_t)(uintptr_t)workspace, (uint64_t)workspace_bytes, (uint64_t)(uintptr_t)u->blob};
+    okr = u->graphs.run((hipStream_t)stream, key, enqueue);
+  }
+  if (peak) *peak = plan_peak;
+  if (!okr) { mx::set_error(err); return 1; }
   return 0;
 }
 

@@ -56,6 +56,7 @@ class MxUNet:
         _lib.check(self._lib.mx_unet_set_weights(self._handle, self.weights.blob.data_ptr(), self.weights.blob.numel(),
                                                  self.weights.table, len(self.weights.names)), "mx_unet_set_weights")
         self._ws: Optional[torch.Tensor] = None
+        self._ws_need = {}
         self.config = _Config(in_channels=cfg.in_channels, time_cond_proj_dim=None,
                               addition_time_embed_dim=cfg.addition_time_embed_dim,
                               projection_class_embeddings_input_dim=cfg.projection_class_embeddings_input_dim,
@@ -72,7 +73,10 @@ class MxUNet:
 
     # -------------------------------------------------------------------------------------------------
     def _workspace(self, batch: int, h: int, w: int, ctx_len: int) -> torch.Tensor:
-        need = self._lib.mx_unet_workspace_bytes(self._handle, batch, h, w, ctx_len)
+        key = (batch, h, w, ctx_len)
+        need = self._ws_need.get(key)
+        if need is None:                      # a dry run of the whole plan: once per shape
+            need = self._ws_need[key] = self._lib.mx_unet_workspace_bytes(self._handle, batch, h, w, ctx_len)
         if need == 0:
             raise _lib.MxError("mx_unet_workspace_bytes: " + self._lib.mx_last_error().decode())
         if self._ws is None or self._ws.numel() < need:

@@ -127,3 +127,21 @@ def test_unet_full_width_sdxl(cuda_device):
     net = MxUNet(UNetConfig.sdxl_base(), P, device="cuda:0")
     got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
     _check(got, want, "unet full width 32x32", max_rel=0.05, l2_rel=0.03)
+
+
+def test_unet_graph_replay_follows_buffer_contents(tiny):
+    """The forward is captured into a hipGraph keyed by its argument pointers (graph_cache.h) and replayed: a replay must read
+    the CURRENT contents of the caller's buffers, and equal inputs must give bit-identical outputs on capture and replay."""
+    ocfg, P, net = tiny
+    s1, t, e, te, ti = ref.make_inputs(ocfg, 2, 32, seed=5)
+    s2 = ref.make_inputs(ocfg, 2, 32, seed=6)[0]
+    sg, tg, eg, teg, tig = s1.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda()
+    outs = []
+    for k in range(4):                      # same tensors (same pointers) every call: capture, then replays
+        if k == 2:
+            sg.copy_(s2.to(torch.bfloat16))   # new contents, same address
+        outs.append(net.forward_one(sg, tg, eg, teg, tig).float().cpu())
+    assert torch.equal(outs[0], outs[1]), "replay differs from the captured run"
+    assert torch.equal(outs[2], outs[3])
+    assert not torch.equal(outs[1], outs[2]), "replay ignored the new buffer contents"
+    _check(outs[2], ref.unet_forward(P, ocfg, s2.to(torch.bfloat16).float(), t, e, te, ti), "graph replay with new contents")

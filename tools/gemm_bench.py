@@ -31,7 +31,17 @@ def bench(fn, iters=20):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+SMALL = [  # UNet batch 2 (one request): level-2 M = 2048, level-1 M = 8192
+    ("gemm", 2048, 1280, 1280), ("gemm", 2048, 1280, 5120), ("gemm", 2048, 3840, 1280), ("geglu", 2048, 10240, 1280),
+    ("gemm", 8192, 640, 640), ("geglu", 8192, 5120, 640), ("gemm", 8192, 640, 2560), ("gemm", 8192, 1920, 640),
+    ("conv", 2, 1280, (32, 1280)), ("conv", 2, 320, (128, 320)), ("conv", 2, 640, (64, 640)),
+]
+
+
 def main():
+    global SHAPES
+    if os.environ.get("SHAPES") == "small":
+        SHAPES = SMALL
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
     print(f"MX_V2_VAR={os.environ.get('MX_V2_VAR', '0')} MX_GEMM_V2={os.environ.get('MX_GEMM_V2', '1')}")
