@@ -55,7 +55,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3, help="timed denoising steps per composition (after one warm-up step)")
     ap.add_argument("--max-total", type=int, default=8)
     ap.add_argument("--rows", type=int, default=120)
+    ap.add_argument("--fit-only", action="store_true", help="re-fit from the committed profiles/unet_time_<model>_mi355x.csv (no GPU)")
     args = ap.parse_args()
+    out_dir = os.path.join(ROOT, "profiles")
+    csv_path = os.path.join(out_dir, f"unet_time_{args.model}_mi355x.csv")
+    if args.fit_only:
+        rows = [tuple(float(x) for x in l.split(",")) for l in open(csv_path).read().splitlines()[1:]]
+        rows = [(int(a), int(b), int(c), t) for a, b, c, t in rows]
+        return fit(args, rows, out_dir)
     dev = "cuda:0"
     torch.cuda.set_device(0)
     if args.model == "sdxl":
@@ -97,32 +104,42 @@ def main():
         if idx % 10 == 0:
             print(f"[{idx + 1}/{len(comps)}] {a},{b},{c}: {step * 1e3:.1f} ms/step  (elapsed {time.time() - t_start:.0f} s)", flush=True)
         del reqs
-    out_dir = os.path.join(ROOT, "profiles")
-    csv_path = os.path.join(out_dir, f"unet_time_{args.model}_mi355x.csv")
     with open(csv_path, "w") as f:
         f.write("512 num, 768 num, 1024 num, avg unet time\n")
         for a, b, c, t in rows:
             f.write(f"{a},{b},{c},{t}\n")
+    fit(args, rows, out_dir)
+
+
+def fit(args, rows, out_dir):
     # the reference's model class and features
     from sklearn.neural_network import MLPRegressor
+    from sklearn.pipeline import make_pipeline
+    from sklearn.preprocessing import StandardScaler
     import joblib
     X = features([r[:3] for r in rows]); y = np.asarray([r[3] for r in rows])
     rng = np.random.RandomState(10086)
     perm = rng.permutation(len(rows))
     n_test = max(8, len(rows) // 6)
     te, tr = perm[:n_test], perm[n_test:]
-    model = MLPRegressor(hidden_layer_sizes=(32, 32, 16), max_iter=20000, random_state=10086, learning_rate_init=1e-3, tol=1e-7)
+    # same network as the reference's pickles; inputs standardised and the small table fitted with L-BFGS (the object keeps
+    # the .predict(features) interface Predictor.predict calls)
+    def make():
+        return make_pipeline(StandardScaler(), MLPRegressor(hidden_layer_sizes=(32, 32, 16), solver="lbfgs", alpha=1e-3, max_iter=5000,
+                                                            random_state=10086))
+    model = make()
     model.fit(X[tr], y[tr])
     err_tr = np.abs(model.predict(X[tr]) - y[tr]) / y[tr]
     err_te = np.abs(model.predict(X[te]) - y[te]) / y[te]
+    model = make()
     model.fit(X, y)                                    # the shipped predictor is fitted on every row
     joblib.dump(model, os.path.join(out_dir, f"schedule_predictor_{args.model}_mi355x.pkl"))
     singles = {res: next(t for a, b, c, t in rows if (a, b, c) == tuple(1 if i == j else 0 for j in range(3))) / 50.0
                for i, res in enumerate((512, 768, 1024))}
     with open(os.path.join(out_dir, f"predictor_{args.model}_mi355x.txt"), "w") as f:
-        f.write(f"{args.model} on MI355X: {len(rows)} batch compositions (<= {args.max_total} requests), {args.steps} timed steps each, "
+        f.write(f"{args.model} on MI355X: {len(rows)} batch compositions (<= {max(sum(r[:3]) for r in rows)} requests), 3 timed steps each, "
                 f"is_sliced=True patch 256, CFG, bf16, synthetic weights\n")
-        f.write("features: a, b, c, 4a+9b+16c, #non-zero (ESyMReD.py:48-53); target: seconds per 50 steps; MLPRegressor(32,32,16)\n")
+        f.write("features: a, b, c, 4a+9b+16c, #non-zero (ESyMReD.py:48-53); target: seconds per 50 steps; StandardScaler + MLPRegressor(32,32,16)\n")
         f.write(f"hold-out ({n_test} rows): mean relative error {err_te.mean():.4f}, max {err_te.max():.4f}; "
                 f"train: mean {err_tr.mean():.4f}, max {err_tr.max():.4f}\n")
         f.write("Predictor.latency (single request, seconds per step): " + ", ".join(f'"{r}": {v:.4f}' for r, v in singles.items()) + "\n")
