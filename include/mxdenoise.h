@@ -83,7 +83,8 @@ enum {
   MX_EPI_QKV      = 1 << 3,  /* column segments of width seg: segment s with (s % period) == period-1
                                 is written transposed into vt[b][vcol][key]; others row-major, compacted */
   MX_EPI_GELU_TANH = 1 << 4, /* out = gelu(v), tanh approximation (diffusers FeedForward "gelu-approximate") */
-  MX_EPI_RES_BCAST = 1 << 5  /* residual row = output row modulo rows_per_batch (positional table broadcast over the batch) */
+  MX_EPI_RES_BCAST = 1 << 5, /* residual row = output row modulo rows_per_batch (positional table broadcast over the batch) */
+  MX_EPI_RMSNORM  = 1 << 6   /* with MX_EPI_QKV: RMS-normalise every 64-wide head of the q and k segments (see rms_wq below) */
 };
 
 typedef struct mx_gemm_desc {
@@ -115,6 +116,12 @@ typedef struct mx_gemm_desc {
   int ldg;
   float out_scale;       /* != 0: v = (acc + bias) * out_scale, before row bias / gate / residual.  Under MX_EPI_QKV only the
                           * first segment of every group (q) is scaled -- for mx_attention_prescaled */
+  /* MX_EPI_RMSNORM (with MX_EPI_QKV, period 3, N % 128 == 0): every 64-wide head of the q and k segments is RMS-normalised
+   * before it is stored: x * rsqrt(mean(x^2) + rms_eps) * w, w = rms_wq / rms_wk (fp32 [64]); out_scale then multiplies the
+   * normalised q.  Fuses diffusers' norm_q / norm_k (RMSNorm(64)) of the SD3 attention into the projection. */
+  const float* rms_wq;
+  const float* rms_wk;
+  float rms_eps;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */

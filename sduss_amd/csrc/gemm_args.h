@@ -27,6 +27,9 @@ struct GemmArgs {
   int ldg;
   int xcd_map;   // 1: XCD-aware workgroup -> tile map (gemm_tile_of_block)
   float out_scale;   // != 0: (acc + bias) * out_scale (QKV: q segments only)
+  const float* rms_wq;   // MX_EPI_RMSNORM: per-head RMSNorm weights of the q / k segments
+  const float* rms_wk;
+  float rms_eps;
 };
 
 // row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)
@@ -40,31 +43,10 @@ __device__ __forceinline__ long gemm_out_row(const GemmArgs& p, int m, int bidx)
   return (long)bidx * p.c_batch_rows + p.c_row_off + (m - bidx * p.rows_per_batch);
 }
 
-// Residual values of the plain epilogue path, fetched by the caller BEFORE its main loop (older than every LDS-DMA, so the
-// kernel's counted vmcnt waits cover them and the HBM read hides under the K loop).
-template <int NI, int MI>
-__device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& p, u32x2 (&pre)[NI][MI], const int m_wave0,
-                                                       const int wave_n0, const int fr, const int fq) {
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int m = m_wave0 + j * 16 + fr;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int n = wave_n0 + i * 16 + fq * 4;
-      long rr = m;
-      if (m < p.M) {
-        const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
-        rr = (p.flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
-      }
-      pre[i][j] = (m < p.M && n < p.N) ? *reinterpret_cast<const u32x2*>(p.residual + rr * p.ldr + n) : u32x2{0u, 0u};
-    }
-  }
-}
-
-template <int NI, int MI, int BN, bool PRE = false>
+// Register-layout epilogue of the generic 128-row kernel (gemm_bf16.hip); the 256-row kernels use gemm_epilogue_staged below.
+template <int NI, int MI, int BN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0,
-                                              const int wave_n0, const int fr, const int fq,
-                                              const u32x2 (*pre)[MI] = nullptr) {
+                                              const int wave_n0, const int fr, const int fq) {
   const int flags = p.flags;
   const bool geglu = (flags & MX_EPI_GEGLU) != 0;
   const bool qkv = (flags & MX_EPI_QKV) != 0;
@@ -78,9 +60,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
     to_vt = (seg_pos == p.period - 1);
   }
 
+  // MX_EPI_RMSNORM: the wave's 64 features are one head (BN = 128).  A token's head is spread over the NI = 4 blocks of a
+  // lane and the 4 lanes fr, fr+16, fr+32, fr+48.
+  const bool rms = qkv && (flags & MX_EPI_RMSNORM) && !to_vt;
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = m_wave0 + j * 16 + fr;
+    float rms_mul = 1.0f;
+    if (rms) {                                   // before the row mask: the shuffles need every lane
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int n = wave_n0 + i * 16 + fq * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float t = acc[i][j][q] + (p.bias ? p.bias[n + q] : 0.f); ss += t * t; }
+      }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      rms_mul = rsqrtf(ss * (1.0f / 64.0f) + p.rms_eps) * ((seg_pos == 0 && p.out_scale != 0.f) ? p.out_scale : 1.0f);
+    }
     if (m >= p.M) continue;
     const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
     const long orow = gemm_out_row(p, m, bidx);
@@ -98,7 +96,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += b4[q];
       }
-      if (p.out_scale != 0.f && (!qkv || seg_pos == 0)) {
+      if (rms) {
+        const float* w = (seg_pos == 0 ? p.rms_wq : p.rms_wk) + ((n - seg_idx * p.seg) & 63);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= rms_mul * w[q];
+      } else if (p.out_scale != 0.f && (!qkv || seg_pos == 0)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] *= p.out_scale;
       }
@@ -130,9 +132,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
         for (int q = 0; q < 4; ++q) v[q] *= g4[q];
       }
       if (p.residual) {
-        u32x2 r;
-        if constexpr (PRE) r = pre[i][j];
-        else r = *reinterpret_cast<const u32x2*>(p.residual + rrow * p.ldr + n);
+        const u32x2 r = *reinterpret_cast<const u32x2*>(p.residual + rrow * p.ldr + n);
         v[0] += bf16lo_to_f32(r[0]); v[1] += bf16hi_to_f32(r[0]);
         v[2] += bf16lo_to_f32(r[1]); v[3] += bf16hi_to_f32(r[1]);
       }
@@ -236,10 +236,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
     w_seg_grp = w_seg_idx / p.period;
     w_to_vt = (w_seg_idx - w_seg_grp * p.period) == p.period - 1;
   }
-  // output scale of this wave's features (QKV: the q segment only)
-  const float w_scale = (p.out_scale != 0.f && (!qkv || (w_seg_idx - w_seg_grp * p.period) == 0)) ? p.out_scale : 1.0f;
+  // MX_EPI_RMSNORM: heads are normalised in the read-out phase, where 8 consecutive lanes hold one 64-wide head of a token
+  const bool rms = qkv && (flags & MX_EPI_RMSNORM);
+  // output scale of this wave's features (QKV: the q segment only; with RMSNorm it is applied after the normalisation)
+  const float w_scale = (!rms && p.out_scale != 0.f && (!qkv || (w_seg_idx - w_seg_grp * p.period) == 0)) ? p.out_scale : 1.0f;
   // read-out assignment of this thread (the same for every slab): chunk c = tid + 512 k -> slab row, feature chunk, C column
   int ro_row[KC], ro_oc[KC], ro_col[KC];       // ro_col < 0: nothing to do (past the slab, or a V^T column)
+  int ro_rms[KC];                              // MX_EPI_RMSNORM: 0 = q chunk, 1 = k chunk
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
     const int c = tid + 512 * k;
@@ -256,10 +259,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
         const int sg = si / p.period;
         const int sp = si - sg * p.period;
         if (sp != p.period - 1) col = sg * (p.period - 1) * p.seg + sp * p.seg + (n - si * p.seg);
+        ro_rms[k] = sp;
       } else {
         col = n0 + oc * 8;
       }
     }
+    if (!qkv || GEGLU) ro_rms[k] = 0;
     ro_col[k] = col;
   }
   // token, output row and residual row of read-out chunk k in slab j
@@ -365,6 +370,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
       const f32x4 a = *reinterpret_cast<const f32x4*>(sb + r * BNO + (pos << 2));
       const f32x4 b = *reinterpret_cast<const f32x4*>(sb + r * BNO + ((pos ^ 1) << 2));
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      if (rms) {   // the 8 lanes of a head all take this path together (OCH % 8 == 0: a head never straddles rows or masks)
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ss += v[q] * v[q];
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        const float mul = rsqrtf(ss * (1.0f / 64.0f) + p.rms_eps) * ((ro_rms[k] == 0 && p.out_scale != 0.f) ? p.out_scale : 1.0f);
+        const float* w = (ro_rms[k] == 0 ? p.rms_wq : p.rms_wk) + ((ro_oc[k] & 7) << 3);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w), w1 = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] *= mul * w0[q]; v[4 + q] *= mul * w1[q]; }
+      }
       if (has_res) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { v[2 * q] += bf16lo_to_f32(rr[q]); v[2 * q + 1] += bf16hi_to_f32(rr[q]); }

@@ -203,6 +203,7 @@ static int pick_v2_bn(const mx_gemm_desc* d, bool conv) {
     if (bn == 256 && (conv || v3_disabled)) continue;
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;
+    if ((d->flags & MX_EPI_RMSNORM) && bn == 160) continue;   // heads must not straddle read-out rows (gemm_epilogue_staged)
     if (qkv && bn != 256 && d->seg % (bn / 2) != 0) continue;
     const long tiles = (long)cdiv(d->M, 256) * (d->N / bn);
     const double cost = (double)((tiles + 255) / 256) * bn * (bn == 256 ? v3_discount : 1.0);
@@ -226,6 +227,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   a.stride = d->stride; a.up = d->up; a.corner_patch = d->corner_patch;
   a.a_batch_rows = d->a_batch_rows; a.a_row_off = d->a_row_off; a.c_batch_rows = d->c_batch_rows; a.c_row_off = d->c_row_off;
   a.gate = d->gate; a.ldg = d->ldg; a.out_scale = d->out_scale;
+  a.rms_wq = d->rms_wq; a.rms_wk = d->rms_wk; a.rms_eps = d->rms_eps;
   static const int xcd_map = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
   a.xcd_map = xcd_map;
 
@@ -264,6 +266,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(d->M % d->rows_per_batch == 0, "gemm: QKV needs M % rows_per_batch == 0");
     MX_CHECK(d->ldc >= d->N / d->period * (d->period - 1) && d->ldc % 4 == 0, "gemm: bad ldc for QKV");
     MX_CHECK(!(d->flags & MX_EPI_OUT_F32), "gemm: QKV output is bf16");
+    if (d->flags & MX_EPI_RMSNORM)
+      MX_CHECK(d->rms_wq && d->rms_wk && d->period == 3 && d->N % 128 == 0 && !conv, "gemm: RMSNORM needs rms_wq/rms_wk, period 3, N % 128 == 0");
   } else {
     MX_CHECK(d->ldc >= d->N && d->ldc % 4 == 0, "gemm: bad ldc");
   }

@@ -99,13 +99,15 @@ struct Plan {
     d.gate = gate; d.ldg = ldg; d.rows_per_batch = rows_per_batch; d.a_batch_rows = a_batch_rows; d.a_row_off = a_row_off;
     return gemm(d);
   }
-  // fused q|k|v projection of `rows_per_batch` tokens per sample into the joint buffers at row offset `row_off`
-  bool qkv(const void* a, const std::string& name, bf16_t* qk, bf16_t* vt, int ldvt, int M, int d_model, int rows_per_batch,
-           int joint_rows, int row_off) {
+  // fused q|k|v projection of `rows_per_batch` tokens per sample into the joint buffers at row offset `row_off`; the epilogue
+  // RMS-normalises every q / k head (norm_q / norm_k, attention.py:332-346, 377-388) and scales q for mx_attention_prescaled
+  bool qkv(const void* a, const std::string& name, const std::string& qnorm, const std::string& knorm, bf16_t* qk, bf16_t* vt, int ldvt,
+           int M, int d_model, int rows_per_batch, int joint_rows, int row_off) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
     d.a = a; d.lda = d_model; d.w = wb(name + ".weight", (size_t)3 * d_model * d_model); d.bias = wf(name + ".bias", 3 * d_model);
-    d.c = qk; d.ldc = 2 * d_model; d.M = M; d.N = 3 * d_model; d.K = d_model; d.flags = MX_EPI_QKV; d.seg = d_model; d.period = 3;
+    d.c = qk; d.ldc = 2 * d_model; d.M = M; d.N = 3 * d_model; d.K = d_model; d.flags = MX_EPI_QKV | MX_EPI_RMSNORM; d.seg = d_model; d.period = 3;
     d.vt = vt; d.ldvt = ldvt; d.rows_per_batch = rows_per_batch; d.c_batch_rows = joint_rows; d.c_row_off = row_off;
+    d.rms_wq = wf(qnorm, 64); d.rms_wk = wf(knorm, 64); d.rms_eps = u->cfg.norm_eps; d.out_scale = MX_ATTN_QSCALE(0.125f);
     return gemm(d);
   }
   bool lnmod(const bf16_t* x, bf16_t* y, bf16_t* y2, const float* scale, const float* shift, const float* scale2,
@@ -116,18 +118,10 @@ struct Plan {
       return fail(std::string("layernorm_mod: ") + mx_last_error());
     return true;
   }
-  bool rms(bf16_t* x, int ld, int rows_per_batch, int batch_rows, int row_off, int heads, const std::string& qname, const std::string& kname) {
-    if (!ok()) return false;
-    const float* wq = wf(qname, 64); const float* wk = wf(kname, 64);
-    if (!ok() || dry) return ok();
-    if (mx_rmsnorm_heads(stream, x, ld, B, rows_per_batch, batch_rows, row_off, 2 * heads, heads, wq, wk, u->cfg.norm_eps, MX_ATTN_QSCALE(0.125f)))
-      return fail(std::string("rmsnorm_heads: ") + mx_last_error());
-    return true;
-  }
   bool attention(const bf16_t* qk, int d_model, const bf16_t* vt, int ldvt, bf16_t* o, int heads, int L) {
     if (!ok()) return false;
     if (dry) return true;
-    // q carries MX_ATTN_QSCALE(1/8) from the RMSNorm kernel (q_scale)
+    // q carries MX_ATTN_QSCALE(1/8) from the QKV epilogue (RMSNorm + out_scale)
     if (mx_attention_prescaled(stream, qk, 2 * d_model, qk + d_model, 2 * d_model, vt, ldvt, (int64_t)d_model * ldvt, o, d_model, B, heads, L, L))
       return fail(std::string("attention: ") + mx_last_error());
     return true;
@@ -214,16 +208,13 @@ struct Plan {
       if (last) lnmod(ctx, cin, nullptr, mc, mc + d, nullptr, nullptr, ntot, MT, d, Lt);        // continuous: (scale, shift)
       else lnmod(ctx, cin, nullptr, mc + d, mc, nullptr, nullptr, ntot, MT, d, Lt);
       // joint attention (attention.py:256-372): image rows first, then text rows
-      qkv(xin, b + ".attn.to_qkv", qk_j, vt_j, ldvt_j, MI, d, L, Lj, 0);
-      qkv(cin, b + ".attn.add_qkv", qk_j, vt_j, ldvt_j, MT, d, Lt, Lj, L);
-      rms(qk_j, 2 * d, L, Lj, 0, heads, b + ".attn.norm_q.weight", b + ".attn.norm_k.weight");
-      rms(qk_j, 2 * d, Lt, Lj, L, heads, b + ".attn.norm_added_q.weight", b + ".attn.norm_added_k.weight");
+      qkv(xin, b + ".attn.to_qkv", b + ".attn.norm_q.weight", b + ".attn.norm_k.weight", qk_j, vt_j, ldvt_j, MI, d, L, Lj, 0);
+      qkv(cin, b + ".attn.add_qkv", b + ".attn.norm_added_q.weight", b + ".attn.norm_added_k.weight", qk_j, vt_j, ldvt_j, MT, d, Lt, Lj, L);
       attention(qk_j, d, vt_j, ldvt_j, o_j, heads, Lj);
       // x += gate_msa * to_out(attn[:, :L])                                   (transformer.py:344-345)
       linear(o_j, d, b + ".attn.to_out.0", x, d, MI, d, d, 0, x, d, mi + 2 * d, ntot, L, Lj, 0);
       if (dual) {                                                             // attn2: image-only self-attention (:347-357)
-        qkv(x2in, b + ".attn2.to_qkv", qk_i, vt_i, ldvt_i, MI, d, L, 0, 0);
-        rms(qk_i, 2 * d, L, L, 0, heads, b + ".attn2.norm_q.weight", b + ".attn2.norm_k.weight");
+        qkv(x2in, b + ".attn2.to_qkv", b + ".attn2.norm_q.weight", b + ".attn2.norm_k.weight", qk_i, vt_i, ldvt_i, MI, d, L, 0, 0);
         attention(qk_i, d, vt_i, ldvt_i, o_i, heads, L);
         linear(o_i, d, b + ".attn2.to_out.0", x, d, MI, d, d, 0, x, d, mi + 8 * d, ntot, L);
       }

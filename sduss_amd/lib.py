@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmxdenoise.so")
 
 MX_F32, MX_F16, MX_BF16 = 0, 1, 2
-EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV, EPI_GELU_TANH, EPI_RES_BCAST = 1, 2, 4, 8, 16, 32
+EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV, EPI_GELU_TANH, EPI_RES_BCAST, EPI_RMSNORM = 1, 2, 4, 8, 16, 32, 64
 
 
 class MxError(RuntimeError):
@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("corner_patch", C.c_int),
         ("a_batch_rows", C.c_int), ("a_row_off", C.c_int), ("c_batch_rows", C.c_int), ("c_row_off", C.c_int),
-        ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float),
+        ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float),
     ]
 
 

@@ -326,3 +326,29 @@ def test_large_tile_joint_rows(cuda_device, li, lt, dm):
                    flags=lib.EPI_RES_BCAST)
     lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
     _close(out, (qkc[:, :li] @ w2.t() + pos).reshape(b * li, 256), 2.0 ** -7, "input row remap + broadcast residual")
+
+
+@pytest.mark.parametrize("rows,dm,k", [(64, 128, 128), (333, 256, 192), (8192, 1536, 128)])
+def test_gemm_qkv_fused_rmsnorm(cuda_device, rows, dm, k):
+    """MX_EPI_QKV | MX_EPI_RMSNORM: q and k heads RMS-normalised (norm_q / norm_k, attention.py:332-346) and q scaled, V^T
+    untouched -- on the generic kernel (small M) and on the 256-row kernels (staged epilogue)."""
+    from sduss_amd import lib, ops
+    l = lib.load()
+    g = torch.Generator().manual_seed(rows + dm)
+    b = 2 if rows > 1000 else 3
+    a = _rt(torch.randn(b * rows, k, generator=g)); w = _rt(torch.randn(3 * dm, k, generator=g) * k ** -0.5); bias = torch.randn(3 * dm, generator=g)
+    wq = 1 + 0.2 * torch.randn(64, generator=g); wk = 1 + 0.2 * torch.randn(64, generator=g)
+    ag, wg, bg, wqg, wkg = _bf(a).cuda(), _bf(w).cuda(), bias.cuda(), wq.cuda(), wk.cuda()
+    ldvt = ops.vt_ld(rows)
+    qk = torch.zeros(b * rows, 2 * dm, dtype=torch.bfloat16, device="cuda")
+    vt = torch.zeros(b, dm, ldvt, dtype=torch.bfloat16, device="cuda")
+    d = _gemm_desc(lib, ag, wg, qk, bias=bg, vt=vt, flags=lib.EPI_QKV | lib.EPI_RMSNORM, seg=dm, period=3, ldvt=ldvt, rows_per_batch=rows,
+                   rms_wq=wqg, rms_wk=wkg, rms_eps=1e-6, out_scale=0.18)
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)))
+    full = (a @ w.t() + bias).reshape(b * rows, 3, dm // 64, 64)
+
+    def rms(x, wgt):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * wgt
+    want = torch.cat([(rms(full[:, 0], wq) * 0.18).reshape(b * rows, dm), rms(full[:, 1], wk).reshape(b * rows, dm)], dim=1)
+    _close(qk, want, 2.0 ** -7, "fused rmsnorm q|k")
+    _close(ops.unpack_vt(vt.float().cpu(), rows), full[:, 2].reshape(b, rows, dm), 2.0 ** -7, "fused rmsnorm leaves V alone")
