@@ -145,3 +145,37 @@ def test_unet_graph_replay_follows_buffer_contents(tiny):
     assert torch.equal(outs[2], outs[3])
     assert not torch.equal(outs[1], outs[2]), "replay ignored the new buffer contents"
     _check(outs[2], ref.unet_forward(P, ocfg, s2.to(torch.bfloat16).float(), t, e, te, ti), "graph replay with new contents")
+
+
+def test_graph_replay_path_in_subprocess(cuda_device):
+    """MX_GRAPH is read once per process, so the opt-in hipGraph replay path (graph_cache.h) is exercised in a child process:
+    same tensors four times (capture + three replays, new contents before the third call) must behave like the eager path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import sdxl_unet_ref as ref
+from sduss_amd.config import UNetConfig
+from sduss_amd.unet import MxUNet
+ocfg = ref.UNetConfig.tiny(); P = ref.init_params(ocfg)
+net = MxUNet(UNetConfig.tiny(), P, device="cuda:0")
+s1, t, e, te, ti = ref.make_inputs(ocfg, 2, 32, seed=5); s2 = ref.make_inputs(ocfg, 2, 32, seed=6)[0]
+sg, tg, eg, teg, tig = s1.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda()
+outs = []
+for k in range(4):
+    if k == 2: sg.copy_(s2.to(torch.bfloat16))
+    outs.append(net.forward_one(sg, tg, eg, teg, tig).float().cpu())
+want = ref.unet_forward(P, ocfg, s2.to(torch.bfloat16).float(), t, e, te, ti)
+err = (outs[3] - want).abs().max().item() / want.abs().max().item()
+assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3]) and not torch.equal(outs[1], outs[2]), "replay mismatch"
+assert err < 0.04, err
+del net
+print("GRAPH_OK", err)
+''' % root
+    env = dict(os.environ, MX_GRAPH="1", MX_GRAPH_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "replays 3 captures 1" in r.stderr, "the graph path did not replay: " + r.stderr[-500:]
