@@ -63,6 +63,8 @@ class SDXLDenoiser:
         self.unet = unet
         self.guidance_scale = guidance_scale   # reference default (pipeline_..._esymred.py:265)
         self._tables: Dict[int, tuple] = {}
+        self.concurrent_resolutions = True
+        self._streams: List[torch.cuda.Stream] = []
 
     def set_timesteps(self, req: Request) -> None:
         if req.num_inference_steps not in self._tables:
@@ -78,40 +80,64 @@ class SDXLDenoiser:
     @torch.inference_mode()
     def denoising_step(self, worker_reqs: Dict[str, List[Request]], do_classifier_free_guidance: bool = True,
                        is_sliced: bool = False, patch_size: int = 256) -> None:
-        """One timestep for every request in ``worker_reqs`` ({str(res): [requests]}), in place."""
-        res_list = sorted(worker_reqs.keys(), key=lambda r: int(r))         # :275-276
+        """One timestep for every request in ``worker_reqs`` ({str(res): [requests]}), in place.
+
+        The reference runs the resolutions of a mixed batch as one patch batch; here each resolution is its own launch
+        sequence, and with more than one resolution present the sequences are issued on separate streams: a small batch
+        (one 512-1024 px request fills about a quarter of the CUs) leaves room for the other sequences to run beside it.
+        The caller's stream waits for all of them; ``self.concurrent_resolutions = False`` serialises them."""
+        res_list = [r for r in sorted(worker_reqs.keys(), key=lambda r: int(r)) if worker_reqs[r]]       # :275-276
+        if len(res_list) <= 1 or not self.concurrent_resolutions:
+            for res in res_list:
+                self._step_resolution(res, worker_reqs[res], do_classifier_free_guidance, is_sliced, patch_size)
+            return
+        cur = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        while len(self._streams) < len(res_list):
+            self._streams.append(torch.cuda.Stream(device=self.unet.device))
+        for i, res in enumerate(res_list):
+            side = self._streams[i]
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                self._step_resolution(res, worker_reqs[res], do_classifier_free_guidance, is_sliced, patch_size)
+            join = torch.cuda.Event()
+            join.record(side)
+            cur.wait_event(join)
+
+    def _step_resolution(self, res: str, reqs: List[Request], do_classifier_free_guidance: bool, is_sliced: bool,
+                         patch_size: int) -> None:
         dev = self.unet.device
-        for res in res_list:                                                 # one launch sequence per resolution
-            reqs = worker_reqs[res]
-            if not reqs:
-                continue
-            n = len(reqs)
-            lat = torch.cat([r.latents for r in reqs], dim=0).contiguous()   # :287-312
-            sig = torch.tensor([float(r.sigmas[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
-            sig_next = torch.tensor([float(r.sigmas[r.step_index + 1]) for r in reqs], dtype=torch.float32, device=dev)
-            ts = torch.tensor([float(r.timesteps[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
-            if do_classifier_free_guidance:                                  # :322-339 row order [uncond..., cond...]
-                ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
-                pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
-                # add_time_ids are interleaved neg/pos per request in the reference (:302-305)
-                tids = torch.cat([t for r in reqs for t in (r.negative_add_time_ids, r.add_time_ids)], dim=0)
-                ts2 = torch.cat([ts, ts], dim=0)
-                rows = 2 * n
-            else:
-                ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
-                pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
-                tids = torch.cat([r.add_time_ids for r in reqs], dim=0)
-                ts2 = ts
-                rows = n
-            x_in = ops.euler_scale_input(lat, sig, rows)                     # :357-360 (+ the cat of :327)
-            noise = self.unet.forward({res: x_in}, ts2, ehs, added_cond_kwargs={"text_embeds": pooled, "time_ids": tids},
-                                      return_dict=False, is_sliced=is_sliced, patch_size=patch_size,
-                                      input_indices={res: [str(r.request_id) for r in reqs]})[0][res]   # :369-380
-            g = self.guidance_scale if do_classifier_free_guidance else 0.0
-            ops.cfg_euler_step_(noise, lat, sig, sig_next, g)                # :382-397
-            for i, r in enumerate(reqs):                                     # :399-403
-                r.step_index += 1
-                r.latents = lat[i:i + 1]
+        n = len(reqs)
+        here = torch.cuda.current_stream()
+        for r in reqs:                                                   # latents may have been produced on another stream
+            r.latents.record_stream(here)
+        lat = torch.cat([r.latents for r in reqs], dim=0).contiguous()   # :287-312
+        sig = torch.tensor([float(r.sigmas[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
+        sig_next = torch.tensor([float(r.sigmas[r.step_index + 1]) for r in reqs], dtype=torch.float32, device=dev)
+        ts = torch.tensor([float(r.timesteps[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
+        if do_classifier_free_guidance:                                  # :322-339 row order [uncond..., cond...]
+            ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
+            pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+            # add_time_ids are interleaved neg/pos per request in the reference (:302-305)
+            tids = torch.cat([t for r in reqs for t in (r.negative_add_time_ids, r.add_time_ids)], dim=0)
+            ts2 = torch.cat([ts, ts], dim=0)
+            rows = 2 * n
+        else:
+            ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
+            pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
+            tids = torch.cat([r.add_time_ids for r in reqs], dim=0)
+            ts2 = ts
+            rows = n
+        x_in = ops.euler_scale_input(lat, sig, rows)                     # :357-360 (+ the cat of :327)
+        noise = self.unet.forward({res: x_in}, ts2, ehs, added_cond_kwargs={"text_embeds": pooled, "time_ids": tids},
+                                  return_dict=False, is_sliced=is_sliced, patch_size=patch_size,
+                                  input_indices={res: [str(r.request_id) for r in reqs]})[0][res]   # :369-380
+        g = self.guidance_scale if do_classifier_free_guidance else 0.0
+        ops.cfg_euler_step_(noise, lat, sig, sig_next, g)                # :382-397
+        for i, r in enumerate(reqs):                                     # :399-403
+            r.step_index += 1
+            r.latents = lat[i:i + 1]
 
 
 def synthetic_request(rid: int, resolution: int, steps: int, cfg, denoiser: SDXLDenoiser, device, dtype=torch.bfloat16,

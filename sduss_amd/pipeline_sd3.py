@@ -53,6 +53,8 @@ class SD3Denoiser:
         self.transformer = transformer
         self.guidance_scale = guidance_scale     # reference default (pipeline_stable_diffusion_3_esymred.py:236)
         self._tables: Dict[int, tuple] = {}
+        self.concurrent_resolutions = True
+        self._streams: List[torch.cuda.Stream] = []
 
     def set_timesteps(self, req: SD3Request) -> None:
         if req.num_inference_steps not in self._tables:
@@ -63,32 +65,54 @@ class SD3Denoiser:
     @torch.inference_mode()
     def denoising_step(self, runner_reqs: Dict[str, List[SD3Request]], do_classifier_free_guidance: bool = True,
                        is_sliced: bool = False, patch_size: int = 256) -> None:
+        """One timestep for every request, in place; the resolutions of a mixed batch run on separate streams (see
+        SDXLDenoiser.denoising_step)."""
+        res_list = [r for r in sorted(runner_reqs.keys(), key=lambda r: int(r)) if runner_reqs[r]]           # :240-241
+        if len(res_list) <= 1 or not self.concurrent_resolutions:
+            for res in res_list:
+                self._step_resolution(res, runner_reqs[res], do_classifier_free_guidance, is_sliced, patch_size)
+            return
+        cur = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        while len(self._streams) < len(res_list):
+            self._streams.append(torch.cuda.Stream(device=self.transformer.device))
+        for i, res in enumerate(res_list):
+            side = self._streams[i]
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                self._step_resolution(res, runner_reqs[res], do_classifier_free_guidance, is_sliced, patch_size)
+            join = torch.cuda.Event()
+            join.record(side)
+            cur.wait_event(join)
+
+    def _step_resolution(self, res: str, reqs: List[SD3Request], do_classifier_free_guidance: bool, is_sliced: bool,
+                         patch_size: int) -> None:
         dev = self.transformer.device
-        for res in sorted(runner_reqs.keys(), key=lambda r: int(r)):            # :240-241
-            reqs = runner_reqs[res]
-            if not reqs:
-                continue
-            n = len(reqs)
-            lat = torch.cat([r.latents for r in reqs], dim=0).contiguous()
-            sig = torch.tensor([float(r.sigmas[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
-            sig_next = torch.tensor([float(r.sigmas[r.step_index + 1]) for r in reqs], dtype=torch.float32, device=dev)
-            ts = torch.tensor([float(r.timesteps[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
-            if do_classifier_free_guidance:                                      # :281-292 rows [uncond..., cond...]
-                ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
-                pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
-                ts2 = torch.cat([ts, ts], dim=0)
-                x_in = ops.euler_scale_input(lat, torch.zeros_like(sig), 2 * n)  # exact x/1 copy == torch.cat([latents] * 2)
-            else:
-                ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
-                pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
-                ts2, x_in = ts, lat
-            noise = self.transformer.forward({res: x_in}, encoder_hidden_states=ehs, pooled_projections=pooled, timestep=ts2,
-                                             return_dict=False, is_sliced=is_sliced, patch_size=patch_size,
-                                             input_indices={res: [str(r.request_id) for r in reqs]})[0][res]   # :312-322
-            ops.cfg_flow_step_(noise, lat, sig, sig_next, self.guidance_scale if do_classifier_free_guidance else 0.0)  # :362-372
-            for i, r in enumerate(reqs):
-                r.step_index += 1
-                r.latents = lat[i:i + 1]
+        n = len(reqs)
+        here = torch.cuda.current_stream()
+        for r in reqs:                                                   # latents may have been produced on another stream
+            r.latents.record_stream(here)
+        lat = torch.cat([r.latents for r in reqs], dim=0).contiguous()
+        sig = torch.tensor([float(r.sigmas[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
+        sig_next = torch.tensor([float(r.sigmas[r.step_index + 1]) for r in reqs], dtype=torch.float32, device=dev)
+        ts = torch.tensor([float(r.timesteps[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
+        if do_classifier_free_guidance:                                      # :281-292 rows [uncond..., cond...]
+            ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
+            pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+            ts2 = torch.cat([ts, ts], dim=0)
+            x_in = ops.euler_scale_input(lat, torch.zeros_like(sig), 2 * n)  # exact x/1 copy == torch.cat([latents] * 2)
+        else:
+            ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
+            pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
+            ts2, x_in = ts, lat
+        noise = self.transformer.forward({res: x_in}, encoder_hidden_states=ehs, pooled_projections=pooled, timestep=ts2,
+                                         return_dict=False, is_sliced=is_sliced, patch_size=patch_size,
+                                         input_indices={res: [str(r.request_id) for r in reqs]})[0][res]   # :312-322
+        ops.cfg_flow_step_(noise, lat, sig, sig_next, self.guidance_scale if do_classifier_free_guidance else 0.0)  # :362-372
+        for i, r in enumerate(reqs):
+            r.step_index += 1
+            r.latents = lat[i:i + 1]
 
 
 def synthetic_sd3_request(rid: int, resolution: int, steps: int, cfg, denoiser: SD3Denoiser, device, dtype=torch.bfloat16,

@@ -39,7 +39,8 @@ class MxSD3Transformer:
         self.weights = PackedWeights(pack_mmdit(cfg, params), self.device)
         _lib.check(self._lib.mx_mmdit_set_weights(self._handle, self.weights.blob.data_ptr(), self.weights.blob.numel(),
                                                   self.weights.table, len(self.weights.names)), "mx_mmdit_set_weights")
-        self._ws: Optional[torch.Tensor] = None
+        self._ws_by_stream = {}
+        self._ws_need = {}
         self.config = _Config(in_channels=cfg.in_channels, patch_size=cfg.patch_size, sample_size=cfg.sample_size,
                               joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim)
 
@@ -66,24 +67,29 @@ class MxSD3Transformer:
         pp = pooled.to(device=self.device, dtype=torch.bfloat16).contiguous()
         assert ts.shape[0] == b and ehs.shape[0] == b and pp.shape == (b, self.cfg.pooled_projection_dim)
         assert ehs.shape[2] == self.cfg.joint_attention_dim
-        need = self._lib.mx_mmdit_workspace_bytes(self._handle, b, h, w, lt)
+        key = (b, h, w, lt)
+        need = self._ws_need.get(key)
+        if need is None:                      # a dry run of the whole plan: once per shape
+            need = self._ws_need[key] = self._lib.mx_mmdit_workspace_bytes(self._handle, b, h, w, lt)
         if need == 0:
             raise _lib.MxError("mx_mmdit_workspace_bytes: " + self._lib.mx_last_error().decode())
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        out = torch.empty((b, self.cfg.out_channels, h, w), dtype=latents.dtype, device=self.device)
         code = _lib.torch_dtype_code(latents.dtype)
         stream = _lib.current_stream()
+        skey = int(stream or 0)               # one grow-only arena per stream (pipeline_sd3.py overlaps resolutions)
+        ws = self._ws_by_stream.get(skey)
+        if ws is None or ws.numel() < need:
+            self._ws_by_stream[skey] = None
+            ws = self._ws_by_stream[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((b, self.cfg.out_channels, h, w), dtype=latents.dtype, device=self.device)
         if stage is None:
             _lib.check(self._lib.mx_mmdit_forward(self._handle, stream, latents.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
-                                                  pp.data_ptr(), out.data_ptr(), b, h, w, lt, self._ws.data_ptr(),
-                                                  self._ws.numel()), "mx_mmdit_forward")
+                                                  pp.data_ptr(), out.data_ptr(), b, h, w, lt, ws.data_ptr(),
+                                                  ws.numel()), "mx_mmdit_forward")
             return out
         st = torch.empty(stage_shape, dtype=torch.bfloat16, device=self.device)
         _lib.check(self._lib.mx_mmdit_forward_trace(self._handle, stream, latents.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
-                                                    pp.data_ptr(), out.data_ptr(), b, h, w, lt, self._ws.data_ptr(),
-                                                    self._ws.numel(), stage.encode(), st.data_ptr(), st.numel() * 2),
+                                                    pp.data_ptr(), out.data_ptr(), b, h, w, lt, ws.data_ptr(),
+                                                    ws.numel(), stage.encode(), st.data_ptr(), st.numel() * 2),
                    "mx_mmdit_forward_trace")
         return st
 

@@ -55,7 +55,7 @@ class MxUNet:
         self.weights = PackedWeights(pack(cfg, params), self.device)
         _lib.check(self._lib.mx_unet_set_weights(self._handle, self.weights.blob.data_ptr(), self.weights.blob.numel(),
                                                  self.weights.table, len(self.weights.names)), "mx_unet_set_weights")
-        self._ws: Optional[torch.Tensor] = None
+        self._ws_by_stream: Dict[int, Optional[torch.Tensor]] = {}
         self._ws_need = {}
         self.config = _Config(in_channels=cfg.in_channels, time_cond_proj_dim=None,
                               addition_time_embed_dim=cfg.addition_time_embed_dim,
@@ -72,17 +72,20 @@ class MxUNet:
         return self
 
     # -------------------------------------------------------------------------------------------------
-    def _workspace(self, batch: int, h: int, w: int, ctx_len: int) -> torch.Tensor:
+    def _workspace(self, batch: int, h: int, w: int, ctx_len: int, stream: int) -> torch.Tensor:
+        """grow-only arena, one per stream: launch sequences issued on different streams (pipeline.py runs the resolutions
+        of a mixed batch concurrently) must not share scratch"""
         key = (batch, h, w, ctx_len)
         need = self._ws_need.get(key)
         if need is None:                      # a dry run of the whole plan: once per shape
             need = self._ws_need[key] = self._lib.mx_unet_workspace_bytes(self._handle, batch, h, w, ctx_len)
         if need == 0:
             raise _lib.MxError("mx_unet_workspace_bytes: " + self._lib.mx_last_error().decode())
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        ws = self._ws_by_stream.get(stream)
+        if ws is None or ws.numel() < need:
+            self._ws_by_stream[stream] = None
+            ws = self._ws_by_stream[stream] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def forward_one(self, sample: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                     text_embeds: torch.Tensor, time_ids: torch.Tensor, gn_patch: int = 0,
@@ -102,9 +105,9 @@ class MxUNet:
         assert ts.shape[0] == b and ehs.shape[0] == b and te.shape[0] == b and ti.shape == (b, 6)
         assert ehs.shape[2] == self.cfg.cross_attention_dim and te.shape[1] == self.cfg.text_embed_dim
         out = torch.empty((b, self.cfg.out_channels, h, w), dtype=sample.dtype, device=self.device)
-        ws = self._workspace(b, h, w, ctx_len)
         code = _lib.torch_dtype_code(sample.dtype)
         stream = _lib.current_stream()
+        ws = self._workspace(b, h, w, ctx_len, int(stream or 0))
         if stage is None:
             _lib.check(self._lib.mx_unet_forward(self._handle, stream, sample.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
                                                  te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, h, w, ctx_len, gn_patch,

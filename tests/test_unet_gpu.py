@@ -179,3 +179,27 @@ print("GRAPH_OK", err)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "replays 3 captures 1" in r.stderr, "the graph path did not replay: " + r.stderr[-500:]
+
+
+def test_denoising_step_mixed_resolutions_concurrent_equals_serial(tiny):
+    """resolutions of a mixed batch run on separate streams (pipeline.py): the result must be bit-identical to running them one
+    after the other, over several steps (latents produced on one stream are consumed on another at the next step)."""
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.pipeline import SDXLDenoiser, synthetic_request
+    ocfg, P, net = tiny
+    cfg = UNetConfig.tiny()
+    outs = []
+    for concurrent in (False, True):
+        den = SDXLDenoiser(net, guidance_scale=5.0)
+        den.concurrent_resolutions = concurrent
+        reqs = {"128": [synthetic_request(0, 128, 6, cfg, den, "cuda:0")],
+                "256": [synthetic_request(1, 256, 6, cfg, den, "cuda:0"), synthetic_request(2, 256, 6, cfg, den, "cuda:0")],
+                "384": [synthetic_request(3, 384, 6, cfg, den, "cuda:0")]}
+        for step in range(4):
+            if step == 2:                       # change the set of resolutions -> streams are re-assigned
+                reqs = {k: v for k, v in reqs.items() if k != "128"}
+            den.denoising_step(reqs, is_sliced=True, patch_size=128)
+        torch.cuda.synchronize()
+        outs.append({k: torch.cat([r.latents for r in v]).float().cpu() for k, v in reqs.items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), f"concurrent != serial at {k}"
