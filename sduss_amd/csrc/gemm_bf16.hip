@@ -176,38 +176,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   gemm_epilogue<NI, MI, BN>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), fr, fq);
 }
 
-int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn);
+int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
 int launch_v3(hipStream_t s, const GemmArgs& a);
 
-// Tile choice for the pipelined 256-row kernels: the feature tile (256, 160 or 128) with the lowest estimated cost =
-// full-chip rounds of 256 workgroups (one per CU) x tile width, the 256-wide tile (gemm_bf16_v3.hip) discounted by its
-// measured per-FLOP advantage; 0 = use the generic 128-row kernel.
-static int pick_v2_bn(const mx_gemm_desc* d, bool conv) {
+// Tile choice for the pipelined kernels.  Candidates (token rows x features): 256x256 (gemm_bf16_v3.hip), 256x160, 256x128,
+// 128x160, 128x128 (gemm_bf16_v2.hip).  Estimated cost = full-chip rounds of 256 workgroups (one per CU) x (rows + features):
+// the K loop of a tile is held by the CU's L2 -> LDS fetch stream, whose bytes per K tile are (rows + features) * 128.  A small
+// problem therefore prefers small tiles (more CUs fetch in parallel: one 1024 px request gives M = 2048), a chip-filling one
+// the tiling with the fewest rounds and the largest tile (fewest bytes per FLOP; the 256x256 kernel is further discounted by
+// its measured advantage).  rows == 0: use the generic 128-row kernel.
+struct TileChoice { int bn; int rows; };
+static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   static const bool disabled = [] { const char* e = getenv("MX_GEMM_V2"); return e && e[0] == '0'; }();
   static const bool v3_disabled = [] { const char* e = getenv("MX_GEMM_V3"); return e && e[0] == '0'; }();
+  static const bool small_disabled = [] { const char* e = getenv("MX_GEMM_ROWS128"); return e && e[0] == '0'; }();
   static const double v3_discount = [] { const char* e = getenv("MX_V3_DISCOUNT"); return e ? atof(e) : 0.87; }();
-  if (disabled || d->M < 256 || d->K < 128) return 0;
-  // the pipelined kernels address their operands with 32-bit byte offsets from a uniform base
-  const long in_rows = d->a_batch_rows > 0 ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
-  if (in_rows * d->lda * 2 >= (1L << 32) || (long)d->N * d->K * 2 >= (1L << 32)) return 0;
+  const TileChoice none = {0, 0};
+  if (disabled || d->M < 128 || d->K < 128) return none;
   // their LDS-staged epilogue moves 16-byte pieces of C and of the residual
-  if (d->ldc % 8 != 0 || ((uintptr_t)d->c & 15) != 0) return 0;
-  if (d->residual && (d->ldr % 8 != 0 || ((uintptr_t)d->residual & 15) != 0)) return 0;
+  if (d->ldc % 8 != 0 || ((uintptr_t)d->c & 15) != 0) return none;
+  if (d->residual && (d->ldr % 8 != 0 || ((uintptr_t)d->residual & 15) != 0)) return none;
   const bool geglu = (d->flags & MX_EPI_GEGLU) != 0, qkv = (d->flags & MX_EPI_QKV) != 0;
-  int best = 0;
+  TileChoice best = none;
   double best_cost = 0;
-  const int cands[3] = {256, 160, 128};
-  for (int c = 0; c < 3; ++c) {
-    const int bn = cands[c];
-    if (d->N % bn != 0) continue;
+  const TileChoice cands[5] = {{256, 256}, {160, 256}, {128, 256}, {160, 128}, {128, 128}};
+  for (int c = 0; c < 5; ++c) {
+    const int bn = cands[c].bn, rows = cands[c].rows;
+    if (d->N % bn != 0 || d->M < rows) continue;
     if (bn == 256 && (conv || v3_disabled)) continue;
+    if (rows == 128 && small_disabled) continue;
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;
     if ((d->flags & MX_EPI_RMSNORM) && bn == 160) continue;   // heads must not straddle read-out rows (gemm_epilogue_staged)
     if (qkv && bn != 256 && d->seg % (bn / 2) != 0) continue;
-    const long tiles = (long)cdiv(d->M, 256) * (d->N / bn);
-    const double cost = (double)((tiles + 255) / 256) * bn * (bn == 256 ? v3_discount : 1.0);
-    if (best == 0 || cost < best_cost) { best = bn; best_cost = cost; }
+    const long tiles = (long)cdiv(d->M, rows) * (d->N / bn);
+    const double cost = (double)((tiles + 255) / 256) * (rows + bn) * (bn == 256 ? v3_discount : 1.0);
+    if (best.rows == 0 || cost < best_cost) { best = cands[c]; best_cost = cost; }
   }
   return best;
 }
@@ -255,7 +259,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   }
   if (d->residual) MX_CHECK(d->ldr >= d->N && d->ldr % 4 == 0, "gemm: bad ldr");
   const bool use128 = (d->N % 128 == 0);
-  const int v2bn = pick_v2_bn(d, conv);
+  const TileChoice tc = pick_tile(d, conv);
+  const int v2bn = tc.bn;
   if (d->flags & MX_EPI_GEGLU) {
     MX_CHECK(use128, "gemm: GEGLU needs N % 128 == 0");
     MX_CHECK(!(d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32)) && !d->residual && !d->rowbias && d->out_scale == 0.f, "gemm: GEGLU excludes other epilogues");
@@ -285,7 +290,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   if (v2bn == 256) {
     launch_v3(s, a);
   } else if (v2bn) {
-    launch_v2(s, a, conv, v2bn);
+    launch_v2(s, a, conv, v2bn, tc.rows);
   } else if (use128) {
     dim3 grid(cdiv(d->M, BM), d->N / 128);
     if (conv) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, block, 0, s, a);

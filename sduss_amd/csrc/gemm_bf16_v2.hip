@@ -35,7 +35,6 @@ namespace mx {
 constexpr int kZeroPageBytes = 16384;
 __device__ __attribute__((aligned(64))) unsigned int g_zero_page[kZeroPageBytes / 4] = {0};
 
-constexpr int BM2 = 256;
 constexpr int BK2 = 64;
 constexpr int NSTAGE = 3;
 
@@ -46,12 +45,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int BN, bool CONV>
+template <int BN, int MI, bool CONV>      // MI: 16-wide token blocks per wave; tile rows BM2 = 64 * MI (256, or 128 for small M)
 __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
+  constexpr int BM2 = 64 * MI;
   constexpr int NI = BN / 32;                 // 16-wide feature blocks per wave (wave covers BN/2 features)
-  constexpr int MI = 4;                       // 16-wide token blocks per wave (wave covers 64 tokens)
   constexpr int WCH = BN * 8;                 // 16-byte chunks of the W tile
-  constexpr int XI = BM2 * 8 / 512;           // X load instructions per thread per tile (4)
+  constexpr int XI = BM2 * 8 / 512;           // X load instructions per thread per tile (4, or 2 for the 128-row tile)
   constexpr int WI = (WCH + 511) / 512;       // W load instructions per thread per tile (3 for BN=160, 2 for 128)
   constexpr int LOADS = XI + WI;              // per-thread DMA instructions per K tile
   constexpr int STAGE_ELEMS = (BM2 + BN) * BK2;
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int row = wm * 64 + j * 16 + fr;
+      const int row = wm * 16 * MI + j * 16 + fr;
       xf[j] = *reinterpret_cast<const bf16x8*>(&sx[row * BK2 + swz2(row, ks * 4 + fq) * 8]);
     }
   };
@@ -221,7 +220,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
       // all but the youngest DMA group (and anything younger) of this thread has completed => stream position g landed
       if constexpr (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (LOADS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      static_assert(LOADS >= 4 && LOADS <= 7, "counted wait");
       __builtin_amdgcn_s_barrier();
       bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
 #if MX_EXP == 3
@@ -290,16 +292,18 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   }
 }
 
-int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn) {
-  const int tiles = cdiv(a.M, BM2) * (a.N / bn);
+// bn: 160 or 128 features per tile; rows: 256, or 128 when the 256-row tiling would leave most CUs idle (small M)
+int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows) {
+  const int tiles = cdiv(a.M, rows) * (a.N / bn);
   dim3 grid(tiles), block(512);
-  if (bn == 160) {
-    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<160, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_v2_kernel<160, false>), grid, block, 0, s, a);
-  } else {
-    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<128, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_v2_kernel<128, false>), grid, block, 0, s, a);
-  }
+#define MX_V2(BN_, MI_) \
+  do { \
+    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<BN_, MI_, true>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((gemm_v2_kernel<BN_, MI_, false>), grid, block, 0, s, a); \
+  } while (0)
+  if (bn == 160) { if (rows == 256) MX_V2(160, 4); else MX_V2(160, 2); }
+  else { if (rows == 256) MX_V2(128, 4); else MX_V2(128, 2); }
+#undef MX_V2
   return 0;
 }
 

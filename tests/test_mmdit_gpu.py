@@ -254,7 +254,8 @@ def _kinds_launched(fn):
     return {k: int(buf[4 * k]) for k in range(11) if buf[4 * k] > 0}
 
 
-@pytest.mark.parametrize("rows,n,k,kinds", [(1024, 1600, 128, {6}), (1024, 640, 192, {6, 8}), (8192, 1536, 128, {10}), (1000, 1024, 128, {8, 10})])
+@pytest.mark.parametrize("rows,n,k,kinds", [(1024, 1600, 128, {6}), (1024, 640, 192, {6, 8}), (8192, 1536, 128, {10}), (1000, 1024, 128, {8, 10}),
+                                             (256, 1600, 128, {6}), (250, 1024, 192, {8})])   # the last two: 128-row tiles (small M)
 def test_large_tile_gemm_gate_residual_rowbias_gelu(cuda_device, rows, n, k, kinds):
     """gated residual (AdaLN-Zero), per-sample row bias (time embedding), GELU-tanh and fp32 output through the staged
     epilogue, incl. a rows_per_batch that is not a multiple of the tile and a row stride wider than N."""
