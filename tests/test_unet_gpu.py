@@ -203,3 +203,29 @@ def test_denoising_step_mixed_resolutions_concurrent_equals_serial(tiny):
         outs.append({k: torch.cat([r.latents for r in v]).float().cpu() for k, v in reqs.items()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), f"concurrent != serial at {k}"
+
+
+def test_plumbing_config0_four_steps_512(tiny):
+    """BASELINE configs[0] (the reference's CPU-runnable plumbing case): one prompt, 4 denoising steps at 512 x 512 (latent
+    64 x 64, UNet batch 2 under CFG) -- the whole loop (scale -> UNet -> CFG combine -> Euler) against the oracle chain, tiny
+    SDXL-topology weights.  Four chained forwards with guidance 5: max error <= 10 % of range, relative L2 <= 6 %."""
+    from oracle import scheduler_ref
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.pipeline import SDXLDenoiser, synthetic_request
+    ocfg, P, net = tiny
+    cfg = UNetConfig.tiny()
+    den = SDXLDenoiser(net, guidance_scale=5.0)
+    req = synthetic_request(0, 512, 4, cfg, den, "cuda:0", dtype=torch.bfloat16)
+    lat = req.latents.float().cpu()
+    pe, ne = req.prompt_embeds.float().cpu(), req.negative_prompt_embeds.float().cpu()
+    pp, npp = req.pooled_prompt_embeds.float().cpu(), req.negative_pooled_prompt_embeds.float().cpu()
+    tid = req.add_time_ids.float().cpu()
+    ts, sig, _ = scheduler_ref.sdxl_euler_tables(4)
+    for step in range(4):
+        den.denoising_step({"512": [req]})
+        x2 = scheduler_ref.scale_model_input(torch.cat([lat, lat]), sig[[step] * 2])
+        noise = ref.unet_forward(P, ocfg, x2, ts[[step] * 2], torch.cat([ne, pe]), torch.cat([npp, pp]), tid.repeat(2, 1))
+        lat = scheduler_ref.euler_step(scheduler_ref.cfg_combine(noise, 5.0), lat, sig[[step]], sig[[step + 1]])
+        lat = lat.to(torch.bfloat16).float()
+    assert req.done()
+    _check(req.latents, lat, "config0 plumbing: 4 steps at 512x512", max_rel=0.10, l2_rel=0.06)
