@@ -208,17 +208,17 @@ __device__ __forceinline__ void gemm_tile_of_block(const int b, const int mt, co
 //   * order of operations as gemm_epilogue: bias -> GEGLU -> row bias -> gate (accumulator layout, before staging),
 //     residual -> SiLU / GELU-tanh -> convert -> store (row layout, after staging);
 //   * MX_EPI_QKV: q|k segments are staged; waves whose 64 features fall in a V segment write V^T directly as before.
-// The caller guarantees that `slab` (2 * 16*WM * BNO floats of LDS) is not being written by any DMA.
+// The caller guarantees that `slab0` / `slab1` (16*WM * BNO floats of LDS each) are not being written by any DMA.
 // ----------------------------------------------------------------------------------------------------------------------
-template <int NI, int MI, int WM, int WN, bool GEGLU>
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&acc)[NI][MI], float* slab, const int m0,
+// VEC: per-sample vectors (row bias, gate) supported; false compiles their registers out (32 VGPRs) for kernels that need the room
+template <int NI, int MI, int WM, int WN, bool GEGLU, bool VEC = true>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&acc)[NI][MI], float* slab0, float* slab1, const int m0,
                                                      const int n0, const int wm, const int wn, const int fr, const int fq,
                                                      const int tid) {
   constexpr int BN = 16 * NI * WN;             // block features
   constexpr int NIO = GEGLU ? NI / 2 : NI;     // staged 16-feature blocks per wave
   constexpr int BNO = GEGLU ? BN / 2 : BN;     // staged features per slab row
   constexpr int ROWS = 16 * WM;                // tokens per slab
-  constexpr int SLAB = ROWS * BNO;             // floats per slab buffer
   constexpr int OCH = BNO / 8;                 // 8-feature output chunks per row
   constexpr int TOTAL = ROWS * OCH;            // output chunks per slab
   constexpr int KC = (TOTAL + 511) / 512;      // chunks per thread per slab
@@ -286,20 +286,22 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
     if (p.bias && (GEGLU || i < NIO)) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + wave_n0 + i * 16 + fq * 4);
   }
   // per-batch vectors (row bias of the time embedding, AdaLN gate): one slab ahead
-  const bool has_rb = !GEGLU && p.rowbias != nullptr, has_gate = !GEGLU && p.gate != nullptr;
+  const bool has_rb = VEC && !GEGLU && p.rowbias != nullptr, has_gate = VEC && !GEGLU && p.gate != nullptr;
   auto wave_bidx = [&](int j) __attribute__((always_inline)) {
     const int m = m0 + wm * 16 * MI + j * 16 + fr;
     const int mc = m < p.M ? m : p.M - 1;
     return (p.rows_per_batch > 0) ? (mc / p.rows_per_batch) : 0;
   };
-  f32x4 rb_r[NIO], gate_r[NIO];
+  f32x4 rb_r[VEC ? NIO : 1], gate_r[VEC ? NIO : 1];
   auto load_batch_vectors = [&](int j) __attribute__((always_inline)) {
-    const int bidx = wave_bidx(j);
+    if constexpr (VEC) {
+      const int bidx = wave_bidx(j);
 #pragma unroll
-    for (int i = 0; i < NIO; ++i) {
-      const int n = wave_n0 + i * 16 + fq * 4;
-      if (has_rb) rb_r[i] = *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ldrb + n);
-      if (has_gate) gate_r[i] = *reinterpret_cast<const f32x4*>(p.gate + (long)bidx * p.ldg + n);
+      for (int i = 0; i < NIO; ++i) {
+        const int n = wave_n0 + i * 16 + fq * 4;
+        if (has_rb) rb_r[i] = *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ldrb + n);
+        if (has_gate) gate_r[i] = *reinterpret_cast<const f32x4*>(p.gate + (long)bidx * p.ldg + n);
+      }
     }
   };
   load_batch_vectors(0);
@@ -311,7 +313,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
 
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
-    float* sb = slab + (j & 1) * SLAB;
+    float* sb = (j & 1) ? slab1 : slab0;
     // ---- phase A: accumulator layout -> slab (or V^T directly) ----
     {
       const int m = m0 + wm * 16 * MI + j * 16 + fr;
@@ -327,8 +329,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
           for (int q = 0; q < 4; ++q) v[q] = v[q] * gelu_fast(g[q]);
         } else {
           v *= w_scale;
-          if (has_rb) v += rb_r[i];
-          if (has_gate) v *= gate_r[i];
+          if constexpr (VEC) {
+            if (has_rb) v += rb_r[i];
+            if (has_gate) v *= gate_r[i];
+          }
         }
         vv[i] = v;
       }

@@ -197,13 +197,16 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   if (d->ldc % 8 != 0 || ((uintptr_t)d->c & 15) != 0) return none;
   if (d->residual && (d->ldr % 8 != 0 || ((uintptr_t)d->residual & 15) != 0)) return none;
   const bool geglu = (d->flags & MX_EPI_GEGLU) != 0, qkv = (d->flags & MX_EPI_QKV) != 0;
+  // the 256x256 kernel addresses its operands with 32-bit byte offsets from the base pointers
+  const long in_rows = d->a_batch_rows > 0 ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
+  const bool fits32 = in_rows * d->lda * 2 < (1L << 32) && (long)d->N * d->K * 2 < (1L << 32);
   TileChoice best = none;
   double best_cost = 0;
   const TileChoice cands[5] = {{256, 256}, {160, 256}, {128, 256}, {160, 128}, {128, 128}};
   for (int c = 0; c < 5; ++c) {
     const int bn = cands[c].bn, rows = cands[c].rows;
     if (d->N % bn != 0 || d->M < rows) continue;
-    if (bn == 256 && (conv || v3_disabled)) continue;
+    if (bn == 256 && (conv || v3_disabled || !fits32)) continue;
     if (rows == 128 && small_disabled) continue;
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;

@@ -284,9 +284,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
     __syncthreads();
     float* slab = reinterpret_cast<float*>(smem);
     if (p.flags & MX_EPI_GEGLU) {
-      if constexpr (BN % 64 == 0 && !CONV) gemm_epilogue_staged<NI, MI, 4, 2, true>(p, acc, slab, m0, n0, wm, wn, fr, fq, tid);
+      if constexpr (BN % 64 == 0 && !CONV) gemm_epilogue_staged<NI, MI, 4, 2, true>(p, acc, slab, slab + 64 * (BN / 2), m0, n0, wm, wn, fr, fq, tid);
     } else {
-      gemm_epilogue_staged<NI, MI, 4, 2, false>(p, acc, slab, m0, n0, wm, wn, fr, fq, tid);
+      gemm_epilogue_staged<NI, MI, 4, 2, false>(p, acc, slab, slab + 64 * BN, m0, n0, wm, wn, fr, fq, tid);
     }
 #endif
   }

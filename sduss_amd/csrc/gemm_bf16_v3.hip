@@ -18,8 +18,12 @@
 //     v_mfma_f32_16x16x32_bf16 (128 VGPRs);
 //   * same XOR swizzle and source-side application as v2 (16-byte chunk ^= (row >> 1) & 7 on 128-byte rows);
 //   * one counted s_waitcnt vmcnt(4) + one raw s_barrier per K tile; the DMA issue is branch-free and interleaved with the MFMAs of
-//     k-step 0 (sched_group_barrier), the fragment reads of k-step 1 with its second half; one tile per workgroup; the
-//     drained ring is the transpose buffer of the LDS-staged epilogue (gemm_args.h).
+//     k-step 0 (sched_group_barrier), the fragment reads of k-step 1 with its second half;
+//   * launches of more tiles than CUs whose epilogue needs no per-sample vectors are PERSISTENT: one workgroup per CU walks
+//     its tiles (t, t + grid, ...) and their half-tiles form one DMA stream, so the first three half-tiles of the next tile
+//     land during the epilogue, which transposes through the two ring slots the last K iteration just released
+//     (gemm_args.h: gemm_epilogue_staged).  The variant with row-bias / gate support is at the 256-VGPR wall and keeps one
+//     tile per workgroup.
 #include <cstdlib>
 
 #include "common.h"
@@ -31,8 +35,6 @@
 #endif
 
 namespace mx {
-
-__device__ __attribute__((aligned(64))) unsigned int g_zero_page3[1024 / 4] = {0};
 
 constexpr int BM3 = 256;
 constexpr int BN3 = 256;
@@ -49,6 +51,9 @@ __device__ __forceinline__ void glds16_3(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// VEC: the epilogue supports per-sample vectors (row bias / gate); the lean variant (!VEC) has the registers to run as a
+// persistent tile stream.
+template <bool VEC>
 __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
   constexpr int NI = 4;                        // 16-wide feature blocks per wave (64 features)
   constexpr int MI = 8;                        // 16-wide token blocks per wave (128 tokens)
@@ -65,63 +70,80 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
   const int wm = wave >> 2;                    // 0..1
   const int wn = wave & 3;                     // 0..3
   const int mt = (p.M + BM3 - 1) / BM3;
+  const int nt = p.N / BN3;
+  const int total_tiles = mt * nt;
   const int nk = p.K / BK3;
-  const char* zero = reinterpret_cast<const char*>(g_zero_page3);
-  int tm, tn;
-  gemm_tile_of_block(blockIdx.x, mt, p.N / BN3, p.xcd_map, tm, tn);
-  const int m0 = tm * BM3, n0 = tn * BN3;
 
-  // ---- issue side: ready-made per-thread source pointers for the next DMA group.  issue_group() is branch-free (it shares
-  //      a basic block with the MFMAs so each LDS-DMA can sit in an MFMA shadow); advance_cursor() holds the control flow
-  //      and runs after the MFMAs. ----
-  // half-tile h = 2g (X of K tile g) or 2g+1 (W of K tile g) lives in slot h % 5
-  int x_kt = 0, w_kt = 0;                      // K tile the next X / W group belongs to (>= nk: parked on the zero page)
-  const char* xsrc[XI];
-  const char* wsrc[WI];
-  {
-    const int cs = tid & 7;
+  // ---- issue side.  The X and W half-tiles of the workgroup's tiles (t = blockIdx.x, + gridDim.x, ...) form ONE stream of
+  //      LDS-DMA groups: X(0) W(0) X(1) W(1) ...; half-tile h of the stream lives in slot h % 5.  Each cursor holds ready-made
+  //      per-thread source offsets for its next group.  issue_x / issue_w are branch-free (they share a basic block with the
+  //      MFMAs so each LDS-DMA can sit in an MFMA shadow); advance_x / advance_w hold the control flow and run after the MFMAs.
+  //      Because the stream runs on into the next tile, that tile's X(0), W(0), X(1) are in flight during the epilogue. ----
+  int x_tile = blockIdx.x, w_tile = blockIdx.x;   // tile of the next X / W group (>= total_tiles: parked)
+  int x_kt = 0, w_kt = 0;                         // its K tile
+  unsigned xoff[XI], woff[WI];                    // byte offsets from p.a / p.w (the chooser guarantees they fit 32 bits)
+  const char* abase = reinterpret_cast<const char*>(p.a);
+  const char* wbase = reinterpret_cast<const char*>(p.w);
+  const int cs = tid & 7;
+  auto setup_x = [&](int t) __attribute__((always_inline)) {
+    int tm, tn;
+    gemm_tile_of_block(t, mt, nt, p.xcd_map, tm, tn);
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int row = (i * 512 + tid) >> 3;    // LDS slot: row, slot cs holds logical chunk swz3(row, cs)
-      const int m = m0 + row;
+      const int m = tm * BM3 + row;
       const int mc = m < p.M ? m : p.M - 1;    // clamped rows are computed and discarded by the epilogue mask
-      xsrc[i] = reinterpret_cast<const char*>(p.a) + (gemm_in_row(p, mc) * p.lda + swz3(row, cs) * 8) * 2;
+      xoff[i] = (unsigned)((gemm_in_row(p, mc) * p.lda + swz3(row, cs) * 8) * 2);
     }
+  };
+  auto setup_w = [&](int t) __attribute__((always_inline)) {
+    int tm, tn;
+    gemm_tile_of_block(t, mt, nt, p.xcd_map, tm, tn);
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int row = (i * 512 + tid) >> 3;
-      wsrc[i] = reinterpret_cast<const char*>(p.w) + ((long)(n0 + row) * p.K + swz3(row, cs) * 8) * 2;
+      woff[i] = (unsigned)(((long)(tn * BN3 + row) * p.K + swz3(row, cs) * 8) * 2);
     }
-  }
+  };
   auto issue_x = [&](int slot) __attribute__((always_inline)) {
     bf16_t* st = smem + slot * SLOT_ELEMS;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) glds16_3(xsrc[i], st + (i * 512 + wave * 64) * 8);
+    for (int i = 0; i < XI; ++i) glds16_3(abase + xoff[i], st + (i * 512 + wave * 64) * 8);
   };
   auto issue_w = [&](int slot) __attribute__((always_inline)) {
     bf16_t* st = smem + slot * SLOT_ELEMS;
 #pragma unroll
-    for (int i = 0; i < WI; ++i) glds16_3(wsrc[i], st + (i * 512 + wave * 64) * 8);
+    for (int i = 0; i < WI; ++i) glds16_3(wbase + woff[i], st + (i * 512 + wave * 64) * 8);
   };
   auto advance_x = [&]() __attribute__((always_inline)) {
-    if (x_kt >= nk) return;                    // parked
-    if (++x_kt == nk) {                        // past the end of the K range: same instruction count, harmless bytes
+    if (x_tile >= total_tiles) return;         // parked
+    if (++x_kt == nk) {                        // on to the workgroup's next tile, or past the end of the stream
+      x_kt = 0;
+      x_tile = VEC ? total_tiles : x_tile + (int)gridDim.x;     // the VEC variant runs one tile per workgroup
+      if constexpr (!VEC) {
+        if (x_tile < total_tiles) { setup_x(x_tile); return; }
+      }
 #pragma unroll
-      for (int i = 0; i < XI; ++i) xsrc[i] = zero + lane * 16;
+      for (int i = 0; i < XI; ++i) xoff[i] = lane * 16;          // same instruction count, harmless bytes (the head of A)
       return;
     }
 #pragma unroll
-    for (int i = 0; i < XI; ++i) xsrc[i] += BK3 * 2;
+    for (int i = 0; i < XI; ++i) xoff[i] += BK3 * 2;
   };
   auto advance_w = [&]() __attribute__((always_inline)) {
-    if (w_kt >= nk) return;
+    if (w_tile >= total_tiles) return;
     if (++w_kt == nk) {
+      w_kt = 0;
+      w_tile = VEC ? total_tiles : w_tile + (int)gridDim.x;
+      if constexpr (!VEC) {
+        if (w_tile < total_tiles) { setup_w(w_tile); return; }
+      }
 #pragma unroll
-      for (int i = 0; i < WI; ++i) wsrc[i] = zero + lane * 16;
+      for (int i = 0; i < WI; ++i) woff[i] = lane * 16;
       return;
     }
 #pragma unroll
-    for (int i = 0; i < WI; ++i) wsrc[i] += BK3 * 2;
+    for (int i = 0; i < WI; ++i) woff[i] += BK3 * 2;
   };
 
   // ---- fragment addresses: lane (fr, fq) reads row base + fr, chunk 4*ks + fq of a 16-row block ----
@@ -133,92 +155,139 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
 #pragma unroll                                 // block of 16 rows: the swizzle depends on (row >> 1) & 7 = (fr >> 1) & 7
   for (int ks = 0; ks < 2; ++ks) koff[ks] = swz3(fr, ks * 4 + fq) * 8;
 
+  setup_x(x_tile);
+  setup_w(w_tile);
   issue_x(0); advance_x();                     // X(0) -> slot 0, W(0) -> slot 1, X(1) -> slot 2
   issue_w(1); advance_w();
   issue_x(2); advance_x();
 
-  f32x4 acc[NI][MI];
+  int xs = 0;                                  // slot of the X half-tile being read = (2 g) % 5 for stream position g; W follows
+  for (int tile = blockIdx.x; tile < total_tiles; tile += (VEC ? total_tiles : (int)gridDim.x)) {
+    f32x4 acc[NI][MI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int xs = 0;                                  // slot of X(kt) = (2 kt) % 5; W(kt) is in the next slot
-  for (int kt = 0; kt < nk; ++kt) {
-    // all but the youngest group (X of K tile kt+1) has landed => X(kt) and W(kt) are in LDS
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int ws = xs == NSLOT - 1 ? 0 : xs + 1;
-    const int f0 = ws == NSLOT - 1 ? 0 : ws + 1;           // slot of X(kt+1), in flight
-    const int f1 = f0 == NSLOT - 1 ? 0 : f0 + 1;           // the two slots read in the previous iteration, which every
-    const int f2 = f1 == NSLOT - 1 ? 0 : f1 + 1;           // wave has left: W(kt+1) and X(kt+2) go there
-    const bf16_t* sx = smem + xs * SLOT_ELEMS;
-    const bf16_t* sw = smem + ws * SLOT_ELEMS;
-    bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
+    for (int kt = 0; kt < nk; ++kt) {
+      // all but the youngest group (the X half-tile of the next stream position) has landed => X and W of this position are in
+      // LDS (vmcnt retires in order: epilogue stores of the previous tile only make the wait more conservative)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int ws = xs == NSLOT - 1 ? 0 : xs + 1;
+      const int f0 = ws == NSLOT - 1 ? 0 : ws + 1;           // slot of the next X half-tile, in flight
+      const int f1 = f0 == NSLOT - 1 ? 0 : f0 + 1;           // the two slots read in the previous iteration (or used by the
+      const int f2 = f1 == NSLOT - 1 ? 0 : f1 + 1;           // previous tile's epilogue), which every wave has left
+      const bf16_t* sx = smem + xs * SLOT_ELEMS;
+      const bf16_t* sw = smem + ws * SLOT_ELEMS;
+      bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(sw + (w_row + 16 * i) * BK3 + koff[0]);
+      for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(sw + (w_row + 16 * i) * BK3 + koff[0]);
 #pragma unroll
-    for (int j = 0; j < MI; ++j) xf0[j] = *reinterpret_cast<const bf16x8*>(sx + (x_row + 16 * j) * BK3 + koff[0]);
+      for (int j = 0; j < MI; ++j) xf0[j] = *reinterpret_cast<const bf16x8*>(sx + (x_row + 16 * j) * BK3 + koff[0]);
 #if MX_EXP != 2
-    issue_w(f1);
-    issue_x(f2);
+      issue_w(f1);
+      issue_x(f2);
 #endif
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(sw + (w_row + 16 * i) * BK3 + koff[1]);
+      for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(sw + (w_row + 16 * i) * BK3 + koff[1]);
 #pragma unroll
-    for (int j = 0; j < MI; ++j) xf1[j] = *reinterpret_cast<const bf16x8*>(sx + (x_row + 16 * j) * BK3 + koff[1]);
+      for (int j = 0; j < MI; ++j) xf1[j] = *reinterpret_cast<const bf16x8*>(sx + (x_row + 16 * j) * BK3 + koff[1]);
 #if MX_EXP != 1 && MX_EXP != 5
 #pragma unroll
-    for (int j = 0; j < MI; ++j)
+      for (int j = 0; j < MI; ++j)
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NI; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < MI; ++j)
+      for (int j = 0; j < MI; ++j)
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NI; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
 #endif
-    // schedule: the 12 fragment reads of k-step 0; then its 32 MFMAs with the 8 LDS-DMAs (first half) and the 12 reads of
-    // k-step 1 (second half) in their shadows; then the 32 MFMAs of k-step 1
-    __builtin_amdgcn_sched_group_barrier(0x100, NI + MI, 0);
+      // schedule: the 12 fragment reads of k-step 0; then its 32 MFMAs with the 8 LDS-DMAs (first half) and the 12 reads of
+      // k-step 1 (second half) in their shadows; then the 32 MFMAs of k-step 1
+      __builtin_amdgcn_sched_group_barrier(0x100, NI + MI, 0);
 #pragma unroll
-    for (int s = 0; s < LOADS; ++s) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
+      for (int s = 0; s < LOADS; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
 #pragma unroll
-    for (int s = 0; s < NI + MI; ++s) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI * MI - 2 * LOADS - (NI + MI), 0);
+      for (int s = 0; s < NI + MI; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI * MI - 2 * LOADS - (NI + MI), 0);
 #if MX_EXP != 2
-    advance_w();
-    advance_x();
+      advance_w();
+      advance_x();
 #endif
-    xs = f0;
-  }
+      xs = f0;
+    }
 
+    int tm, tn;
+    gemm_tile_of_block(tile, mt, nt, p.xcd_map, tm, tn);
+    const int m0 = tm * BM3, n0 = tn * BN3;
 #if MX_EXP == 4   // no epilogue: keep the accumulators alive with a store that never executes on real data
-  {
-    float t = 0.f;
-    for (int i = 0; i < NI; ++i) for (int j = 0; j < MI; ++j) for (int q = 0; q < 4; ++q) t += acc[i][j][q];
-    if (t == 12345.678f) reinterpret_cast<bf16_t*>(p.c)[m0 + n0] = f32_to_bf16(t);
-  }
+    {
+      float t = 0.f;
+      for (int i = 0; i < NI; ++i) for (int j = 0; j < MI; ++j) for (int q = 0; q < 4; ++q) t += acc[i][j][q];
+      if (t == 12345.678f) reinterpret_cast<bf16_t*>(p.c)[m0 + n0] = f32_to_bf16(t);
+    }
 #else
-  // every DMA has landed and every wave has left the K loop: the ring becomes the epilogue's transpose buffer
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  float* slab = reinterpret_cast<float*>(smem);
-  if (p.flags & MX_EPI_GEGLU) gemm_epilogue_staged<NI, MI, 2, 4, true>(p, acc, slab, m0, n0, wm, wn, fr, fq, tid);
-  else gemm_epilogue_staged<NI, MI, 2, 4, false>(p, acc, slab, m0, n0, wm, wn, fr, fq, tid);
+    // Every wave has left the K loop.  The two slots read in its last iteration are free -- the three others hold the first
+    // half-tiles of the workgroup's next tile, still landing -- and become the two transpose buffers of the epilogue.
+    __syncthreads();
+    const int s_w = xs == 0 ? NSLOT - 1 : xs - 1;            // W slot of the last iteration
+    const int s_x = s_w == 0 ? NSLOT - 1 : s_w - 1;          // X slot of the last iteration
+    float* slab0 = reinterpret_cast<float*>(smem + s_x * SLOT_ELEMS);
+    float* slab1 = reinterpret_cast<float*>(smem + s_w * SLOT_ELEMS);
+    if (p.flags & MX_EPI_GEGLU) gemm_epilogue_staged<NI, MI, 2, 4, true, VEC>(p, acc, slab0, slab1, m0, n0, wm, wn, fr, fq, tid);
+    else gemm_epilogue_staged<NI, MI, 2, 4, false, VEC>(p, acc, slab0, slab1, m0, n0, wm, wn, fr, fq, tid);
+    // the cursors' per-thread offsets are recomputed from (tile, K tile) rather than kept in registers across the epilogue
+    if constexpr (!VEC) {
+    if (x_tile < total_tiles) {
+      setup_x(x_tile);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) xoff[i] += x_kt * (BK3 * 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) xoff[i] = lane * 16;
+    }
+    if (w_tile < total_tiles) {
+      setup_w(w_tile);
+#pragma unroll
+      for (int i = 0; i < WI; ++i) woff[i] += w_kt * (BK3 * 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < WI; ++i) woff[i] = lane * 16;
+    }
+    }
 #endif
+    if constexpr (VEC) break;                          // one tile per workgroup: no loop-carried state for the register allocator
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end DMAs before the workgroup retires
 }
 
 int launch_v3(hipStream_t s, const GemmArgs& a) {
-  dim3 grid(cdiv(a.M, BM3) * (a.N / BN3)), block(512);
-  hipLaunchKernelGGL(gemm_v3_kernel, grid, block, 0, s, a);
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    }
+    return n & ~7;                              // whole XCD groups, so tile % 8 stays the workgroup's XCD (gemm_tile_of_block)
+  }();
+  static const bool persist = [] { const char* e = getenv("MX_V3_PERSIST"); return !(e && e[0] == '0'); }();
+  const int tiles = cdiv(a.M, BM3) * (a.N / BN3);
+  dim3 block(512);
+  if (a.rowbias || a.gate) {                    // per-sample vectors: the full epilogue has no registers to spare, one tile per workgroup
+    hipLaunchKernelGGL(gemm_v3_kernel<true>, dim3(tiles), block, 0, s, a);
+  } else {
+    // more tiles than CUs: one workgroup per CU walks its tiles as one DMA stream (the next tile's operands fly during the epilogue)
+    hipLaunchKernelGGL(gemm_v3_kernel<false>, dim3(persist && tiles > ncu && ncu > 0 ? ncu : tiles), block, 0, s, a);
+  }
   return 0;
 }
 
