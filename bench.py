@@ -40,10 +40,10 @@ KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<12
               "gemm_v3_kernel (256x256)"]
 
 
-KIND_SYMBOLS = {  # bench kernel label -> symbol prefix in the rocprofv3 summaries (all instantiations of the kind)
-    "gemm_v2_kernel<160,false>": "mx::gemm_v2_kernel<160, false>", "gemm_v2_kernel<160,true> (conv3x3)": "mx::gemm_v2_kernel<160, true>",
-    "gemm_v2_kernel<128,false>": "mx::gemm_v2_kernel<128, false>", "gemm_v2_kernel<128,true> (conv3x3)": "mx::gemm_v2_kernel<128, true>",
-    "gemm_v3_kernel (256x256)": "mx::gemm_v3_kernel(", "attn_fwd_kernel": "mx::attn_fwd_kernel",
+KIND_SYMBOLS = {  # bench kernel label -> regex over the symbols in the rocprofv3 summaries (all instantiations of the kind)
+    "gemm_v2_kernel<160,false>": r"mx::gemm_v2_kernel<160, \d+, false>", "gemm_v2_kernel<160,true> (conv3x3)": r"mx::gemm_v2_kernel<160, \d+, true>",
+    "gemm_v2_kernel<128,false>": r"mx::gemm_v2_kernel<128, \d+, false>", "gemm_v2_kernel<128,true> (conv3x3)": r"mx::gemm_v2_kernel<128, \d+, true>",
+    "gemm_v3_kernel (256x256)": r"mx::gemm_v3_kernel<", "attn_fwd_kernel": r"mx::attn_fwd_kernel",
 }
 
 
@@ -52,13 +52,14 @@ def pmc_traffic_bytes(kernel_label, model):
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, tools/pmc_traffic.py), launch-weighted over the kind's
     instantiations.  PMC cannot be collected inside the timed run."""
     import glob
+    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic_{model}*.txt")))
-    prefix = KIND_SYMBOLS.get(kernel_label)
-    if not files or not prefix:
+    pat = KIND_SYMBOLS.get(kernel_label)
+    if not files or not pat:
         return None, None
     n, mb = 0, 0.0
     for line in open(files[-1]):
-        if line.startswith(prefix):
+        if re.match(pat, line):
             f = line.split()
             n += int(f[-4]); mb += int(f[-4]) * float(f[-1])
     return (mb / n * 1e6, os.path.basename(files[-1])) if n else (None, None)
