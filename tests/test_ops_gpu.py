@@ -253,7 +253,8 @@ class _expect_v3:
         return False
 
 
-@pytest.mark.parametrize("m,n,k", [(4096, 4096, 256), (3900, 4096, 192), (8192, 2048, 128)])
+@pytest.mark.parametrize("m,n,k", [(4096, 4096, 256), (3900, 4096, 192), (8192, 2048, 128),
+                                   (8000, 8192, 128), (4900, 4096, 192)])   # the last two: more tiles than CUs -> persistent stream
 def test_gemm_tile256_bias_residual(cuda_device, m, n, k):
     from sduss_amd import ops
     g = torch.Generator().manual_seed(m + n + k)
