@@ -276,3 +276,39 @@ def make_inputs(cfg: MMDiTConfig, batch: int, latent_hw: int, seed: int = 10086,
     pooled = torch.randn(batch, cfg.pooled_projection_dim, generator=g)
     t = torch.full((batch,), 701.0)
     return lat, t, ehs, pooled
+
+
+# --------------------------------------------------------------------------------------
+# token re-chunk either side of the sliced MMDiT forward  (modules/utils.py:86-136)
+# Pinned against the reference itself: tests/golden/ref_utils_sd3.npz (tests/golden/make_ref_fixtures.py).
+# --------------------------------------------------------------------------------------
+def split_sample_sd3(samples: Dict[str, torch.Tensor], patch_size: int, input_indices: Dict[str, list]):
+    """samples: {resolution: tokens [n, L, D]} -> (indices, encoder_indices, latent_offset, resolution_offset, chunks).
+    Every latent is cut into (resolution // patch_size)^2 equal TOKEN RANGES (not 2-D patches: utils.py:110) and all chunks
+    are stacked -- so every chunk of the call must have the same length (a torch.stack of unequal chunks raises)."""
+    latent_offset, resolution_offset = [0], [0]
+    chunks, indices, encoder_indices = [], [], []
+    for resolution, res_sample in samples.items():
+        if res_sample is None or res_sample.shape[0] == 0:
+            continue
+        pn = int(resolution) // patch_size
+        for i, sample in enumerate(res_sample):
+            latent_offset.append(latent_offset[-1] + pn ** 2)
+            rid = input_indices[str(int(resolution))][i]
+            encoder_indices.append(rid)
+            indices.extend(f"{rid}-{h}" for h in range(pn * pn))
+            chunks.extend(sample.chunk(pn * pn, dim=0))
+        resolution_offset.append(len(latent_offset) - 1)
+    return indices, encoder_indices, latent_offset, resolution_offset, torch.stack(chunks)
+
+
+def concat_sample_tokens(patch_size: int, new_sample: torch.Tensor, latent_offset) -> Dict[str, torch.Tensor]:
+    """inverse of split_sample_sd3 on the token axis (utils.py:124-136): chunks of one latent are viewed back as one
+    [1, L, D] sequence and grouped under str(sqrt(chunks) * patch_size)."""
+    import math
+    samples: Dict[str, list] = {}
+    for i in range(len(latent_offset) - 1):
+        n = latent_offset[i + 1] - latent_offset[i]
+        size = int(math.sqrt(n)) * patch_size
+        samples.setdefault(str(size), []).append(new_sample[latent_offset[i]:latent_offset[i + 1]].reshape(1, -1, new_sample.shape[-1]))
+    return {k: torch.cat(v, dim=0) for k, v in samples.items()}

@@ -25,6 +25,35 @@ def greedy_assign(resolutions: Sequence[int], n_ranks: int, outstanding: Dict[in
     return out
 
 
+class GreedyPlacer:
+    """Stateful mirror of the reference dispatcher's bookkeeping for one node: ``add`` places newly arrived requests
+    (GreedyDispath.dispatch_requests, greedy.py:16-36, over RequestPool.get_pixels_all_dp_rank, request_pool.py:95-102),
+    ``finish`` drops completed ones (RequestPool.remove_requests).  Placement is sticky for a request's lifetime.
+    Checked against the reference classes themselves by tests/test_ref_fixtures.py (tests/golden/ref_greedy_dispatch.json)."""
+
+    def __init__(self, n_ranks: int):
+        self.n_ranks = n_ranks
+        self._req: Dict[int, Tuple[int, int]] = {}          # request id -> (dp_rank, resolution)
+
+    def outstanding(self) -> Dict[int, int]:
+        load = {r: 0 for r in range(self.n_ranks)}
+        for rank, res in self._req.values():
+            load[rank] += res * res
+        return load
+
+    def add(self, request_ids: Sequence[int], resolutions: Sequence[int]) -> List[int]:
+        ranks = greedy_assign(resolutions, self.n_ranks, self.outstanding())
+        for rid, res, rank in zip(request_ids, resolutions, ranks):
+            if rid in self._req:
+                raise RuntimeError(f"Request with id {rid} already exists.")    # request_pool.py:40-41
+            self._req[rid] = (rank, int(res))
+        return ranks
+
+    def finish(self, request_ids: Sequence[int]) -> None:
+        for rid in request_ids:
+            self._req.pop(rid)
+
+
 def my_share(n_requests: int, rank: int, world: int, resolutions: Sequence[int] = None) -> List[int]:
     """indices of the requests this rank serves."""
     res = list(resolutions) if resolutions is not None else [1024] * n_requests
