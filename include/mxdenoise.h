@@ -214,7 +214,9 @@ int mx_unet_validate(const mx_unet* u, int batch, int H, int W, int ctx_len);
  *   out      [batch, out_channels, H, W] of `io_dtype`
  *   gn_patch 0 = is_sliced False (exact GroupNorm, zero-padded convs);
  *            p>0 = is_sliced True with latent patch edge p: patch-averaged GroupNorm statistics and the
- *            halo-corner rule, i.e. bit-for-bit the arithmetic of the reference's sliced path on whole images. */
+ *            halo-corner rule, i.e. the same real-number arithmetic as the reference's sliced path, evaluated on whole
+ *            images (not bit-for-bit: bf16 storage and fp32 statistics here, fp16 storage and fp16-rounded statistics
+ *            there, norm_silu_concat.cpp:84-85; tolerance stated in tests/test_unet_gpu.py). */
 int mx_unet_forward(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
                     const void* ehs, const void* text_embeds, const float* time_ids, void* out,
                     int batch, int H, int W, int ctx_len, int gn_patch, void* workspace, size_t workspace_bytes);

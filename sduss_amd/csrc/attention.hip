@@ -333,6 +333,7 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
   using namespace mx;
   MX_CHECK(q && k && vt && o, "attention: null operand");
   MX_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
+  MX_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o) & 15) == 0, "attention: operand pointers must be 16-byte aligned");
   MX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: strides must be multiples of 8 elements");
   MX_CHECK(ldq >= H * 64 && ldk >= H * 64 && ldo >= H * 64, "attention: row stride smaller than H*64");
   MX_CHECK(ldvt >= MX_VT_LD(Lk), "attention: ldvt must cover MX_VT_LD(Lk) (keys are stored in MX_VT_POS order)");

@@ -249,6 +249,13 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(d->Hout == (Hv + d->stride - 1) / d->stride && d->Wout == (Wv + d->stride - 1) / d->stride,
              "conv3x3: output grid does not match input grid / stride");
     MX_CHECK((long)d->B * d->Hout * d->Wout == d->M, "conv3x3: M != B*Hout*Wout");
+    MX_CHECK(2 * d->Cin <= 16384, "conv3x3: Cin > 8192 (the pipelined loader walks a 16 KB zero page for padding taps)");
+    MX_CHECK(!(d->flags & MX_EPI_GEGLU), "conv3x3: no GEGLU epilogue");
+  }
+  // the LDS-DMA loaders and the staged epilogue move 16-byte pieces: every base pointer must be 16-byte aligned
+  {
+    const void* ptrs[] = {d->a, d->w, d->c, d->bias, d->rowbias, d->residual, d->gate, d->rms_wq, d->rms_wk};
+    for (const void* q : ptrs) MX_CHECK(((uintptr_t)q & 15) == 0, "gemm: operand pointers must be 16-byte aligned");
   }
   if (d->rowbias || d->gate || d->a_batch_rows > 0 || d->c_batch_rows > 0 || (d->flags & (MX_EPI_QKV | MX_EPI_RES_BCAST)))
     MX_CHECK(d->rows_per_batch > 0, "gemm: rows_per_batch required");

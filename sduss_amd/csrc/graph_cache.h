@@ -24,7 +24,7 @@
 namespace mx {
 
 struct GraphCache {
-  struct Entry { std::vector<uint64_t> key; hipGraphExec_t exec; uint64_t stamp; };
+  struct Entry { std::vector<uint64_t> key; hipGraphExec_t exec; uint64_t stamp; hipStream_t last; };   // last: stream of the latest launch
   std::vector<Entry> entries;
   uint64_t clock = 0;
   int miss_streak = 0;
@@ -39,10 +39,22 @@ struct GraphCache {
   }
   ~GraphCache() {
     if (getenv("MX_GRAPH_DEBUG")) fprintf(stderr, "[mx graph] replays %ld captures %ld eager %ld disabled %d\n", n_replay, n_capture, n_eager, (int)disabled);
-    for (auto& e : entries) (void)hipGraphExecDestroy(e.exec);
+    clear();
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
     if (side) (void)hipStreamDestroy(side);
+  }
+
+  // An exec may still be running when it is dropped (the launch is asynchronous): wait for the stream it last ran on first.
+  static void retire(Entry& e) {
+    if (e.last) (void)hipStreamSynchronize(e.last);
+    (void)hipGraphExecDestroy(e.exec);
+  }
+  // drop every captured graph: called when the handle's weight table changes (the key holds pointers, not the table)
+  void clear() {
+    for (auto& e : entries) retire(e);
+    entries.clear();
+    miss_streak = 0;
   }
 
   // body(stream) enqueues the plan on `stream` and returns true on success.  Returns true if the work was enqueued (by
@@ -63,7 +75,7 @@ struct GraphCache {
     }
     hipGraphExec_t exec = nullptr;
     for (auto& e : entries)
-      if (e.key == key) { exec = e.exec; e.stamp = ++clock; break; }
+      if (e.key == key) { exec = e.exec; e.stamp = ++clock; e.last = s; break; }
     if (!exec) {
       if (++miss_streak > 16) { disabled = true; return body(user); }
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); disabled = true; return body(user); }
@@ -79,10 +91,10 @@ struct GraphCache {
       if (entries.size() >= 8) {
         size_t lru = 0;
         for (size_t i = 1; i < entries.size(); ++i) if (entries[i].stamp < entries[lru].stamp) lru = i;
-        (void)hipGraphExecDestroy(entries[lru].exec);
+        retire(entries[lru]);
         entries.erase(entries.begin() + lru);
       }
-      entries.push_back(Entry{key, exec, ++clock});
+      entries.push_back(Entry{key, exec, ++clock, s});
       ++n_capture;
     } else {
       miss_streak = 0;

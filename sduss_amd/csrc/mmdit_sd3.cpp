@@ -305,6 +305,7 @@ extern "C" void mx_mmdit_destroy(mx_mmdit* u) { delete u; }
 
 extern "C" int mx_mmdit_set_weights(mx_mmdit* u, const void* blob, uint64_t blob_bytes, const mx_weight_entry* table, int n) {
   MX_CHECK(u && blob && table && n > 0, "mmdit_set_weights: bad arguments");
+  u->graphs.clear();    // captured graphs hold addresses resolved through the old table
   u->table.clear();
   for (int i = 0; i < n; ++i) {
     MX_CHECK(table[i].name != nullptr, "mmdit_set_weights: null name");

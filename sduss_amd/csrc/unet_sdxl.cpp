@@ -476,6 +476,7 @@ extern "C" void mx_unet_destroy(mx_unet* u) { delete u; }
 
 extern "C" int mx_unet_set_weights(mx_unet* u, const void* blob, uint64_t blob_bytes, const mx_weight_entry* table, int n) {
   MX_CHECK(u && blob && table && n > 0, "unet_set_weights: bad arguments");
+  u->graphs.clear();    // captured graphs hold addresses resolved through the old table
   u->table.clear();
   for (int i = 0; i < n; ++i) {
     MX_CHECK(table[i].name != nullptr, "unet_set_weights: null name");

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .step_state import StepCache
 from .unet import MxUNet
 
 
@@ -65,6 +66,7 @@ class SDXLDenoiser:
         self._tables: Dict[int, tuple] = {}
         self.concurrent_resolutions = True
         self._streams: List[torch.cuda.Stream] = []
+        self._cache = StepCache(unet.device)      # per batch composition: conditioning cats, sigma/timestep tables (step_state.py)
 
     def set_timesteps(self, req: Request) -> None:
         if req.num_inference_steps not in self._tables:
@@ -104,31 +106,35 @@ class SDXLDenoiser:
             join = torch.cuda.Event()
             join.record(side)
             cur.wait_event(join)
+        for res in res_list:                       # the new latents were allocated on side streams: consumers on `cur`
+            for r in worker_reqs[res]:             # (post_inference / VAE) are now known to the allocator
+                r.latents.record_stream(cur)
 
     def _step_resolution(self, res: str, reqs: List[Request], do_classifier_free_guidance: bool, is_sliced: bool,
                          patch_size: int) -> None:
-        dev = self.unet.device
         n = len(reqs)
         here = torch.cuda.current_stream()
         for r in reqs:                                                   # latents may have been produced on another stream
             r.latents.record_stream(here)
-        lat = torch.cat([r.latents for r in reqs], dim=0).contiguous()   # :287-312
-        sig = torch.tensor([float(r.sigmas[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
-        sig_next = torch.tensor([float(r.sigmas[r.step_index + 1]) for r in reqs], dtype=torch.float32, device=dev)
-        ts = torch.tensor([float(r.timesteps[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
-        if do_classifier_free_guidance:                                  # :322-339 row order [uncond..., cond...]
-            ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
-            pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
-            # add_time_ids are interleaved neg/pos per request in the reference (:302-305)
-            tids = torch.cat([t for r in reqs for t in (r.negative_add_time_ids, r.add_time_ids)], dim=0)
-            ts2 = torch.cat([ts, ts], dim=0)
-            rows = 2 * n
-        else:
-            ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
-            pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
-            tids = torch.cat([r.add_time_ids for r in reqs], dim=0)
-            ts2 = ts
-            rows = n
+
+        def build_cond():
+            if do_classifier_free_guidance:                              # :322-339 row order [uncond..., cond...]
+                ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+                # add_time_ids are interleaved neg/pos per request in the reference (:302-305)
+                tids = torch.cat([t for r in reqs for t in (r.negative_add_time_ids, r.add_time_ids)], dim=0)
+            else:
+                ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
+                tids = torch.cat([r.add_time_ids for r in reqs], dim=0)
+            return ehs, pooled, tids
+        # embeddings are fixed for a request's lifetime: one cat per batch composition, not per step (:287-316 redo it every step)
+        e = self._cache.entry((res, do_classifier_free_guidance, tuple(r.request_id for r in reqs), tuple(id(r) for r in reqs)), reqs, build_cond)
+        ehs, pooled, tids = e.cond
+        lat = self._cache.latents(e, reqs)                               # :287-312
+        sig, sig_next, ts = self._cache.step_scalars(e, reqs)
+        rows = 2 * n if do_classifier_free_guidance else n
+        ts2 = torch.cat([ts, ts], dim=0) if do_classifier_free_guidance else ts
         x_in = ops.euler_scale_input(lat, sig, rows)                     # :357-360 (+ the cat of :327)
         noise = self.unet.forward({res: x_in}, ts2, ehs, added_cond_kwargs={"text_embeds": pooled, "time_ids": tids},
                                   return_dict=False, is_sliced=is_sliced, patch_size=patch_size,

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .step_state import StepCache
 from .transformer_sd3 import MxSD3Transformer
 
 
@@ -55,6 +56,7 @@ class SD3Denoiser:
         self._tables: Dict[int, tuple] = {}
         self.concurrent_resolutions = True
         self._streams: List[torch.cuda.Stream] = []
+        self._cache = StepCache(transformer.device)
 
     def set_timesteps(self, req: SD3Request) -> None:
         if req.num_inference_steps not in self._tables:
@@ -85,26 +87,33 @@ class SD3Denoiser:
             join = torch.cuda.Event()
             join.record(side)
             cur.wait_event(join)
+        for res in res_list:
+            for r in runner_reqs[res]:
+                r.latents.record_stream(cur)
 
     def _step_resolution(self, res: str, reqs: List[SD3Request], do_classifier_free_guidance: bool, is_sliced: bool,
                          patch_size: int) -> None:
-        dev = self.transformer.device
         n = len(reqs)
         here = torch.cuda.current_stream()
         for r in reqs:                                                   # latents may have been produced on another stream
             r.latents.record_stream(here)
-        lat = torch.cat([r.latents for r in reqs], dim=0).contiguous()
-        sig = torch.tensor([float(r.sigmas[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
-        sig_next = torch.tensor([float(r.sigmas[r.step_index + 1]) for r in reqs], dtype=torch.float32, device=dev)
-        ts = torch.tensor([float(r.timesteps[r.step_index]) for r in reqs], dtype=torch.float32, device=dev)
-        if do_classifier_free_guidance:                                      # :281-292 rows [uncond..., cond...]
-            ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
-            pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+
+        def build_cond():
+            if do_classifier_free_guidance:                                  # :281-292 rows [uncond..., cond...]
+                ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+            else:
+                ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
+            return ehs, pooled
+        e = self._cache.entry((res, do_classifier_free_guidance, tuple(r.request_id for r in reqs), tuple(id(r) for r in reqs)), reqs, build_cond)
+        ehs, pooled = e.cond
+        lat = self._cache.latents(e, reqs)
+        sig, sig_next, ts = self._cache.step_scalars(e, reqs)
+        if do_classifier_free_guidance:
             ts2 = torch.cat([ts, ts], dim=0)
             x_in = ops.euler_scale_input(lat, torch.zeros_like(sig), 2 * n)  # exact x/1 copy == torch.cat([latents] * 2)
         else:
-            ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
-            pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
             ts2, x_in = ts, lat
         noise = self.transformer.forward({res: x_in}, encoder_hidden_states=ehs, pooled_projections=pooled, timestep=ts2,
                                          return_dict=False, is_sliced=is_sliced, patch_size=patch_size,

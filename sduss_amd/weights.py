@@ -62,6 +62,20 @@ def load_safetensors_dir(unet_dir: str) -> Tuple[UNetConfig, Dict[str, torch.Ten
     return cfg, params
 
 
+def load_mmdit_safetensors_dir(transformer_dir: str):
+    """SD3.5: <dir>/config.json + diffusion_pytorch_model*.safetensors of the HF ``transformer/`` sub-folder."""
+    from safetensors.torch import load_file
+    from .config import MMDiTConfig
+    cfg = MMDiTConfig.from_hf_json(os.path.join(transformer_dir, "config.json"))
+    files = sorted(f for f in os.listdir(transformer_dir) if f.endswith(".safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no .safetensors under {transformer_dir}")
+    params: Dict[str, torch.Tensor] = {}
+    for f in [f for f in files if "fp16" not in f] or files:
+        params.update(load_file(os.path.join(transformer_dir, f)))
+    return cfg, params
+
+
 def _conv_pack(w: torch.Tensor, pad_in: int = 0) -> torch.Tensor:
     o, i, kh, kw = w.shape
     w = w.permute(0, 2, 3, 1)  # O, kh, kw, I

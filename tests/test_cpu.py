@@ -209,3 +209,112 @@ def test_geglu_interleave_layout():
     p = _geglu_interleave(t)
     assert p[:32].tolist() == list(range(0, 32)) and p[32:64].tolist() == list(range(256, 288))
     assert p[64:96].tolist() == list(range(32, 64))
+
+
+def test_step_cache_follows_host_step_indices():
+    """sduss_amd/step_state.py: per-composition sigma / timestep table + device-side step index == the per-step lists the
+    reference builds (scheduling_euler_discrete.py:171-175, 213-217), including a rewound request and latents reuse."""
+    from types import SimpleNamespace
+    from sduss_amd.pipeline import euler_tables
+    from sduss_amd.step_state import StepCache
+    t50, s50, _ = euler_tables(50)
+    t30, s30, _ = euler_tables(30)
+    reqs = [SimpleNamespace(request_id=i, timesteps=t, sigmas=s, step_index=k, latents=torch.full((1, 4, 2, 2), float(i)))
+            for i, (t, s, k) in enumerate(((t50, s50, 0), (t30, s30, 7), (t50, s50, 49)))]
+    cache = StepCache("cpu")
+    built = []
+    e = cache.entry(("k",), reqs, lambda: built.append(1) or ("cond",))
+    assert cache.entry(("k",), reqs, lambda: built.append(1) or ("x",)) is e and built == [1]
+    for it in range(3):
+        if it == 2:
+            reqs[2].step_index = 0            # the caller rewinds a request (bench.py keeps its batch full this way)
+        sig, sig_next, ts = cache.step_scalars(e, reqs)
+        for i, r in enumerate(reqs):
+            assert sig[i].item() == r.sigmas[r.step_index] and sig_next[i].item() == r.sigmas[r.step_index + 1]
+            assert ts[i].item() == r.timesteps[r.step_index]
+        lat = cache.latents(e, reqs)
+        assert [lat[i, 0, 0, 0].item() for i in range(3)] == [0.0, 1.0, 2.0]
+        if it > 0:
+            assert lat.data_ptr() == prev.data_ptr(), "latents buffer must be reused once the requests hold views of it"
+        prev = lat
+        for i, r in enumerate(reqs):
+            r.latents = lat[i:i + 1]
+            if it < 1 or i < 2:
+                r.step_index += 1
+        if it == 0:
+            reqs[2].step_index = 49           # stays at its last step (done() would retire it in the real loop)
+    reqs[0].step_index = 50
+    with pytest.raises(IndexError):
+        cache.step_scalars(e, reqs)
+
+
+def _validate_unet(l, pcfg, pw, batch, hw):
+    from sduss_amd import lib
+    cc = lib.UNetConfigC()
+    cc.in_channels, cc.out_channels, cc.n_levels, cc.layers_per_block = pcfg.in_channels, pcfg.out_channels, len(pcfg.block_out_channels), pcfg.layers_per_block
+    for i, v in enumerate(pcfg.block_out_channels):
+        cc.block_out_channels[i] = v; cc.down_has_attn[i] = int(pcfg.down_has_attn[i])
+        cc.transformer_layers[i] = pcfg.transformer_layers_per_block[i]; cc.num_heads[i] = pcfg.num_heads[i]
+    cc.cross_attention_dim, cc.addition_time_embed_dim = pcfg.cross_attention_dim, pcfg.addition_time_embed_dim
+    cc.projection_class_embeddings_input_dim, cc.norm_num_groups = pcfg.projection_class_embeddings_input_dim, pcfg.norm_num_groups
+    h = l.mx_unet_create(C.byref(cc))
+    assert h and l.mx_unet_set_weights(h, pw.blob.data_ptr(), pw.blob.numel(), pw.table, len(pw.names)) == 0
+    rc = l.mx_unet_validate(h, batch, hw, hw, 77)
+    msg = l.mx_last_error()
+    l.mx_unet_destroy(h)
+    return rc, msg
+
+
+def test_hf_layout_directories_load_into_the_step_plans(tmp_path):
+    """The calls INTEGRATION.md tells a maintainer to make: an HF-layout ``unet/`` and ``transformer/`` folder
+    (config.json in diffusers' key set + diffusion_pytorch_model.safetensors, model_loader.py:64-66) goes through
+    from_hf_json / load_safetensors_dir / pack into mx_*_validate.  A stray fp16 shard is ignored."""
+    import json
+    from safetensors.torch import save_file
+    from oracle import sd3_mmdit_ref as mref, sdxl_unet_ref as uref
+    from sduss_amd import config, lib, weights
+    l = lib.load()
+    # ---- unet/ ----
+    ocfg = uref.UNetConfig.tiny()
+    P = uref.init_params(ocfg)
+    pc = config.UNetConfig.tiny()
+    ud = tmp_path / "unet"; ud.mkdir()
+    hf = {"_class_name": "UNet2DConditionModel", "_diffusers_version": "0.32.1", "in_channels": pc.in_channels, "out_channels": pc.out_channels,
+          "block_out_channels": list(pc.block_out_channels), "layers_per_block": pc.layers_per_block,
+          "down_block_types": ["CrossAttnDownBlock2D" if a else "DownBlock2D" for a in pc.down_has_attn],
+          "up_block_types": ["CrossAttnUpBlock2D" if a else "UpBlock2D" for a in reversed(pc.down_has_attn)],
+          "attention_head_dim": list(pc.num_heads), "transformer_layers_per_block": list(pc.transformer_layers_per_block),
+          "cross_attention_dim": pc.cross_attention_dim, "addition_embed_type": "text_time", "addition_time_embed_dim": pc.addition_time_embed_dim,
+          "projection_class_embeddings_input_dim": pc.projection_class_embeddings_input_dim, "norm_num_groups": pc.norm_num_groups,
+          "norm_eps": 1e-5, "use_linear_projection": True, "sample_size": 128, "act_fn": "silu"}
+    (ud / "config.json").write_text(json.dumps(hf))
+    save_file({k: v.to(torch.float16).contiguous() for k, v in P.items()}, str(ud / "diffusion_pytorch_model.safetensors"))
+    save_file({"junk": torch.zeros(1)}, str(ud / "diffusion_pytorch_model.fp16.safetensors"))
+    cfg, params = weights.load_safetensors_dir(str(ud))
+    assert cfg == pc and set(params) == set(P)
+    rc, msg = _validate_unet(l, cfg, weights.PackedWeights(weights.pack(cfg, params), "cpu"), 2, 32)
+    assert rc == 0, msg
+    # ---- transformer/ ----
+    mo = mref.MMDiTConfig.tiny()
+    PM = mref.init_params(mo)
+    mc = config.MMDiTConfig.tiny()
+    td = tmp_path / "transformer"; td.mkdir()
+    hf = {"_class_name": "SD3Transformer2DModel", "sample_size": mc.sample_size, "patch_size": mc.patch_size, "in_channels": mc.in_channels,
+          "out_channels": mc.out_channels, "num_layers": mc.num_layers, "attention_head_dim": mc.attention_head_dim,
+          "num_attention_heads": mc.num_attention_heads, "joint_attention_dim": mc.joint_attention_dim,
+          "caption_projection_dim": mc.caption_projection_dim, "pooled_projection_dim": mc.pooled_projection_dim,
+          "pos_embed_max_size": mc.pos_embed_max_size, "dual_attention_layers": list(mc.dual_attention_layers), "qk_norm": "rms_norm"}
+    (td / "config.json").write_text(json.dumps(hf))
+    save_file({k: v.to(torch.float16).contiguous() for k, v in PM.items()}, str(td / "diffusion_pytorch_model.safetensors"))
+    cfg, params = weights.load_mmdit_safetensors_dir(str(td))
+    assert cfg == mc and set(params) == set(PM)
+    pw = weights.PackedWeights(weights.pack_mmdit(cfg, params), "cpu")
+    cc = lib.MMDiTConfigC()
+    cc.patch_size, cc.in_channels, cc.out_channels, cc.num_layers, cc.num_attention_heads = cfg.patch_size, cfg.in_channels, cfg.out_channels, cfg.num_layers, cfg.num_attention_heads
+    cc.joint_attention_dim, cc.pooled_projection_dim, cc.pos_embed_max_size, cc.norm_eps = cfg.joint_attention_dim, cfg.pooled_projection_dim, cfg.pos_embed_max_size, 1e-6
+    for i in cfg.dual_attention_layers:
+        cc.dual_attention[i] = 1
+    h = l.mx_mmdit_create(C.byref(cc))
+    assert h and l.mx_mmdit_set_weights(h, pw.blob.data_ptr(), pw.blob.numel(), pw.table, len(pw.names)) == 0
+    assert l.mx_mmdit_validate(h, 2, 16, 16, 37) == 0, l.mx_last_error()
+    l.mx_mmdit_destroy(h)
