@@ -30,6 +30,7 @@ struct GemmArgs {
   const float* rms_wq;   // MX_EPI_RMSNORM: per-head RMSNorm weights of the q / k segments
   const float* rms_wk;
   float rms_eps;
+  int stagger_ticks;   // experiment (gemm_bf16_v3.hip)
 };
 
 // row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)
@@ -336,7 +337,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
         }
         vv[i] = v;
       }
-      if (j + 1 < MI && (has_rb || has_gate)) load_batch_vectors(j + 1);
+        if (j + 1 < MI && (has_rb || has_gate)) load_batch_vectors(j + 1);
       if (qkv && w_to_vt) {
         if (m < p.M) {
           const int key0 = (p.c_batch_rows > 0 ? p.c_row_off : 0) + m - bidx * p.rows_per_batch;
@@ -404,6 +405,238 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&
       } else {
         const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + ro_col[k]) = o;
+      }
+    }
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Register-exchange epilogue of the 256-row kernels (round 2; replaces gemm_epilogue_staged in gemm_bf16_v2/v3.hip).
+//
+// The staged epilogue above costs ~15 us per 256 x 256 tile (8 slabs x {ds_write, barrier, ds_read, store}: 30 % of a
+// K = 1536 launch and > 40 % at the SDXL depths K = 640 / 1280, profiles/r01_e_gemm_component_removal.txt) with the
+// matrix pipe idle, and it occupies the LDS ring, so a persistent workgroup cannot keep its operand stream running.
+// Here the transpose happens in registers instead.  In the accumulator layout the four lane rows fq = lane >> 4 of a
+// 16-token block hold features 4 fq .. 4 fq + 3 of each 16-feature block.  For a PAIR of adjacent blocks (32 features)
+// two half-wave exchanges per register,
+//     v_permlane32_swap a, b   (lanes 32-63 of a <-> lanes 0-31 of b)
+//     v_permlane16_swap a, b   (odd 16-lane rows of a <-> even rows of b),
+// leave lane row q with the eight consecutive features 8 q .. 8 q + 7 of the pair: [a, b] of that lane.  A token's 32
+// features are then 4 lanes x 16 bytes = 64 contiguous bytes per store instruction (two instructions complete a
+// 128-byte line), and the residual is read the same way.  No LDS, no barrier: every wave streams its own rows, waves
+// that finish early move on, and the LDS ring keeps receiving the next tile's operands.
+//   * order of operations unchanged: bias -> (RMSNorm | out_scale) -> GEGLU | row bias -> gate (accumulator layout),
+//     exchange in fp32, residual -> SiLU / GELU-tanh -> one rounding -> store (row layout);
+//   * an odd block count (BN = 160: five blocks per wave) stores its last block from the accumulator layout (8 bytes per
+//     lane, 32 contiguous bytes per token);
+//   * MX_EPI_QKV: waves whose features fall in a V segment write V^T directly (2-byte stores along the key axis).
+// ----------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lane_exchange_pair(float (&a)[4], float (&b)[4]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    unsigned x = __float_as_uint(a[d]), y = __float_as_uint(b[d]);
+    auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    auto t = __builtin_amdgcn_permlane16_swap(r[0], r[1], false, false);
+    a[d] = __uint_as_float(t[0]);
+    b[d] = __uint_as_float(t[1]);
+  }
+}
+
+// VPF: per-sample vectors are loaded one token block ahead (costs 8 * NIO registers; off in the persistent 256 x 256 kernel)
+template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true>
+__device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
+                                                   const int fr, const int fq) {
+  constexpr int NIO = GEGLU ? NI / 2 : NI;     // output blocks per wave
+  constexpr int NP = NIO / 2;                  // exchanged pairs
+  constexpr bool ODD = (NIO & 1) != 0;         // a last block stored from the accumulator layout
+  constexpr int DEPTH = 2;                     // residual loads run this many token blocks ahead
+  static_assert(!GEGLU || NI % 4 == 0, "GEGLU: hidden and gate halves must be whole pairs");
+  const int flags = p.flags;
+  const bool qkv = (flags & MX_EPI_QKV) != 0;
+  int seg_idx = 0, seg_grp = 0, seg_pos = 0;
+  bool to_vt = false;
+  if (qkv) {                                   // the wave's feature range lies inside one segment (seg % (16 NI) == 0)
+    seg_idx = wave_n0 / p.seg;
+    seg_grp = seg_idx / p.period;
+    seg_pos = seg_idx - seg_grp * p.period;
+    to_vt = seg_pos == p.period - 1;
+  }
+  const bool rms = qkv && (flags & MX_EPI_RMSNORM) && !to_vt;
+  const float w_scale = (!rms && p.out_scale != 0.f && (!qkv || seg_pos == 0)) ? p.out_scale : 1.0f;
+  // first output column of the wave
+  const int col0 = GEGLU ? wave_n0 / 2 : qkv ? seg_grp * (p.period - 1) * p.seg + seg_pos * p.seg + (wave_n0 - seg_idx * p.seg) : wave_n0;
+  const bool has_res = !GEGLU && p.residual != nullptr;
+  const bool has_rb = VEC && !GEGLU && p.rowbias != nullptr, has_gate = VEC && !GEGLU && p.gate != nullptr;
+  const bool f32out = (flags & MX_EPI_OUT_F32) != 0;
+
+  f32x4 bias_r[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    bias_r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && (GEGLU || i < NIO)) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + wave_n0 + i * 16 + fq * 4);
+  }
+  f32x4 rmsw_r[NI];                            // RMSNorm weight of the lane's features (one 64-wide head per wave)
+  if (rms) {
+    const float* w = seg_pos == 0 ? p.rms_wq : p.rms_wk;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) rmsw_r[i] = *reinterpret_cast<const f32x4*>(w + ((wave_n0 - seg_idx * p.seg + i * 16 + fq * 4) & 63));
+  }
+
+  // row addressing of token block j: accumulator layout (token = lane & 15) and row layout are the same token
+  auto token = [&](int j) __attribute__((always_inline)) { return m_wave0 + j * 16 + fr; };
+  auto load_res = [&](int j, int pr) __attribute__((always_inline)) -> u32x4 {
+    const int m = token(j);
+    if (!has_res || m >= p.M) return u32x4{0u, 0u, 0u, 0u};
+    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
+    const long rrow = (flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
+    return *reinterpret_cast<const u32x4*>(p.residual + rrow * p.ldr + col0 + pr * 32 + fq * 8);
+  };
+  auto load_res_odd = [&](int j) __attribute__((always_inline)) -> u32x2 {
+    const int m = token(j);
+    if (!has_res || m >= p.M) return u32x2{0u, 0u};
+    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
+    const long rrow = (flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
+    return *reinterpret_cast<const u32x2*>(p.residual + rrow * p.ldr + col0 + NP * 32 + fq * 4);
+  };
+  // per-sample vectors (row bias of the time embedding, AdaLN gate) of the lane's token: one token block ahead
+  f32x4 rb_r[VEC ? NIO : 1], gate_r[VEC ? NIO : 1];
+  auto load_batch_vectors = [&](int j) __attribute__((always_inline)) {
+    if constexpr (VEC) {
+      const int m = token(j);
+      const int mc = m < p.M ? m : p.M - 1;
+      const int bidx = (p.rows_per_batch > 0) ? (mc / p.rows_per_batch) : 0;
+#pragma unroll
+      for (int i = 0; i < NIO; ++i) {
+        const int n = wave_n0 + i * 16 + fq * 4;
+        if (has_rb) rb_r[i] = *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ldrb + n);
+        if (has_gate) gate_r[i] = *reinterpret_cast<const f32x4*>(p.gate + (long)bidx * p.ldg + n);
+      }
+    }
+  };
+  if constexpr (VPF) { if (has_rb || has_gate) load_batch_vectors(0); }
+  u32x4 res_r[DEPTH][NP > 0 ? NP : 1];
+  u32x2 res_o[DEPTH];
+  if (!(qkv && to_vt)) {
+#pragma unroll
+    for (int d = 0; d < DEPTH && d < MI; ++d) {
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) res_r[d][pr] = load_res(d, pr);
+      if constexpr (ODD) res_o[d] = load_res_odd(d);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = token(j);
+    const int mc = m < p.M ? m : p.M - 1;
+    const int bidx = (p.rows_per_batch > 0) ? (mc / p.rows_per_batch) : 0;
+    // ---- accumulator layout: bias, RMSNorm / scale, GEGLU, per-sample vectors ----
+    float v[NIO][4];
+    float rms_mul = 1.0f;
+    if constexpr (!VPF) { if (has_rb || has_gate) load_batch_vectors(j); }
+    if (rms) {                                 // every lane takes part in the shuffles (masking happens at the store)
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float t = acc[i][j][q] + bias_r[i][q]; ss += t * t; }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      rms_mul = rsqrtf(ss * (1.0f / 64.0f) + p.rms_eps) * ((seg_pos == 0 && p.out_scale != 0.f) ? p.out_scale : 1.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < NIO; ++i) {
+      f32x4 t = acc[i][j] + bias_r[i];
+      if constexpr (GEGLU) {
+        const f32x4 g = acc[i + NI / 2][j] + bias_r[i + NI / 2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = t[q] * gelu_fast(g[q]);
+      } else {
+        if (rms) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[q] *= rms_mul * rmsw_r[i][q];
+        } else {
+          t *= w_scale;
+        }
+        if constexpr (VEC) {
+          if (has_rb) t += rb_r[i];
+          if (has_gate) t *= gate_r[i];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[i][q] = t[q];
+    }
+    if constexpr (VPF) { if (j + 1 < MI && (has_rb || has_gate)) load_batch_vectors(j + 1); }
+    if (qkv && to_vt) {                        // V^T: keys along the lanes, 2-byte stores (see gemm_epilogue)
+      if (m < p.M) {
+        const int key0 = (p.c_batch_rows > 0 ? p.c_row_off : 0) + m - bidx * p.rows_per_batch;
+        const int key = MX_VT_POS(key0);
+        const int nv = p.N / p.period;
+#pragma unroll
+        for (int i = 0; i < NIO; ++i) {
+          const int nin = wave_n0 + i * 16 + fq * 4 - seg_idx * p.seg;
+          bf16_t* dst = p.vt + ((long)bidx * nv + (long)seg_grp * p.seg + nin) * p.ldvt + key;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[(long)q * p.ldvt] = f32_to_bf16(v[i][q]);
+        }
+      }
+      continue;
+    }
+    const long orow = gemm_out_row(p, mc, bidx);
+    // ---- pairs of blocks: exchange, then residual -> activation -> store in the row layout ----
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+      lane_exchange_pair(v[2 * pr], v[2 * pr + 1]);
+      float o[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o[q] = v[2 * pr][q]; o[4 + q] = v[2 * pr + 1][q]; }
+      const u32x4 rr = res_r[j % DEPTH][pr];
+      if (j + DEPTH < MI) res_r[j % DEPTH][pr] = load_res(j + DEPTH, pr);
+      if (has_res) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[2 * q] += bf16lo_to_f32(rr[q]); o[2 * q + 1] += bf16hi_to_f32(rr[q]); }
+      }
+      if (flags & MX_EPI_SILU) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
+      }
+      if (flags & MX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = gelu_tanh_f(o[q]);
+      }
+      if (m < p.M) {
+        const int col = col0 + pr * 32 + fq * 8;
+        if (f32out) {
+          float* dst = reinterpret_cast<float*>(p.c) + orow * p.ldc + col;
+          *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        } else {
+          const u32x4 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = w;
+        }
+      }
+    }
+    // ---- odd last block: straight from the accumulator layout ----
+    if constexpr (ODD) {
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = v[NIO - 1][q];
+      const u32x2 rr = res_o[j % DEPTH];
+      if (j + DEPTH < MI) res_o[j % DEPTH] = load_res_odd(j + DEPTH);
+      if (has_res) { o[0] += bf16lo_to_f32(rr[0]); o[1] += bf16hi_to_f32(rr[0]); o[2] += bf16lo_to_f32(rr[1]); o[3] += bf16hi_to_f32(rr[1]); }
+      if (flags & MX_EPI_SILU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = silu_f(o[q]);
+      }
+      if (flags & MX_EPI_GELU_TANH) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = gelu_tanh_f(o[q]);
+      }
+      if (m < p.M) {
+        const int col = col0 + NP * 32 + fq * 4;
+        if (f32out) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + orow * p.ldc + col) = f32x4{o[0], o[1], o[2], o[3]};
+        else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
       }
     }
   }

@@ -226,6 +226,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   MX_CHECK(d->K % BK == 0, "gemm: K must be a multiple of 64");
   MX_CHECK(d->N % 4 == 0, "gemm: N must be a multiple of 4");
   GemmArgs a;
+  a.stagger_ticks = 0;
   a.a = (const bf16_t*)d->a; a.w = (const bf16_t*)d->w; a.c = d->c;
   a.bias = d->bias; a.rowbias = d->rowbias; a.residual = (const bf16_t*)d->residual; a.vt = (bf16_t*)d->vt;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldrb = d->ldrb;

@@ -279,15 +279,13 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       if (t == 12345.678f) reinterpret_cast<bf16_t*>(p.c)[m0 + n0] = f32_to_bf16(t);
     }
 #else
-    // every DMA has landed and every wave has left the K loop: the ring becomes the epilogue's transpose buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float* slab = reinterpret_cast<float*>(smem);
+    // register-exchange epilogue (gemm_args.h): no LDS, no barrier; the past-the-end DMAs are drained before the workgroup retires
     if (p.flags & MX_EPI_GEGLU) {
-      if constexpr (BN % 64 == 0 && !CONV) gemm_epilogue_staged<NI, MI, 4, 2, true>(p, acc, slab, slab + 64 * (BN / 2), m0, n0, wm, wn, fr, fq, tid);
+      if constexpr (NI % 4 == 0 && !CONV) gemm_epilogue_regs<NI, MI, true>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq);
     } else {
-      gemm_epilogue_staged<NI, MI, 4, 2, false>(p, acc, slab, slab + 64 * BN, m0, n0, wm, wn, fr, fq, tid);
+      gemm_epilogue_regs<NI, MI, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   }
 }

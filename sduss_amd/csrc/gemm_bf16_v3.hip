@@ -36,6 +36,14 @@
 
 namespace mx {
 
+#if MX_EXP == 7   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime) per workgroup and tile, read back by tools/exp/stamps_v3.py
+__device__ unsigned long long g_v3_stamps[256 * 2 * 64];
+#define MX_STAMP(slot) do { if (lane == 0 && (wave == 0 || wave == 7) && (slot) < 64) \
+    g_v3_stamps[(blockIdx.x * 2 + (wave == 7)) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MX_STAMP(slot) do {} while (0)
+#endif
+
 constexpr int BM3 = 256;
 constexpr int BN3 = 256;
 constexpr int BK3 = 64;
@@ -55,6 +63,7 @@ __device__ __forceinline__ void glds16_3(const void* gsrc, void* lds_dst) {
 // persistent tile stream.
 template <bool VEC>
 __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
+  constexpr bool PERSIST = true;               // one workgroup per CU walks its tiles (round 2: also the per-sample-vector variant)
   constexpr int NI = 4;                        // 16-wide feature blocks per wave (64 features)
   constexpr int MI = 8;                        // 16-wide token blocks per wave (128 tokens)
   constexpr int XI = BM3 * 8 / 512;            // X DMA instructions per thread per K tile (4)
@@ -119,8 +128,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
     if (x_tile >= total_tiles) return;         // parked
     if (++x_kt == nk) {                        // on to the workgroup's next tile, or past the end of the stream
       x_kt = 0;
-      x_tile = VEC ? total_tiles : x_tile + (int)gridDim.x;     // the VEC variant runs one tile per workgroup
-      if constexpr (!VEC) {
+      x_tile = !PERSIST ? total_tiles : x_tile + (int)gridDim.x;
+      if constexpr (PERSIST) {
         if (x_tile < total_tiles) { setup_x(x_tile); return; }
       }
 #pragma unroll
@@ -134,8 +143,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
     if (w_tile >= total_tiles) return;
     if (++w_kt == nk) {
       w_kt = 0;
-      w_tile = VEC ? total_tiles : w_tile + (int)gridDim.x;
-      if constexpr (!VEC) {
+      w_tile = !PERSIST ? total_tiles : w_tile + (int)gridDim.x;
+      if constexpr (PERSIST) {
         if (w_tile < total_tiles) { setup_w(w_tile); return; }
       }
 #pragma unroll
@@ -155,14 +164,21 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
 #pragma unroll                                 // block of 16 rows: the swizzle depends on (row >> 1) & 7 = (fr >> 1) & 7
   for (int ks = 0; ks < 2; ++ks) koff[ks] = swz3(fr, ks * 4 + fq) * 8;
 
+  if (p.stagger_ticks > 0) {                   // EXPERIMENT: XCD x (= blockIdx % 8) starts x/8 of a tile period late
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long want = (unsigned long long)p.stagger_ticks * (blockIdx.x & 7) / 8;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < want) __builtin_amdgcn_s_sleep(32);
+  }
   setup_x(x_tile);
   setup_w(w_tile);
   issue_x(0); advance_x();                     // X(0) -> slot 0, W(0) -> slot 1, X(1) -> slot 2
   issue_w(1); advance_w();
   issue_x(2); advance_x();
 
+  MX_STAMP(0);
+  [[maybe_unused]] int stamp_i = 1;
   int xs = 0;                                  // slot of the X half-tile being read = (2 g) % 5 for stream position g; W follows
-  for (int tile = blockIdx.x; tile < total_tiles; tile += (VEC ? total_tiles : (int)gridDim.x)) {
+  for (int tile = blockIdx.x; tile < total_tiles; tile += (!PERSIST ? total_tiles : (int)gridDim.x)) {
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -174,6 +190,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
       // LDS (vmcnt retires in order: epilogue stores of the previous tile only make the wait more conservative)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#if MX_EXP == 7
+      if (kt == 0) { MX_STAMP(stamp_i); }
+#endif
       const int ws = xs == NSLOT - 1 ? 0 : xs + 1;
       const int f0 = ws == NSLOT - 1 ? 0 : ws + 1;           // slot of the next X half-tile, in flight
       const int f1 = f0 == NSLOT - 1 ? 0 : f0 + 1;           // the two slots read in the previous iteration (or used by the
@@ -226,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
       xs = f0;
     }
 
+    MX_STAMP(stamp_i + 1);
     int tm, tn;
     gemm_tile_of_block(tile, mt, nt, p.xcd_map, tm, tn);
     const int m0 = tm * BM3, n0 = tn * BN3;
@@ -236,17 +256,15 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
       if (t == 12345.678f) reinterpret_cast<bf16_t*>(p.c)[m0 + n0] = f32_to_bf16(t);
     }
 #else
-    // Every wave has left the K loop.  The two slots read in its last iteration are free -- the three others hold the first
-    // half-tiles of the workgroup's next tile, still landing -- and become the two transpose buffers of the epilogue.
-    __syncthreads();
-    const int s_w = xs == 0 ? NSLOT - 1 : xs - 1;            // W slot of the last iteration
-    const int s_x = s_w == 0 ? NSLOT - 1 : s_w - 1;          // X slot of the last iteration
-    float* slab0 = reinterpret_cast<float*>(smem + s_x * SLOT_ELEMS);
-    float* slab1 = reinterpret_cast<float*>(smem + s_w * SLOT_ELEMS);
-    if (p.flags & MX_EPI_GEGLU) gemm_epilogue_staged<NI, MI, 2, 4, true, VEC>(p, acc, slab0, slab1, m0, n0, wm, wn, fr, fq, tid);
-    else gemm_epilogue_staged<NI, MI, 2, 4, false, VEC>(p, acc, slab0, slab1, m0, n0, wm, wn, fr, fq, tid);
+    // Register-exchange epilogue (gemm_args.h): no LDS, no barrier.  The ring keeps receiving the first half-tiles of the
+    // workgroup's next tile meanwhile; a wave that finishes early waits at the next K loop's first barrier, behind which
+    // the slots its slower siblings are still reading get re-issued.
+    if (p.flags & MX_EPI_GEGLU) gemm_epilogue_regs<NI, MI, true, VEC, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq);
+    else gemm_epilogue_regs<NI, MI, false, VEC, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq);
+    MX_STAMP(stamp_i + 2);
+    stamp_i += 3;
     // the cursors' per-thread offsets are recomputed from (tile, K tile) rather than kept in registers across the epilogue
-    if constexpr (!VEC) {
+    if constexpr (PERSIST) {
     if (x_tile < total_tiles) {
       setup_x(x_tile);
 #pragma unroll
@@ -265,10 +283,16 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
     }
     }
 #endif
-    if constexpr (VEC) break;                          // one tile per workgroup: no loop-carried state for the register allocator
+    if constexpr (!PERSIST) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end DMAs before the workgroup retires
 }
+
+#if MX_EXP == 7
+extern "C" int mx_debug_v3_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v3_stamps), sizeof(g_v3_stamps));
+}
+#endif
 
 int launch_v3(hipStream_t s, const GemmArgs& a) {
   static const int ncu = [] {
@@ -282,12 +306,12 @@ int launch_v3(hipStream_t s, const GemmArgs& a) {
   static const bool persist = [] { const char* e = getenv("MX_V3_PERSIST"); return !(e && e[0] == '0'); }();
   const int tiles = cdiv(a.M, BM3) * (a.N / BN3);
   dim3 block(512);
-  if (a.rowbias || a.gate) {                    // per-sample vectors: the full epilogue has no registers to spare, one tile per workgroup
-    hipLaunchKernelGGL(gemm_v3_kernel<true>, dim3(tiles), block, 0, s, a);
-  } else {
-    // more tiles than CUs: one workgroup per CU walks its tiles as one DMA stream (the next tile's operands fly during the epilogue)
-    hipLaunchKernelGGL(gemm_v3_kernel<false>, dim3(persist && tiles > ncu && ncu > 0 ? ncu : tiles), block, 0, s, a);
-  }
+  // more tiles than CUs: one workgroup per CU walks its tiles as one DMA stream (the next tile's operands fly during the epilogue)
+  const dim3 grid(persist && tiles > ncu && ncu > 0 ? ncu : tiles);
+  static const int stagger = [] { const char* e = getenv("MX_V3_STAGGER_US"); return e ? (int)(atof(e) * 100.0) : 0; }();   // 100 MHz ticks
+  GemmArgs a2 = a; a2.stagger_ticks = stagger;
+  if (a.rowbias || a.gate) hipLaunchKernelGGL(gemm_v3_kernel<true>, grid, block, 0, s, a2);    // per-sample vectors compiled in
+  else hipLaunchKernelGGL(gemm_v3_kernel<false>, grid, block, 0, s, a2);
   return 0;
 }
 
