@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
 int launch_v3(hipStream_t s, const GemmArgs& a);
+int launch_v4(hipStream_t s, const GemmArgs& a);
 
 // Tile choice for the pipelined kernels.  Candidates (token rows x features): 256x256 (gemm_bf16_v3.hip), 256x160, 256x128,
 // 128x160, 128x128 (gemm_bf16_v2.hip).  Estimated cost = full-chip rounds of 256 workgroups (one per CU) x (rows + features):
@@ -298,8 +299,9 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     const int kind = v2bn == 256 ? PROF_GEMM_V3_256 : v2bn ? (conv ? PROF_CONV_V2_160 : PROF_GEMM_V2_160) + (v2bn == 160 ? 0 : 2) : (conv ? PROF_CONV128 : PROF_GEMM128) + (use128 ? 0 : 1);
     prof_begin(s, kind, flops, bytes, d->M, d->N, (int)kk);
   }
+  static const bool use_v4 = [] { const char* e = getenv("MX_GEMM_V4"); return !(e && e[0] == '0'); }();   // 8-phase ping-pong (gemm_bf16_v4.hip)
   if (v2bn == 256) {
-    launch_v3(s, a);
+    if (use_v4) launch_v4(s, a); else launch_v3(s, a);
   } else if (v2bn) {
     launch_v2(s, a, conv, v2bn, tc.rows);
   } else if (use128) {
