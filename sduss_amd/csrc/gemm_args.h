@@ -443,6 +443,14 @@ __device__ __forceinline__ void lane_exchange_pair(float (&a)[4], float (&b)[4])
   }
 }
 
+// neighbour-lane exchange (lane ^ 1) of a 16-byte value: DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ u32x4 lane_xor1(const u32x4 x) {
+  u32x4 r;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) r[d] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[d], 0xB1, 0xF, 0xF, true);
+  return r;
+}
+
 // VPF: per-sample vectors are loaded one token block ahead (costs 8 * NIO registers; off in the persistent 256 x 256 kernel)
 template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true>
 __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
@@ -468,7 +476,6 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   const int col0 = GEGLU ? wave_n0 / 2 : qkv ? seg_grp * (p.period - 1) * p.seg + seg_pos * p.seg + (wave_n0 - seg_idx * p.seg) : wave_n0;
   const bool has_res = !GEGLU && p.residual != nullptr;
   const bool has_rb = VEC && !GEGLU && p.rowbias != nullptr, has_gate = VEC && !GEGLU && p.gate != nullptr;
-  const bool f32out = (flags & MX_EPI_OUT_F32) != 0;
 
   f32x4 bias_r[NI];
 #pragma unroll
@@ -515,13 +522,32 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
     }
   };
   if constexpr (VPF) { if (has_rb || has_gate) load_batch_vectors(0); }
+  // FULL-LINE form (bf16 output, two pairs at a time).  After the pair exchange the two lanes of a lane pair (tokens T, T + 1)
+  // swap one pair each, so that instruction A writes token T -- the even lane its first pair, the odd lane token T's second
+  // pair: 8 lanes x 16 B = 128 contiguous bytes per token -- and instruction B writes token T + 1.  Measured 2.7x the per-CU
+  // store rate of 64-byte row pieces (profiles/r02_a_dma_stream_and_store_microbench.txt).  The residual is read the same way.
+  constexpr int NG = NP / 2;                   // groups of two pairs
+  constexpr bool fullmode = NG > 0;     // (fp32 output is served by the generic kernel: pick_tile)
+  const bool odd_lane = (fr & 1) != 0;
+  // slot 2g of a group: (token A = even token of the lane pair, this lane's column pair); slot 2g + 1: (token B = odd token, same pair)
+  auto load_res_full = [&](int j, int g, int which) __attribute__((always_inline)) -> u32x4 {
+    const int m = (token(j) & ~1) + which;
+    if (!has_res || m >= p.M) return u32x4{0u, 0u, 0u, 0u};
+    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
+    const long rrow = (flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
+    return *reinterpret_cast<const u32x4*>(p.residual + rrow * p.ldr + col0 + (2 * g + (odd_lane ? 1 : 0)) * 32 + fq * 8);
+  };
+  auto load_res_any = [&](int j, int pr) __attribute__((always_inline)) -> u32x4 {
+    if (pr < 2 * NG) return load_res_full(j, pr >> 1, pr & 1);
+    return load_res(j, pr);
+  };
   u32x4 res_r[DEPTH][NP > 0 ? NP : 1];
   u32x2 res_o[DEPTH];
   if (!(qkv && to_vt)) {
 #pragma unroll
     for (int d = 0; d < DEPTH && d < MI; ++d) {
 #pragma unroll
-      for (int pr = 0; pr < NP; ++pr) res_r[d][pr] = load_res(d, pr);
+      for (int pr = 0; pr < NP; ++pr) res_r[d][pr] = load_res_any(d, pr);
       if constexpr (ODD) res_o[d] = load_res_odd(d);
     }
   }
@@ -585,14 +611,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
     }
     const long orow = gemm_out_row(p, mc, bidx);
     // ---- pairs of blocks: exchange, then residual -> activation -> store in the row layout ----
-#pragma unroll
-    for (int pr = 0; pr < NP; ++pr) {
-      lane_exchange_pair(v[2 * pr], v[2 * pr + 1]);
-      float o[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { o[q] = v[2 * pr][q]; o[4 + q] = v[2 * pr + 1][q]; }
-      const u32x4 rr = res_r[j % DEPTH][pr];
-      if (j + DEPTH < MI) res_r[j % DEPTH][pr] = load_res(j + DEPTH, pr);
+    auto finish8 = [&](float (&o)[8], const u32x4 rr) __attribute__((always_inline)) {
       if (has_res) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o[2 * q] += bf16lo_to_f32(rr[q]); o[2 * q + 1] += bf16hi_to_f32(rr[q]); }
@@ -605,16 +624,58 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = gelu_tanh_f(o[q]);
       }
+    };
+    if constexpr (fullmode) {
+      // rows of the lane pair's two tokens
+      const int mp = m ^ 1;
+      const int mpc = mp < p.M ? mp : p.M - 1;
+      const int bp = (p.rows_per_batch > 0) ? (mpc / p.rows_per_batch) : 0;
+      const long prow = gemm_out_row(p, mpc, bp);
+      const long row_a = odd_lane ? prow : orow, row_b = odd_lane ? orow : prow;
+      const bool ok_a = (m & ~1) < p.M, ok_b = (m | 1) < p.M;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        lane_exchange_pair(v[4 * g], v[4 * g + 1]);
+        lane_exchange_pair(v[4 * g + 2], v[4 * g + 3]);
+        float oa[8], ob[8];                      // (own token, pair 2g), (own token, pair 2g + 1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { oa[q] = v[4 * g][q]; oa[4 + q] = v[4 * g + 1][q]; ob[q] = v[4 * g + 2][q]; ob[4 + q] = v[4 * g + 3][q]; }
+        const u32x4 ra = res_r[j % DEPTH][2 * g], rb = res_r[j % DEPTH][2 * g + 1];     // (token A, my pair), (token B, my pair)
+        if (j + DEPTH < MI) { res_r[j % DEPTH][2 * g] = load_res_full(j + DEPTH, g, 0); res_r[j % DEPTH][2 * g + 1] = load_res_full(j + DEPTH, g, 1); }
+        u32x4 res_a = ra, res_b = rb;
+        if (has_res) {
+          // even lane: ra = (T, pair 2g) is its own; it lacks (T, pair 2g + 1) = the odd lane's ra.  Odd lane: rb = (T + 1, pair 2g + 1)
+          // is its own; it lacks (T + 1, pair 2g) = the even lane's rb.
+          const u32x4 got = lane_xor1(odd_lane ? ra : rb);
+          res_a = odd_lane ? got : ra;
+          res_b = odd_lane ? rb : got;
+        }
+        finish8(oa, res_a);
+        finish8(ob, res_b);
+        const u32x4 wa = {pack_bf16x2(oa[0], oa[1]), pack_bf16x2(oa[2], oa[3]), pack_bf16x2(oa[4], oa[5]), pack_bf16x2(oa[6], oa[7])};
+        const u32x4 wb = {pack_bf16x2(ob[0], ob[1]), pack_bf16x2(ob[2], ob[3]), pack_bf16x2(ob[4], ob[5]), pack_bf16x2(ob[6], ob[7])};
+        // even lane gives away its second pair and receives the odd token's first pair; the odd lane the other way round
+        const u32x4 got = lane_xor1(odd_lane ? wa : wb);
+        const u32x4 st_a = odd_lane ? got : wa;      // token A (even): even lane pair 2g, odd lane pair 2g + 1
+        const u32x4 st_b = odd_lane ? wb : got;      // token B (odd)
+        const int col = col0 + (2 * g + (odd_lane ? 1 : 0)) * 32 + fq * 8;
+        if (ok_a) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + row_a * p.ldc + col) = st_a;
+        if (ok_b) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + row_b * p.ldc + col) = st_b;
+      }
+    }
+#pragma unroll
+    for (int pr = 2 * NG; pr < NP; ++pr) {
+      lane_exchange_pair(v[2 * pr], v[2 * pr + 1]);
+      float o[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o[q] = v[2 * pr][q]; o[4 + q] = v[2 * pr + 1][q]; }
+      const u32x4 rr = res_r[j % DEPTH][pr];
+      if (j + DEPTH < MI) res_r[j % DEPTH][pr] = load_res(j + DEPTH, pr);
+      finish8(o, rr);
       if (m < p.M) {
         const int col = col0 + pr * 32 + fq * 8;
-        if (f32out) {
-          float* dst = reinterpret_cast<float*>(p.c) + orow * p.ldc + col;
-          *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
-          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
-        } else {
-          const u32x4 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = w;
-        }
+        const u32x4 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = w;
       }
     }
     // ---- odd last block: straight from the accumulator layout ----
@@ -635,8 +696,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       }
       if (m < p.M) {
         const int col = col0 + NP * 32 + fq * 4;
-        if (f32out) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + orow * p.ldc + col) = f32x4{o[0], o[1], o[2], o[3]};
-        else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
       }
     }
   }

@@ -194,6 +194,7 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   static const double v3_discount = [] { const char* e = getenv("MX_V3_DISCOUNT"); return e ? atof(e) : 0.87; }();
   const TileChoice none = {0, 0};
   if (disabled || d->M < 128 || d->K < 128) return none;
+  if (d->flags & MX_EPI_OUT_F32) return none;     // the register-exchange epilogue of the 256-row kernels writes bf16 only
   // their LDS-staged epilogue moves 16-byte pieces of C and of the residual
   if (d->ldc % 8 != 0 || ((uintptr_t)d->c & 15) != 0) return none;
   if (d->residual && (d->ldr % 8 != 0 || ((uintptr_t)d->residual & 15) != 0)) return none;

@@ -1,36 +1,39 @@
-// bf16 MFMA GEMM, 256 x 256 output tile, EIGHT-PHASE PING-PONG schedule (round 2).  Same math, orientation, swizzle and
-// epilogue as gemm_bf16_v3.hip; what changes is how the eight waves share a CU.
+// bf16 MFMA GEMM, 256 x 256 output tile, PING-PONG schedule of the two wave rows (round 2).  Same math, orientation,
+// swizzle and epilogue as gemm_bf16_v3.hip; what changes is how the eight waves share a CU.
 //
 // Why.  Measured in round 2 (profiles/r02_a_dma_stream_and_store_microbench.txt): the L2 -> LDS operand stream alone delivers a
 // 64-KB K tile in 0.73-0.79 us (83-90 GB/s per CU) and its 64 MFMAs per wave need ~1.0 us of matrix-pipe time, but the
 // one-barrier-per-K-tile loop of gemm_v3 takes 1.48 us: all eight waves wait, pass the barrier together, read their 24
 // fragments together (LDS saturated, matrix pipe idle), then compete for the matrix pipe together.  Here the two wave rows
-// run the SAME program one barrier apart (cdna guide "The 256^2 8-phase template"), so that on every SIMD one wave is in a
-// matrix segment (16 MFMAs on register operands) while its partner reads fragments from LDS and issues LDS-DMA:
+// run the SAME program one barrier apart (after the cdna guide's "256^2 8-phase template"), so that on every SIMD one wave
+// is in a matrix segment (MFMAs on register operands only) while its partner reads fragments and issues LDS-DMA:
 //
-//   per K tile, per wave:   L1 | M1 | L2 | M2 | L3 | M3 | L4 | M4        (| = s_barrier; rows wm = 1 lag by one barrier)
-//     L1  read W sub-tile 0 (4 x ds_read_b128) and X sub-tile 0 (8)       M1  acc[W0, X0] += ...   (16 MFMA = one C quadrant x K 64)
-//     L2  read W sub-tile 1 (4)                                           M2  acc[W1, X0]
-//     L3  read X sub-tile 1 (8, into X0's registers)                      M3  acc[W1, X1]
-//     L4  counted s_waitcnt vmcnt(4)                                      M4  acc[W0, X1]
-//   each L segment also issues one 16-KB half-tile of the operand stream (2 LDS-DMA instructions per thread).
+//   per K tile, per wave:   LA | MA | LB | MB          (| = s_barrier; wave row 1 lags row 0 by one barrier)
+//     LA  read W sub-tiles 0, 1 (8 x ds_read_b128) and X sub-tile 0 (8); issue 2 half-tiles of the operand stream
+//     MA  32 MFMA: acc[W0, X0], acc[W1, X0]
+//     LB  read X sub-tile 1 (8, into X0's registers); issue 2 half-tiles; one counted s_waitcnt vmcnt(4)
+//     MB  32 MFMA: acc[W1, X1], acc[W0, X1]
+//   A first form with 16-MFMA segments (four per K tile, eight barriers) was correct but only 3 % faster than gemm_v3: its
+//   ablation builds (tools/exp/build_v4_variants.sh) showed ~150 cycles of barrier + bookkeeping and ~200 cycles of fragment
+//   reads + LDS-DMA issue per 256-cycle matrix segment, i.e. the partner's L segment was the longer one.  32-MFMA segments halve
+//   the barriers and give the L segments 512 cycles of cover; the loader's control flow is peeled out of the hot loop.
 //
 //   * tile 256 tokens x 256 features x BK 64; 512 threads = 8 waves as 2 (tokens) x 4 (features); a wave owns 128 x 64 outputs
-//     (32 accumulator blocks of v_mfma_f32_16x16x32_bf16, 128 VGPRs), walked as four 64 x 32 quadrants in snake order so every
-//     L segment loads at most one new register sub-tile (X 32 VGPRs, W0 / W1 16 each);
-//   * LDS: two K-tile buffers x four half-tiles of 16 KB = 128 KB.  Half-tile XH[q] holds, for BOTH wave rows, token sub-range q
-//     of the wave's 128 tokens; WH[h] holds feature sub-range h of all four wave columns' 64 features -- so segment L1 needs
-//     only XH[0] + WH[0], L2 WH[1], L3 XH[1].  This is a loader-side row permutation (the per-lane DMA source address); waves keep
-//     contiguous 128-token x 64-feature output blocks, so the epilogue and the GEGLU / QKV / RMSNorm pairings are unchanged;
-//   * operand stream: half-tiles of stream position t + 2 are issued during K tiles t and t + 1 (XH0 in L3, WH0 in L4, WH1 in the
-//     next L1, XH1 in the next L2): each lands in a buffer region whose last fragment read completed at least two barriers
-//     earlier for BOTH wave rows, and one counted wait per K tile (vmcnt(4) in L4: everything but the two youngest half-tiles)
-//     followed by two barriers orders the landing before the first read (cdna guide "Read a staged buffer one phase AFTER
-//     the wait that retires it" with the extra barrier for staggered wave groups);
+//     (32 accumulator blocks of v_mfma_f32_16x16x32_bf16, 128 VGPRs); register sub-tiles: X 32 VGPRs, W0 / W1 16 each;
+//   * half-tiles (16 KB = 128 rows x 64 k): XH[q] holds, for BOTH wave rows, token sub-range q of the wave's 128 tokens; WH[h]
+//     holds feature sub-range h of all four wave columns' 64 features -- so LA needs XH0, WH0, WH1 and LB needs XH1.  This is a
+//     loader-side row permutation (the per-lane DMA source address); waves keep contiguous 128-token x 64-feature output blocks,
+//     so the epilogue and the GEGLU / QKV / RMSNorm pairings are unchanged;
+//   * LDS = a ring of TEN half-tile slots (all 160 KB); the stream order is XH0 WH0 WH1 XH1 per K tile, half-tile s lives in
+//     slot s mod 10.  LA of K tile t issues WH1, XH1 of tile t + 1 and LB issues XH0, WH0 of tile t + 2: each DMA lands in a slot
+//     whose last fragment read completed at least two barriers earlier for BOTH wave rows, and the wait in LB (all but the two
+//     youngest half-tiles) plus the two barriers before the next LA order landing before reading (cdna guide: "Read a staged
+//     buffer one phase AFTER the wait that retires it", one barrier more for staggered wave groups);
 //   * persistent: one workgroup per CU walks tiles t, t + grid, ...; the stream runs on into the next tile; the epilogue is the
 //     register-exchange one (gemm_args.h: no LDS, no barrier).  The two wave rows re-align for the epilogue (row 0 takes one
 //     extra barrier after the K loop, row 1 one before it).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "../../include/mxdenoise.h"
@@ -45,7 +48,8 @@ namespace mx {
 constexpr int BM4 = 256;
 constexpr int BN4 = 256;
 constexpr int BK4 = 64;
-constexpr int HT_ELEMS = 128 * BK4;            // one half-tile: 128 rows x 64 k = 16 KB
+constexpr int HT_BYTES = 128 * BK4 * 2;        // one half-tile: 128 rows x 64 k = 16 KB
+constexpr int NSLOT4 = 10;
 
 __device__ __forceinline__ int swz4(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
@@ -69,12 +73,31 @@ __device__ __forceinline__ f32x4 mx_mfma_stub(bf16x8 a, bf16x8 b, f32x4 c) { asm
 #else
 #define MX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
+#if MX_EXP == 2 || MX_EXP == 12 || MX_EXP == 23 || MX_EXP == 123
+#define MX_NO_DMA 1
+#else
+#define MX_NO_DMA 0
+#endif
+#if MX_EXP == 3 || MX_EXP == 13 || MX_EXP == 23 || MX_EXP == 123
+#define MX_NO_READS 1
+#else
+#define MX_NO_READS 0
+#endif
+
+#if MX_EXP == 7   // diagnostic build: shader-clock stamps per segment, summed over the K loop (tools/exp/stamps_v4.py)
+__device__ unsigned long long g_v4_sums[256 * 8 * 16];
+#define MX_T(k) asm volatile("s_memtime %0" : "=s"(tk[k]) :: "memory")        /* issued, NOT waited for */
+#define MX_TWAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define MX_T(k) do {} while (0)
+#define MX_TWAIT() do {} while (0)
+#endif
 
 template <bool VEC>
 __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
   constexpr int NI = 4;                        // 16-wide feature blocks per wave (64 features)
   constexpr int MI = 8;                        // 16-wide token blocks per wave (128 tokens)
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * HT_ELEMS];   // [buffer][XH0, XH1, WH0, WH1]
+  __shared__ __attribute__((aligned(16))) char smem[NSLOT4 * HT_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,11 +112,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
   const char* wbase = reinterpret_cast<const char*>(p.w);
   const int cs = tid & 7;
 
-  // ---- issue side: four cursors, one per half-tile kind, in stream order XH0, WH0, WH1, XH1.  Cursor c points at the next
-  //      (tile, K tile) of its kind and holds ready-made per-thread byte offsets (the chooser guarantees they fit 32 bits). ----
-  int c_tile[4], c_kt[4];
+  // ---- issue side: four cursors, one per half-tile kind (0 XH0, 1 WH0, 2 WH1, 3 XH1 = stream order inside a K tile).  Cursor c
+  //      points at the next (tile, K tile) of its kind, holds ready-made per-thread byte offsets (the chooser guarantees they fit
+  //      32 bits) and the ring slot of its next half-tile (stream index mod 10: + 4 per issue). ----
+  int c_tile[4], c_kt[4], c_slot[4];
   unsigned c_off[4][2];
-  unsigned c_buf = 0;                          // bit c: LDS buffer the cursor's next issue goes to
   auto setup = [&](const int c, const int t) __attribute__((always_inline)) {
     int tm, tn;
     gemm_tile_of_block(t, mt, nt, p.xcd_map, tm, tn);
@@ -113,15 +136,19 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
     }
   };
   auto issue = [&](const int c) __attribute__((always_inline)) {     // branch-free
-#if MX_EXP == 2 || MX_EXP == 12 || MX_EXP == 23 || MX_EXP == 123
-    if (c_kt[c] >= 0) { c_buf ^= 1u << c; return; }   // ablation: no LDS-DMA (results garbage)
-#endif
-    const int slot = c == 0 ? 0 : c == 3 ? 1 : c == 1 ? 2 : 3;
-    bf16_t* st = smem + (((c_buf >> c) & 1) * 4 + slot) * HT_ELEMS;
+#if !MX_NO_DMA
+    char* st = smem + c_slot[c] * HT_BYTES;
     const char* base = (c == 0 || c == 3) ? abase : wbase;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16_4(base + c_off[c][i], st + (i * 512 + wave * 64) * 8);
-    c_buf ^= 1u << c;
+    for (int i = 0; i < 2; ++i) glds16_4(base + c_off[c][i], st + (i * 512 + wave * 64) * 16);
+#endif
+    c_slot[c] = c_slot[c] >= NSLOT4 - 4 ? c_slot[c] - (NSLOT4 - 4) : c_slot[c] + 4;
+  };
+  // hot form: the cursor stays inside its tile (the caller guarantees it)
+  auto advance_hot = [&](const int c) __attribute__((always_inline)) {
+    ++c_kt[c];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c_off[c][i] += BK4 * 2;
   };
   auto advance = [&](const int c) __attribute__((always_inline)) {
     if (c_tile[c] >= total_tiles) return;      // parked
@@ -146,31 +173,33 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
     xrd[ks] = (unsigned)(((64 * wm + fr) * BK4 + swz4(fr, ks * 4 + fq) * 8) * 2);
     wrd[ks] = (unsigned)(((32 * wn + fr) * BK4 + swz4(fr, ks * 4 + fq) * 8) * 2);
   }
-  const char* sbase = reinterpret_cast<const char*>(smem);
-  auto read_x = [&](bf16x8 (&xf)[4][2], const int buf, const int q) __attribute__((always_inline)) {
-#if MX_EXP == 3 || MX_EXP == 13 || MX_EXP == 23 || MX_EXP == 123
-    asm volatile("" : "+v"(xf[0][0]), "+v"(xf[1][0]), "+v"(xf[2][0]), "+v"(xf[3][0])); return;   // ablation: no fragment reads
-#endif
-    const char* s = sbase + (buf * 4 + q) * (HT_ELEMS * 2);
+  auto read_x = [&](bf16x8 (&xf)[4][2], const int slot) __attribute__((always_inline)) {
+#if MX_NO_READS
+    asm volatile("" : "+v"(xf[0][0]), "+v"(xf[1][0]), "+v"(xf[2][0]), "+v"(xf[3][0]));
+#else
+    const char* s = smem + slot * HT_BYTES;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) xf[jj][ks] = *reinterpret_cast<const bf16x8*>(s + xrd[ks] + jj * (16 * BK4 * 2));
-  };
-  auto read_w = [&](bf16x8 (&wf)[2][2], const int buf, const int h) __attribute__((always_inline)) {
-#if MX_EXP == 3 || MX_EXP == 13 || MX_EXP == 23 || MX_EXP == 123
-    asm volatile("" : "+v"(wf[0][0]), "+v"(wf[1][0])); return;
 #endif
-    const char* s = sbase + (buf * 4 + 2 + h) * (HT_ELEMS * 2);
+  };
+  auto read_w = [&](bf16x8 (&wf)[2][2], const int slot) __attribute__((always_inline)) {
+#if MX_NO_READS
+    asm volatile("" : "+v"(wf[0][0]), "+v"(wf[1][0]));
+#else
+    const char* s = smem + slot * HT_BYTES;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) wf[ii][ks] = *reinterpret_cast<const bf16x8*>(s + wrd[ks] + ii * (16 * BK4 * 2));
+#endif
   };
+  auto wrap = [](int s) __attribute__((always_inline)) { return s >= NSLOT4 ? s - NSLOT4 : s; };
 
   // ---- prologue: stream positions 0 (all four kinds) and 1 (XH0, WH0) ----
 #pragma unroll
-  for (int c = 0; c < 4; ++c) { c_tile[c] = blockIdx.x; c_kt[c] = 0; setup(c, blockIdx.x); }
+  for (int c = 0; c < 4; ++c) { c_tile[c] = blockIdx.x; c_kt[c] = 0; c_slot[c] = c; setup(c, blockIdx.x); }
   issue(0); advance(0);
   issue(1); advance(1);
   issue(2); advance(2);
@@ -180,7 +209,12 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // position 0 has landed (this thread's part)
   MX_BAR();
 
-  int buf = 0;                                 // LDS buffer of the K tile being computed = stream position & 1
+#if MX_EXP == 7
+  unsigned long long tk[9];
+  unsigned long long sums[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev_end = 0;
+#endif
+  int rs = 0;                                  // ring slot of XH0 of the K tile being computed (stream index 4 t mod 10)
   for (int tile = blockIdx.x; tile < total_tiles; tile += (int)gridDim.x) {
     f32x4 acc[NI][MI];
 #pragma unroll
@@ -190,13 +224,21 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
 
     if (wm == 1) MX_BAR();                     // wave row 1 runs one barrier behind row 0
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K tile; HOT: no cursor leaves its tile during this iteration (plain pointer increments, no control flow)
+    auto k_tile = [&](auto hot_tag) __attribute__((always_inline)) {
+      constexpr bool HOT = decltype(hot_tag)::value;
       bf16x8 xf[4][2], w0[2][2], w1[2][2];
-      // ---- L1 / M1 ----
-      read_w(w0, buf, 0);
-      read_x(xf, buf, 0);
-      issue(2); advance(2);
+      // ---- LA ----
+      MX_T(0);
+      read_w(w0, wrap(rs + 1));
+      read_x(xf, rs);
+      read_w(w1, wrap(rs + 2));
+      issue(2); if constexpr (HOT) advance_hot(2); else advance(2);
+      issue(3); if constexpr (HOT) advance_hot(3); else advance(3);
+      MX_T(1);
       MX_BAR();
+      // ---- MA ----
+      MX_TWAIT(); MX_T(2); MX_TWAIT();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -204,13 +246,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) acc[ii][jj] = MX_MFMA(w0[ii][ks], xf[jj][ks], acc[ii][jj]);
-      __builtin_amdgcn_s_setprio(0);
-      MX_BAR();
-      // ---- L2 / M2 ----
-      read_w(w1, buf, 1);
-      issue(3); advance(3);
-      MX_BAR();
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -218,11 +253,18 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) acc[2 + ii][jj] = MX_MFMA(w1[ii][ks], xf[jj][ks], acc[2 + ii][jj]);
       __builtin_amdgcn_s_setprio(0);
+      MX_T(3);
       MX_BAR();
-      // ---- L3 / M3 ----
-      read_x(xf, buf, 1);
-      issue(0); advance(0);
+      // ---- LB ----
+      MX_T(4);
+      read_x(xf, wrap(rs + 3));
+      issue(0); if constexpr (HOT) advance_hot(0); else advance(0);
+      issue(1); if constexpr (HOT) advance_hot(1); else advance(1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the two youngest half-tiles: the next stream position has landed
+      MX_T(5);
       MX_BAR();
+      // ---- MB ----
+      MX_TWAIT(); MX_T(6); MX_TWAIT();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -230,13 +272,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) acc[2 + ii][4 + jj] = MX_MFMA(w1[ii][ks], xf[jj][ks], acc[2 + ii][4 + jj]);
-      __builtin_amdgcn_s_setprio(0);
-      MX_BAR();
-      // ---- L4 / M4 ----
-      issue(1); advance(1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the two youngest half-tiles: the next stream position has landed
-      MX_BAR();
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -244,9 +279,31 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) acc[ii][4 + jj] = MX_MFMA(w0[ii][ks], xf[jj][ks], acc[ii][4 + jj]);
       __builtin_amdgcn_s_setprio(0);
+      MX_T(7);
       MX_BAR();
-      buf ^= 1;
-    }
+#if MX_EXP == 7
+      MX_TWAIT();
+      if (t_prev_end) sums[7] += tk[0] - t_prev_end;     // barrier after MB (previous K tile) -> LA start
+      sums[0] += tk[1] - tk[0];                          // LA issue
+      sums[1] += tk[2] - tk[1];                          // barrier + fragment wait
+      sums[2] += tk[3] - tk[2];                          // MA
+      sums[3] += tk[4] - tk[3];                          // barrier
+      sums[4] += tk[5] - tk[4];                          // LB issue + vmcnt wait
+      sums[5] += tk[6] - tk[5];                          // barrier + fragment wait
+      sums[6] += tk[7] - tk[6];                          // MB
+      t_prev_end = tk[7];
+#endif
+      rs = rs >= NSLOT4 - 4 ? rs - (NSLOT4 - 4) : rs + 4;
+    };
+    // During K tile kt the cursors of WH1 / XH1 move from stream position kt + 1 to kt + 2 and those of XH0 / WH0 from kt + 2 to
+    // kt + 3: all stay inside this tile while kt + 3 < nk.
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) k_tile(std::true_type{});
+    for (; kt < nk; ++kt) k_tile(std::false_type{});
+
+#if MX_EXP == 7
+    t_prev_end = 0;
+#endif
     if (wm == 0) MX_BAR();                     // re-align the two wave rows
 
     int tm, tn;
@@ -256,7 +313,18 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
     else gemm_epilogue_regs<NI, MI, false, VEC, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end DMAs before the workgroup retires
+#if MX_EXP == 7
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) g_v4_sums[(blockIdx.x * 8 + wave) * 16 + k] = sums[k];
+#endif
 }
+
+#if MX_EXP == 7
+extern "C" int mx_debug_v4_sums(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v4_sums), sizeof(g_v4_sums)); }
+#endif
+
+static void v4_unused_marker() {}
+
 
 int launch_v4(hipStream_t s, const GemmArgs& a) {
   static const int ncu = [] {
