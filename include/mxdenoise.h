@@ -35,9 +35,9 @@ int mx_version(void);
 /* Optional per-launch timing for bench.py's roofline leg: while enabled, every GEMM / conv / attention / norm launch
  * is bracketed by hipEvents on its own stream.  mx_profile_collect (after the stream is synchronised) fills
  * out[4 * MX_PROF_KINDS] = for kind in {gemm<128>, gemm<64>, conv3x3<128>, conv3x3<64>, attention, groupnorm,
- *           gemm_v2<160>, conv3x3_v2<160>, gemm_v2<128>, conv3x3_v2<128>, gemm_v3 (256x256)}:
+ *           gemm_v2<160>, conv3x3_v2<160>, gemm_v2<128>, conv3x3_v2<128>, gemm 256x256, cross-attention (Lk <= 96)}:
  *           {launches, milliseconds, algorithmic flops, algorithmic bytes}. */
-#define MX_PROF_KINDS 11
+#define MX_PROF_KINDS 12
 int mx_profile_enable(int on);
 int mx_profile_collect(double* out);
 /* per-launch records of the last collect: out[6*i..] = {kind, M, N, K, ms, flops}; returns the number written */
@@ -122,6 +122,10 @@ typedef struct mx_gemm_desc {
   const float* rms_wq;
   const float* rms_wk;
   float rms_eps;
+  /* conv3x3, patch-parallel (mx_unet_forward_pp): 1 = every image of `a` is stored with ONE extra row above and below
+   * ([B, Hin + 2, Win, Cin], `a` pointing at the top halo row of image 0); taps that leave the image vertically read those
+   * rows (the neighbour ranks' boundary rows, or zeros at the true image border) instead of zero padding. */
+  int vhalo;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -226,6 +230,38 @@ int mx_unet_forward_trace(mx_unet* u, void* stream, const void* latents, int io_
                           const void* ehs, const void* text_embeds, const float* time_ids, void* out,
                           int batch, int H, int W, int ctx_len, int gn_patch, void* workspace,
                           size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch parallelism (BASELINE.json configs[3]): ONE request's latent rows split over `world` GPUs, the bundled distrifuser
+ * baseline's DistriUNetPP (distrifuser/distrifuser/distrifuser/models/distri_sdxl_unet_pp.py:15-216) in its synchronous mode
+ * (every step exchanges fresh tensors; utils.py:119-214 PatchParallelismCommManager, modules/pp/{conv2d,groupnorm,attn}.py):
+ *   - 3x3 convs read one boundary row of each neighbour rank (all-gather of [2][batch][W * C] per conv),
+ *   - GroupNorm folds the ranks' per-(image, group) {sum, sum of squares} (all-gather of 16-byte records),
+ *   - self-attention keeps its local queries and gathers the other ranks' K rows and V^T columns,
+ *   - everything per-token (LayerNorm, projections, GEGLU, cross-attention, 1x1 convs) is local.
+ * Rank r owns latent rows [r * H_local, (r + 1) * H_local); H_local must be divisible by 2^(levels - 1) and H_local * W / 4^level
+ * a multiple of 64 at every attention level.  The collective is supplied by the caller: all_gather(ctx, stream, send, recv,
+ * bytes_per_rank) must place rank k's `send` at recv + k * bytes_per_rank, ordered after prior work on `stream` and before
+ * later work on it, and return 0.  sduss_amd/patch_parallel.py binds it to torch.distributed (backend "nccl" == RCCL over
+ * xGMI on MI355X; gloo through host memory in the tests).  send / recv always lie inside `workspace`.
+ * Results equal mx_unet_forward on the whole latent (gn_patch 0) up to the summation order of the GroupNorm statistics.
+ * ------------------------------------------------------------------------------------------ */
+typedef int (*mx_allgather_fn)(void* ctx, void* stream, const void* send, void* recv, size_t bytes_per_rank);
+typedef struct mx_pp_comm { int rank, world; mx_allgather_fn all_gather; void* ctx; } mx_pp_comm;
+size_t mx_unet_workspace_bytes_pp(const mx_unet* u, int batch, int H_local, int W, int ctx_len, int world);
+/* latents_local / out_local: [batch, C, H_local, W] of io_dtype (this rank's rows, NCHW) */
+int mx_unet_forward_pp(mx_unet* u, void* stream, const void* latents_local, int io_dtype, const float* timesteps, const void* ehs,
+                       const void* text_embeds, const float* time_ids, void* out_local, int batch, int H_local, int W, int ctx_len,
+                       const mx_pp_comm* comm, void* workspace, size_t workspace_bytes);
+/* Host-only walk of the patch-parallel plan (no launches, no GPU): calls comm->all_gather once per exchange of a forward, in
+ * order, with send / recv = (void*)(0x1000 + byte offset of the region inside the workspace). */
+int mx_unet_pp_comm_plan(const mx_unet* u, int batch, int H_local, int W, int ctx_len, const mx_pp_comm* comm);
+/* mx_attention_prescaled for K / V^T gathered rank-major: keys [c * key_chunk, (c + 1) * key_chunk) of batch b have their K rows at
+ * k + c * k_chunk_stride + b * k_batch_stride (row stride ldk) and their V^T words at vt + c * vt_chunk_stride + b * vt_batch_stride
+ * + (h * 64 + d) * ldvt + MX_VT_POS(key - c * key_chunk); key_chunk % 64 == 0, Lk % key_chunk == 0 (strides in elements). */
+int mx_attention_prescaled_chunked(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                   int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, int key_chunk,
+                                   int64_t k_batch_stride, int64_t k_chunk_stride, int64_t vt_chunk_stride);
 
 /* ------------------------------------------------------------------------------------------
  * Outer boundary: the SD3.5 MMDiT in the ``transformer`` slot

@@ -42,6 +42,10 @@ struct AttnArgs {
   int B, H, Lq, Lk;
   float scale_log2;  // scale * log2(e)
   int xcd_map;       // 1: XCD-aware workgroup order (needs B*H % 8 == 0)
+  // patch-parallel K / V^T (mx_attention_prescaled_chunked): keys come in `key_chunk`-long chunks gathered from the ranks;
+  // chunk c of batch b starts at k + c * k_cstride + b * k_bstride (rows of ldk) and vt + c * vt_cstride + b * vt_bstride
+  int key_chunk;     // 0: one contiguous key range per batch
+  long k_bstride, k_cstride, vt_cstride;
 };
 
 constexpr int KT = 64;                 // keys per tile
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   // ---- staging: 512 16-byte chunks per tile per operand, 2 per thread (rows srow, srow+32; chunk sch) ----
   const int srow = tid >> 3;
   const int sch = tid & 7;
-  const bf16_t* kbase = p.k + (long)b * p.Lk * p.ldk + head * 64 + sch * 8;
+  const bf16_t* kbase = p.k + (long)b * p.k_bstride + head * 64 + sch * 8;
   const bf16_t* vbase = p.vt + (long)b * p.vt_bstride + ((long)head * 64) * p.ldvt + sch * 8;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   u32x4 rk[2], rv[2];
@@ -106,11 +110,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   unsigned st_off = (unsigned)(srow * 128 + ((sch ^ ((srow >> 1) & 7)) * 16));     // byte offset inside the K image of buffer 0
 
   auto load_tile = [&](int kt) {               // full tile: no predicates
-    const int key0 = kt * KT;
+    int key0 = kt * KT;
+    const bf16_t* kb_ = kbase;
+    const bf16_t* vb_ = vbase;
+    if (p.key_chunk > 0) {                     // tiles never straddle a chunk (key_chunk % 64 == 0)
+      const int ch = key0 / p.key_chunk;
+      key0 -= ch * p.key_chunk;
+      kb_ += ch * p.k_cstride;
+      vb_ += ch * p.vt_cstride;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      rk[i] = *reinterpret_cast<const u32x4*>(kbase + (long)(key0 + srow + 32 * i) * p.ldk);
-      rv[i] = *reinterpret_cast<const u32x4*>(vbase + (long)(srow + 32 * i) * p.ldvt + key0);
+      rk[i] = *reinterpret_cast<const u32x4*>(kb_ + (long)(key0 + srow + 32 * i) * p.ldk);
+      rv[i] = *reinterpret_cast<const u32x4*>(vb_ + (long)(srow + 32 * i) * p.ldvt + key0);
     }
   };
   auto load_tile_tail = [&](int kt) {          // last, partial tile: keys >= Lk are zero-filled (0 * garbage must not be NaN)
@@ -326,25 +338,210 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Cross-attention with a SHORT key sequence (Lk <= 96: the 77 text tokens of SDXL; PatchCrossAttention.forward,
+// modules/attention.py:59-110).  Half of the attention launches of a UNet step (70 of 140) are this shape, and the general
+// kernel above spends them on machinery they do not need: two 64-key LDS tiles (the second 13/64 valid), a barrier per
+// tile, the online-softmax rescale, and 8-byte output stores.  Here
+//   * every wave works alone (no LDS tiles, no barrier): the head's K rows and V^T rows live in REGISTERS as ready-made MFMA
+//     fragments (<= 12 + 12 fragments, loaded once per wave from L2) and are reused for all of the wave's query blocks;
+//   * keys are padded to the next multiple of 32 for S^T = K Q^T (3 blocks for 77 keys) and of 16 for O^T += V^T P^T (5 steps);
+//   * single-pass softmax: all scores of a query are in the lane (<= 48 per half-wave), so one max, one exp2 pass, one sum;
+//   * the output block is transposed through a wave-private 4-KB LDS patch, so O is written as full 128-byte rows (8 lanes x
+//     16 B; the per-CU store rate of full lines is 2.7x that of 8-byte pieces: profiles/r02_a_*), and the next query block's
+//     Q rows are fetched while the current one computes.
+// The launch is bound by its HBM traffic (Q read + O write); K / V^T stay in L2.
+// ----------------------------------------------------------------------------------------------------------------------
+constexpr int XK_MAXBLK = 3;                   // 32-key blocks (Lk <= 96)
+constexpr int XK_QPW = 64;                     // queries per wave (two 32-query blocks)
+
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 4096];       // one 32 x 64 bf16 patch per wave
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31;
+  const int hh = lane >> 5;
+  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
+  if (p.xcd_map) {                             // XCD x owns the (batch, head) pairs == x (mod 8): their K / V^T stay in one L2
+    const int lin = blockIdx.x + gridDim.x * bh;
+    const int local = lin >> 3;
+    qb = local % (int)gridDim.x;
+    bh = ((local / (int)gridDim.x) << 3) + (lin & 7);
+  }
+  const int head = bh % p.H;
+  const int b = bh / p.H;
+  const int nblk = (p.Lk + 31) >> 5;           // <= XK_MAXBLK (launcher)
+  const int nst = (p.Lk + 15) >> 4;
+
+  // ---- K fragments (A operand of S^T): K[32 kb + r][16 ks + 8 hh ..]; rows >= Lk are zero ----
+  bf16x8 kf[XK_MAXBLK][4];
+  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+#pragma unroll
+  for (int kb = 0; kb < XK_MAXBLK; ++kb) {
+    const int key = kb * 32 + r;
+    const bf16_t* kp = p.k + ((long)b * p.Lk + (key < p.Lk ? key : 0)) * p.ldk + head * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = (kb < nblk && key < p.Lk) ? *reinterpret_cast<const bf16x8*>(kp + ks * 16) : zero8;
+  }
+  // ---- V^T fragments (A operand of O^T): vt[64 head + 32 db + r][16 s + 8 hh ..] (MX_VT_POS order); keys >= Lk zeroed, the pad of
+  //      a V^T row may hold anything ----
+  bf16x8 vf[2 * XK_MAXBLK][2];
+#pragma unroll
+  for (int st = 0; st < 2 * XK_MAXBLK; ++st) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (st < nst) {
+        v = *reinterpret_cast<const u32x4*>(p.vt + (long)b * p.vt_bstride + ((long)head * 64 + db * 32 + r) * p.ldvt + st * 16 + hh * 8);
+        // element e of the word is position 16 st + 8 hh + e = key 16 st + 4 hh + (e & 3) + 8 (e >> 2)   (MX_VT_POS swaps bits 2 and 3)
+        const int kbase = st * 16 + 4 * hh;
+        if (kbase + 12 > p.Lk) {               // some element may be past the end (only in the last step)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k0 = kbase + 2 * (e & 1) + 8 * (e >> 1);
+            unsigned w = v[e];
+            if (k0 >= p.Lk) w &= 0xffff0000u;
+            if (k0 + 1 >= p.Lk) w &= 0x0000ffffu;
+            v[e] = w;
+          }
+        }
+      }
+      vf[st][db] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  const float c = PRE ? 1.0f : p.scale_log2;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  char* patch = smem + wave * 4096;
+  const int q_wave0 = qb * (4 * XK_QPW) + wave * XK_QPW;
+
+  auto load_q = [&](bf16x8 (&qf)[4], int q0) __attribute__((always_inline)) {
+    int qi = q0 + r;
+    if (qi > p.Lq - 1) qi = p.Lq - 1;
+    const bf16_t* qp = p.q + ((long)b * p.Lq + qi) * p.ldq + head * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  };
+  bf16x8 qf[4], qn[4];
+  load_q(qf, q_wave0);
+#pragma unroll
+  for (int blk = 0; blk < XK_QPW / 32; ++blk) {
+    const int q0 = q_wave0 + blk * 32;
+    if (q0 >= p.Lq) break;                     // wave-uniform
+    if (blk + 1 < XK_QPW / 32) load_q(qn, q0 + 32);
+    // ---- S^T = K Q^T ----
+    f32x16 s[XK_MAXBLK];
+#pragma unroll
+    for (int kb = 0; kb < XK_MAXBLK; ++kb) {
+      s[kb] = zero16;
+      if (kb < nblk) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- single-pass softmax over the lane's keys (block kb element e = key 32 kb + (e & 3) + 8 (e >> 2) + 4 hh) ----
+    float mx_ = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < XK_MAXBLK; ++kb) {
+      if (kb >= nblk) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        float v = s[kb][e] * c;
+        if ((kb + 1) * 32 > p.Lk && key >= p.Lk) v = -INFINITY;
+        s[kb][e] = v;
+        mx_ = fmaxf(mx_, v);
+      }
+    }
+    mx_ = max_across_halves(mx_);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < XK_MAXBLK; ++kb) {
+      if (kb >= nblk) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(s[kb][e] - mx_);
+        s[kb][e] = pe;
+        psum += pe;
+      }
+    }
+    const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
+    // ---- O^T = V^T P^T ----
+    f32x16 oacc[2] = {zero16, zero16};
+#pragma unroll
+    for (int st = 0; st < 2 * XK_MAXBLK; ++st) {
+      if (st >= nst) continue;
+      const int kb = st >> 1, s2 = st & 1;
+      u32x4 pw;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pw[e] = pack2(s[kb][8 * s2 + 2 * e], s[kb][8 * s2 + 2 * e + 1]);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st][db], pf, oacc[db], 0, 0, 0);
+    }
+    // ---- O[q][d]: lane (r, hh) holds d = 32 db + 8 g + 4 hh + {0..3} of query r.  Through the wave's LDS patch (rows = queries,
+    //      128 B, 16-byte chunk ^= row & 7) so that the global stores are whole rows. ----
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2 o = {pack2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv), pack2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
+        const int chunk = (4 * db + g) ^ (r & 7);
+        *reinterpret_cast<u32x2*>(patch + r * 128 + chunk * 16 + hh * 8) = o;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (lane >> 3) + 8 * i;
+      const int ch = lane & 7;
+      const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * 128 + ((ch ^ (row & 7)) * 16));
+      const int qi = q0 + row;
+      if (qi < p.Lq) *reinterpret_cast<u32x4*>(p.o + ((long)b * p.Lq + qi) * p.ldo + head * 64 + ch * 8) = o;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+  }
+}
+
 }  // namespace mx
 
 static int launch_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
-                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale, bool pre) {
+                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale, bool pre,
+                            int key_chunk = 0, int64_t k_bstride = 0, int64_t k_cstride = 0, int64_t vt_cstride = 0) {
   using namespace mx;
   MX_CHECK(q && k && vt && o, "attention: null operand");
   MX_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
   MX_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o) & 15) == 0, "attention: operand pointers must be 16-byte aligned");
   MX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: strides must be multiples of 8 elements");
   MX_CHECK(ldq >= H * 64 && ldk >= H * 64 && ldo >= H * 64, "attention: row stride smaller than H*64");
-  MX_CHECK(ldvt >= MX_VT_LD(Lk), "attention: ldvt must cover MX_VT_LD(Lk) (keys are stored in MX_VT_POS order)");
+  if (key_chunk > 0) {
+    MX_CHECK(key_chunk % 64 == 0 && Lk % key_chunk == 0, "attention: key_chunk must be a multiple of 64 and divide Lk");
+    MX_CHECK(ldvt >= key_chunk && k_bstride % 8 == 0 && k_cstride % 8 == 0 && vt_cstride % 8 == 0, "attention: bad chunk strides");
+  } else {
+    MX_CHECK(ldvt >= MX_VT_LD(Lk), "attention: ldvt must cover MX_VT_LD(Lk) (keys are stored in MX_VT_POS order)");
+  }
   MX_CHECK(vt_batch_stride % 8 == 0 && vt_batch_stride >= (int64_t)H * 64 * ldvt, "attention: bad vt_batch_stride");
   AttnArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.o = (bf16_t*)o;
   a.vt_bstride = (long)vt_batch_stride;
   a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale_log2 = scale * 1.4426950408889634f;
+  a.key_chunk = key_chunk; a.k_bstride = key_chunk > 0 ? (long)k_bstride : (long)Lk * ldk; a.k_cstride = (long)k_cstride; a.vt_cstride = (long)vt_cstride;
   static const int xcd_env = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
   a.xcd_map = (xcd_env && ((B * H) % 8 == 0)) ? 1 : 0;
+  static const bool cross_off = [] { const char* e = getenv("MX_ATTN_CROSS"); return e && e[0] == '0'; }();
+  if (Lk <= 32 * XK_MAXBLK && Lq >= 2048 && !cross_off && key_chunk == 0) {   // (at Lq 1024 the general kernel is 7 % faster: both are latency-bound)    // short key sequence: every wave keeps K / V^T in registers (attn_cross_kernel)
+    MX_CHECK(ldo % 8 == 0, "attention: ldo must be a multiple of 8 elements");
+    dim3 xgrid(cdiv(Lq, 4 * XK_QPW), H, B);
+    prof_begin((hipStream_t)stream, PROF_ATTN_CROSS, 4.0 * B * H * (double)Lq * Lk * 64.0, 2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
+    if (pre) hipLaunchKernelGGL(attn_cross_kernel<true>, xgrid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_cross_kernel<false>, xgrid, dim3(256), 0, (hipStream_t)stream, a);
+    prof_end((hipStream_t)stream);
+    MX_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(cdiv(Lq, 128), H, B);
   prof_begin((hipStream_t)stream, PROF_ATTN, 4.0 * B * H * (double)Lq * Lk * 64.0,
              2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
@@ -363,4 +560,14 @@ extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k,
 extern "C" int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                                       int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk) {
   return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, 1.0f, true);
+}
+
+/* patch-parallel form (mx_unet_forward_pp): K rows and V^T columns of the `world` ranks arrive rank-major from the all-gather.
+ * keys [c * key_chunk, (c + 1) * key_chunk) of batch b: K rows at k + c * k_chunk_stride + b * k_batch_stride (row stride ldk),
+ * V^T at vt + c * vt_chunk_stride + b * vt_batch_stride + (h * 64 + d) * ldvt + MX_VT_POS(key - c * key_chunk). */
+extern "C" int mx_attention_prescaled_chunked(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                              int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, int key_chunk,
+                                              int64_t k_batch_stride, int64_t k_chunk_stride, int64_t vt_chunk_stride) {
+  return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, 1.0f, true, key_chunk,
+                          k_batch_stride, k_chunk_stride, vt_chunk_stride);
 }

@@ -31,6 +31,7 @@ struct GemmArgs {
   const float* rms_wk;
   float rms_eps;
   int stagger_ticks;   // experiment (gemm_bf16_v3.hip)
+  int vhalo;           // conv: images stored with one halo row above and below (patch-parallel)
 };
 
 // row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)

@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
           const bool cross_c = ((ix + P) / P) != ((cx[i] + P) / P);
           if (cross_r && cross_c) iy = cy[i];
         }
-        const bool ok = (cb[i] >= 0) && (iy >= 0) && (iy < Hv) && (ix >= 0) && (ix < Wv);
+        const bool ok = (cb[i] >= 0) && (iy >= -p.vhalo) && (iy < Hv + p.vhalo) && (ix >= 0) && (ix < Wv);
         if (ok) {
-          const long src = (((long)cb[i] * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up)) * p.Cin + c0 + sch * 8;
+          const long src = (((long)cb[i] * (p.Hin + 2 * p.vhalo) + (iy >> p.up) + p.vhalo) * p.Win + (ix >> p.up)) * p.Cin + c0 + sch * 8;
           rx[i] = *reinterpret_cast<const u32x4*>(p.a + src);
         } else {
           rx[i] = zero4;
@@ -229,6 +229,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   MX_CHECK(d->N % 4 == 0, "gemm: N must be a multiple of 4");
   GemmArgs a;
   a.stagger_ticks = 0;
+  a.vhalo = conv ? d->vhalo : 0;
   a.a = (const bf16_t*)d->a; a.w = (const bf16_t*)d->w; a.c = d->c;
   a.bias = d->bias; a.rowbias = d->rowbias; a.residual = (const bf16_t*)d->residual; a.vt = (bf16_t*)d->vt;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldrb = d->ldrb;
@@ -254,6 +255,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK((long)d->B * d->Hout * d->Wout == d->M, "conv3x3: M != B*Hout*Wout");
     MX_CHECK(2 * d->Cin <= 16384, "conv3x3: Cin > 8192 (the pipelined loader walks a 16 KB zero page for padding taps)");
     MX_CHECK(!(d->flags & MX_EPI_GEGLU), "conv3x3: no GEGLU epilogue");
+    MX_CHECK(d->vhalo == 0 || (d->vhalo == 1 && d->corner_patch == 0), "conv3x3: vhalo must be 0 or 1 and excludes the sliced corner rule");
   }
   // the LDS-DMA loaders and the staged epilogue move 16-byte pieces: every base pointer must be 16-byte aligned
   {

@@ -96,8 +96,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
         const bool cross_c = ((ix + P) / P) != ((cx[i] + P) / P);
         if (cross_r && cross_c) iy = cy[i];
       }
-      const bool ok = (cb[i] >= 0) && (iy >= 0) && (iy < Hv) && (ix >= 0) && (ix < Wv);
-      const long off = ((((long)cb[i] * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up)) * p.Cin) * 2;
+      const bool ok = (cb[i] >= 0) && (iy >= -p.vhalo) && (iy < Hv + p.vhalo) && (ix >= 0) && (ix < Wv);
+      const long off = ((((long)cb[i] * (p.Hin + 2 * p.vhalo) + (iy >> p.up) + p.vhalo) * p.Win + (ix >> p.up)) * p.Cin) * 2;
       xsrc[i] = (ok ? reinterpret_cast<const char*>(p.a) + off : zero) + xchb[i];
     }
   };

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void gn_fold_kernel(const float* __restrict__ p
 
 template <bool SILU>
 __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                const float* __restrict__ coef, GnGeom g, int pix_per_block) {
+                                const float* __restrict__ coef, GnGeom g, int pix_per_block, long y_img) {
   const int t = threadIdx.x;
   const int b = blockIdx.y;
   const int cv = t % g.tpr;
@@ -145,7 +145,47 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict
       if (SILU) { lo = silu_f(lo); hi = silu_f(hi); }
       o[e] = pack_bf16x2(lo, hi);
     }
-    *reinterpret_cast<u32x4*>(y + off) = o;
+    *reinterpret_cast<u32x4*>(y + (long)b * y_img + (long)pi * g.C + cv * 8) = o;
+  }
+}
+
+// ---- patch-parallel GroupNorm (mx_unet_forward_pp): the image's rows are split over `world` ranks; each rank folds its
+//      partials to per-(image, group) {sum, sum of squares} in fp64, the ranks all-gather those 16-byte records, and every
+//      rank finishes the same scale / shift (distrifuser modules/pp/groupnorm.py:9-98 exchanges E[x], E[x^2] likewise) ----
+__global__ __launch_bounds__(64) void gn_pp_sums_kernel(const float* __restrict__ part, double* __restrict__ sums, GnGeom g, int groups) {
+  const int grp = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int cpg = g.C / groups;
+  const int ntiles = g.tiles_y * g.tiles_x;
+  double s = 0.0, q = 0.0;
+  for (int it = lane; it < ntiles * cpg; it += 64) {
+    const int tile = it / cpg, c = it - tile * cpg;
+    const float* src = part + (((long)b * ntiles + tile) * g.C + grp * cpg + c) * 2;
+    s += (double)src[0];
+    q += (double)src[1];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane == 0) { sums[((long)b * groups + grp) * 2] = s; sums[((long)b * groups + grp) * 2 + 1] = q; }
+}
+
+__global__ __launch_bounds__(64) void gn_pp_coef_kernel(const double* __restrict__ all_sums, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ coef, int B, int C,
+                                                        int groups, int world, double cnt, float eps) {
+  const int grp = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int cpg = C / groups;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < world; ++r) {            // fixed rank order: every rank computes bit-identical coefficients
+    s += all_sums[(((long)r * B + b) * groups + grp) * 2];
+    q += all_sums[(((long)r * B + b) * groups + grp) * 2 + 1];
+  }
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int c = lane; c < cpg; c += 64) {
+    const int ch = grp * cpg + c;
+    coef[((long)b * C + ch) * 2] = (float)(rstd * (double)gamma[ch]);
+    coef[((long)b * C + ch) * 2 + 1] = (float)((double)beta[ch] - rstd * (double)gamma[ch] * mean);
   }
 }
 
@@ -212,12 +252,47 @@ extern "C" int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const flo
   int ppb = g.L * 8;  // pixels per block
   if (ppb > hw) ppb = hw;
   dim3 grid(cdiv(hw, ppb), B);
-  if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb);
-  else hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb);
+  if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb, (long)hw * C);
+  else hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb, (long)hw * C);
   prof_end(s);
   MX_LAUNCH_CHECK();
   return 0;
 }
+
+namespace mx {
+// local part: stats -> per-(image, group) fp64 sums.  workspace: gn_workspace_exact(B, H, W, C, 0) bytes; sums: double [B][groups][2]
+int launch_gn_pp_partial(hipStream_t s, const void* x, int B, int H, int W, int C, int groups, void* workspace, double* sums) {
+  GnGeom g;
+  if (gn_geom(g, B, H, W, C, 0)) return 1;
+  const int ntiles = g.tiles_y * g.tiles_x;
+  float* part = (float*)workspace;
+  const int threads = ((g.tpr * g.L + 63) / 64) * 64;
+  const size_t smem = (size_t)g.L * C * 2 * sizeof(float);
+  MX_CHECK(smem <= 160 * 1024, "groupnorm: LDS budget exceeded");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ntiles, B), dim3(threads), smem, s, (const bf16_t*)x, part, g);
+  hipLaunchKernelGGL(gn_pp_sums_kernel, dim3(groups, B), dim3(64), 0, s, (const float*)part, sums, g, groups);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+// all_sums: double [world][B][groups][2]; y rows of image b start at y + b * y_img_elems; H = LOCAL rows, H_total = rows of the whole image
+int launch_gn_pp_finish(hipStream_t s, const void* x, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
+                        int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace) {
+  GnGeom g;
+  if (gn_geom(g, B, H, W, C, 0)) return 1;
+  float* coef = (float*)workspace + (size_t)B * g.tiles_y * g.tiles_x * C * 2;
+  const double cnt = (double)H_total * W * (C / groups);
+  hipLaunchKernelGGL(gn_pp_coef_kernel, dim3(groups, B), dim3(64), 0, s, all_sums, gamma, beta, coef, B, C, groups, world, cnt, eps);
+  const int threads = ((g.tpr * g.L + 63) / 64) * 64;
+  const int hw = H * W;
+  int ppb = g.L * 8;
+  if (ppb > hw) ppb = hw;
+  dim3 grid(cdiv(hw, ppb), B);
+  if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb, y_img_elems);
+  else hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb, y_img_elems);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mx
 
 // ------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wave per row, values held in registers between the passes.

@@ -33,7 +33,13 @@ int launch_time_embed(hipStream_t s, const float* timesteps, const void* text_em
                       void* tsin, void* addin, int B, int d0, int text_dim, int da);
 int launch_concat(hipStream_t s, const void* a, const void* b, void* out, long M, int C1, int C2);
 size_t gn_workspace_exact(int B, int H, int W, int C, int patch);
+int launch_gn_pp_partial(hipStream_t s, const void* x, int B, int H, int W, int C, int groups, void* workspace, double* sums);
+int launch_gn_pp_finish(hipStream_t s, const void* x, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
+                        int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace);
 }  // namespace mx
+extern "C" int mx_attention_prescaled_chunked(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                              int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, int key_chunk,
+                                              int64_t k_batch_stride, int64_t k_chunk_stride, int64_t vt_chunk_stride);
 
 using mx::bf16_t;
 
@@ -71,6 +77,10 @@ struct Plan {
   bool lookup = false;      // dry pass that still resolves every weight (mx_unet_validate)
   const char* stage = nullptr; void* stage_out = nullptr; size_t stage_bytes = 0; bool stage_hit = false;
   std::string err;
+  // patch-parallel (mx_unet_forward_pp): this rank owns H (local) of Htot latent rows; distrifuser sync mode (utils.py:119-214)
+  int pp_rank = 0, pp_world = 1, Htot = 0;
+  mx_allgather_fn pp_ag = nullptr; void* pp_ctx = nullptr;
+  bool is_pp() const { return pp_world > 1; }
   // per-forward tensors
   float* temb_all = nullptr; int temb_total = 0; int temb_off = 0;
   struct KV { bf16_t* k; bf16_t* vt; int ldk; int ldvt; long vt_bstride; int next; int dim; };
@@ -99,6 +109,70 @@ struct Plan {
 
   bool ok() const { return err.empty(); }
 
+  // ---- patch-parallel helpers --------------------------------------------------------------
+  bool all_gather(const void* send, void* recv, size_t bytes_per_rank) {
+    if (!ok()) return false;
+    if (dry && !pp_ag) return true;          // sizing pass
+    // dry with a callback (mx_unet_pp_comm_plan): the callback sees the arena's placeholder addresses (0x1000 + offset)
+    if (pp_ag(pp_ctx, stream, send, recv, bytes_per_rank)) return fail("patch-parallel all_gather failed");
+    return true;
+  }
+  // [B, h + 2, wd, C] image with one halo row above and below; returns the base (the top halo row of image 0)
+  bf16_t* alloc_padded(int h, int wd, int C) { return alloc<bf16_t>((size_t)B * (h + 2) * wd * C); }
+  static bf16_t* interior(bf16_t* P, int wd, int C) { return P + (size_t)wd * C; }
+  bool copy_to_padded(const bf16_t* x, bf16_t* P, int h, int wd, int C) {
+    if (!ok()) return false;
+    if (dry) return true;
+    const size_t img = (size_t)h * wd * C * 2, pimg = (size_t)(h + 2) * wd * C * 2;
+    if (hipMemcpy2DAsync(interior(P, wd, C), pimg, x, img, img, B, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("copy_to_padded failed");
+    return true;
+  }
+  // fill the halo rows of P from the neighbour ranks' boundary rows (zeros at the true image border): one all-gather of
+  // [2][B][wd * C] per rank (distrifuser modules/pp/conv2d.py:98 gathers [2, b, C, pad, W] the same way)
+  bool halo_exchange(bf16_t* P, int h, int wd, int C) {
+    if (!ok()) return false;
+    const size_t m = ar.mark();
+    const size_t row = (size_t)wd * C * 2, pimg = (size_t)(h + 2) * row;
+    char* send = (char*)ar.alloc(2 * B * row);
+    char* recv = (char*)ar.alloc((size_t)pp_world * 2 * B * row);
+    if (!send || !recv) return fail("workspace too small");
+    if (dry) { if (!all_gather(send, recv, 2 * B * row)) return false; }
+    if (!dry) {
+      char* Pc = (char*)P;
+      bool e = hipMemcpy2DAsync(send, row, Pc + row, pimg, row, B, hipMemcpyDeviceToDevice, stream) != hipSuccess;
+      e |= hipMemcpy2DAsync(send + B * row, row, Pc + (size_t)h * row, pimg, row, B, hipMemcpyDeviceToDevice, stream) != hipSuccess;
+      if (e) return fail("halo pack failed");
+      if (!all_gather(send, recv, 2 * B * row)) return false;
+      if (pp_rank > 0) e |= hipMemcpy2DAsync(Pc, pimg, recv + ((size_t)(pp_rank - 1) * 2 + 1) * B * row, row, row, B, hipMemcpyDeviceToDevice, stream) != hipSuccess;
+      else e |= hipMemset2DAsync(Pc, pimg, 0, row, B, stream) != hipSuccess;
+      if (pp_rank < pp_world - 1) e |= hipMemcpy2DAsync(Pc + (size_t)(h + 1) * row, pimg, recv + ((size_t)(pp_rank + 1) * 2) * B * row, row, row, B, hipMemcpyDeviceToDevice, stream) != hipSuccess;
+      else e |= hipMemset2DAsync(Pc + (size_t)(h + 1) * row, pimg, 0, row, B, stream) != hipSuccess;
+      if (e) return fail("halo unpack failed");
+    }
+    ar.release(m);
+    return true;
+  }
+  // GroupNorm over the whole image from the ranks' partial sums; y may be the interior of a padded image (y_img elements per image)
+  bool groupnorm_pp(const bf16_t* x, bf16_t* y, long y_img, const std::string& prefix, int h, int wd, int C, float eps, bool silu, int level) {
+    if (!ok()) return false;
+    const size_t m = ar.mark();
+    const int G = u->cfg.norm_num_groups;
+    void* ws = ar.alloc(mx::gn_workspace_exact(B, h, wd, C, 0));
+    double* sums = (double*)ar.alloc((size_t)B * G * 2 * sizeof(double));
+    double* all = (double*)ar.alloc((size_t)pp_world * B * G * 2 * sizeof(double));
+    if (!ws || !sums || !all) return fail("workspace too small");
+    const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
+    if (ok() && dry) all_gather(sums, all, (size_t)B * G * 2 * sizeof(double));
+    if (ok() && !dry) {
+      if (mx::launch_gn_pp_partial(stream, x, B, h, wd, C, G, ws, sums)) return fail(std::string("groupnorm: ") + mx_last_error());
+      if (!all_gather(sums, all, (size_t)B * G * 2 * sizeof(double))) return false;
+      if (mx::launch_gn_pp_finish(stream, x, y, y_img, g, b, all, pp_world, B, h, wd, C, G, Htot >> level, eps, silu ? 1 : 0, ws))
+        return fail(std::string("groupnorm: ") + mx_last_error());
+    }
+    ar.release(m);
+    return ok();
+  }
+
   // ---- op wrappers -------------------------------------------------------------------------
   bool gemm(mx_gemm_desc& d, bool conv) {
     if (!ok()) return false;
@@ -116,8 +190,9 @@ struct Plan {
     return gemm(d, false);
   }
   bool conv(const bf16_t* x, int Hin, int Win, int Cin, const std::string& prefix, bf16_t* out, int Cout, int stride, int up,
-            int corner_patch, const float* rowbias = nullptr, int ldrb = 0, const void* residual = nullptr) {
+            int corner_patch, const float* rowbias = nullptr, int ldrb = 0, const void* residual = nullptr, int vhalo = 0) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+    d.vhalo = vhalo;
     const int Hv = Hin << up, Wv = Win << up;
     d.a = x; d.w = wb(prefix + ".weight", (size_t)Cout * 9 * Cin); d.bias = wf(prefix + ".bias", Cout);
     d.c = out; d.ldc = Cout; d.B = B; d.Hin = Hin; d.Win = Win; d.Cin = Cin;
@@ -176,6 +251,27 @@ struct Plan {
     bf16_t* out = alloc<bf16_t>((size_t)M * Cout);
     const size_t m = ar.mark();
     const int patch = level_patch(level);
+    if (is_pp()) {     // row-split image: GroupNorm from gathered sums, convs on halo'd inputs (modules/pp/{groupnorm,conv2d}.py)
+      bf16_t* n1p = alloc_padded(h, wd, Cin);
+      groupnorm_pp(x, interior(n1p, wd, Cin), (long)(h + 2) * wd * Cin, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, level);
+      halo_exchange(n1p, h, wd, Cin);
+      bf16_t* h1 = alloc<bf16_t>((size_t)M * Cout);
+      conv(n1p, h, wd, Cin, p + ".conv1", h1, Cout, 1, 0, 0, temb_all ? temb_all + temb_off : nullptr, temb_total, nullptr, 1);
+      temb_off += Cout;
+      bf16_t* n2p = alloc_padded(h, wd, Cout);
+      groupnorm_pp(h1, interior(n2p, wd, Cout), (long)(h + 2) * wd * Cout, p + ".norm2", h, wd, Cout, u->cfg.norm_eps, true, level);
+      halo_exchange(n2p, h, wd, Cout);
+      const bf16_t* sc = x;
+      if (Cin != Cout) {
+        bf16_t* s2 = alloc<bf16_t>((size_t)M * Cout);
+        linear(x, Cin, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin);
+        sc = s2;
+      }
+      conv(n2p, h, wd, Cout, p + ".conv2", out, Cout, 1, 0, 0, nullptr, 0, sc, 1);
+      ar.release(m);
+      dump(p, out, (size_t)M * Cout);
+      return out;
+    }
     bf16_t* n1 = alloc<bf16_t>((size_t)M * Cin);
     groupnorm(x, n1, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, patch);
     bf16_t* h1 = alloc<bf16_t>((size_t)M * Cout);
@@ -208,7 +304,8 @@ struct Plan {
     bf16_t* out = alloc<bf16_t>((size_t)M * C);
     const size_t m0 = ar.mark();
     bf16_t* n = alloc<bf16_t>((size_t)M * C);
-    groupnorm(x, n, p + ".norm", h, wd, C, u->cfg.transformer_norm_eps, false, level_patch(level));
+    if (is_pp()) groupnorm_pp(x, n, (long)L * C, p + ".norm", h, wd, C, u->cfg.transformer_norm_eps, false, level);
+    else groupnorm(x, n, p + ".norm", h, wd, C, u->cfg.transformer_norm_eps, false, level_patch(level));
     bf16_t* y = alloc<bf16_t>((size_t)M * C);
     linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C);
     bf16_t* ln = n;  // reuse
@@ -218,6 +315,13 @@ struct Plan {
     bf16_t* ao = alloc<bf16_t>((size_t)M * C);
     bf16_t* q2 = alloc<bf16_t>((size_t)M * C);
     bf16_t* ff = alloc<bf16_t>((size_t)M * 4 * C);
+    // patch-parallel: every rank gathers the other ranks' K rows and V^T columns (modules/pp/attn.py:137: all_gather(kv))
+    bf16_t* qk_all = nullptr; bf16_t* vt_all = nullptr;
+    if (is_pp()) {
+      if (L % 64 != 0) fail("patch-parallel: local tokens per image must be a multiple of 64 at every attention level");
+      qk_all = alloc<bf16_t>((size_t)pp_world * M * 2 * C);
+      vt_all = alloc<bf16_t>((size_t)pp_world * B * C * ldvt);
+    }
     KV* kvp = kv_for(C);
     if (!kvp && ok()) fail("no cross-attention K/V buffer for width " + std::to_string(C));
     for (int k = 0; k < layers && ok(); ++k) {
@@ -231,7 +335,16 @@ struct Plan {
         d.rows_per_batch = L; d.out_scale = MX_ATTN_QSCALE(0.125f);   // q segment only
         gemm(d, false);
       }
-      attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
+      if (is_pp()) {
+        all_gather(qk, qk_all, (size_t)M * 2 * C * 2);
+        all_gather(vt, vt_all, (size_t)B * C * ldvt * 2);
+        if (ok() && !dry &&
+            mx_attention_prescaled_chunked(stream, qk, 2 * C, qk_all + C, 2 * C, vt_all, ldvt, (int64_t)C * ldvt, ao, C, B, heads, L, pp_world * L, L,
+                                           (int64_t)L * 2 * C, (int64_t)M * 2 * C, (int64_t)B * C * ldvt))
+          fail(std::string("attention: ") + mx_last_error());
+      } else {
+        attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
+      }
       linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", y, C, M, C, C, y, C);
       // cross-attention (K/V of encoder_hidden_states precomputed for all layers of this width)
       layernorm(y, ln, b + ".norm2", M, C);
@@ -320,6 +433,12 @@ struct Plan {
     bf16_t* x0 = alloc<bf16_t>((size_t)B * h * wd * kConvInPad);
     if (ok() && !dry && mx::launch_prep_latent(stream, latents, io_dtype, x0, B, c.in_channels, h * wd, kConvInPad)) fail(mx_last_error());
     bf16_t* x = alloc<bf16_t>((size_t)B * h * wd * C0);
+    if (is_pp()) {
+      bf16_t* x0p = alloc_padded(h, wd, kConvInPad);
+      copy_to_padded(x0, x0p, h, wd, kConvInPad);
+      halo_exchange(x0p, h, wd, kConvInPad);
+      conv(x0p, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0, nullptr, 0, nullptr, 1);
+    } else
     conv(x0, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0);  // patches are cut from the true latent: no corner rule (unet.py:123-158)
     dump("conv_in", x, (size_t)B * h * wd * C0);
 
@@ -343,6 +462,15 @@ struct Plan {
       if (i != nlev - 1) {
         const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0";
         bf16_t* d = alloc<bf16_t>((size_t)B * (h / 2) * (wd / 2) * Cout);
+        if (is_pp()) {
+          if (h % 2) fail("patch-parallel: local rows must stay even down to the last level");
+          const size_t mk = ar.mark();
+          bf16_t* xp = alloc_padded(h, wd, Cout);
+          copy_to_padded(x, xp, h, wd, Cout);
+          halo_exchange(xp, h, wd, Cout);
+          conv(xp, h, wd, Cout, dp + ".conv", d, Cout, 2, 0, 0, nullptr, 0, nullptr, 1);
+          ar.release(mk);
+        } else
         conv(x, h, wd, Cout, dp + ".conv", d, Cout, 2, 0, level_patch(i));   // resnet.py:364-371
         h /= 2; wd /= 2;
         x = d;
@@ -377,6 +505,14 @@ struct Plan {
       if (i != nlev - 1) {
         const std::string upn = "up_blocks." + std::to_string(i) + ".upsamplers.0";
         bf16_t* d = alloc<bf16_t>((size_t)B * (2 * h) * (2 * wd) * Cout);
+        if (is_pp()) {
+          const size_t mk = ar.mark();
+          bf16_t* xp = alloc_padded(h, wd, Cout);
+          copy_to_padded(x, xp, h, wd, Cout);
+          halo_exchange(xp, h, wd, Cout);
+          conv(xp, h, wd, Cout, upn + ".conv", d, Cout, 1, 1, 0, nullptr, 0, nullptr, 1);
+          ar.release(mk);
+        } else
         conv(x, h, wd, Cout, upn + ".conv", d, Cout, 1, 1, level_patch(level - 1));  // resnet.py:316, 327-333
         h *= 2; wd *= 2;
         x = d;
@@ -386,12 +522,19 @@ struct Plan {
     // ---- out (unet.py:508-517) ----
     {
       const size_t M = (size_t)B * h * wd;
-      bf16_t* n = alloc<bf16_t>(M * C0);
-      groupnorm(x, n, "conv_norm_out", h, wd, C0, c.norm_eps, true, level_patch(0));
       const int Co = c.out_channels;
       const int ldo = (Co + 3) / 4 * 4;
       bf16_t* o = alloc<bf16_t>(M * ldo);
+      if (is_pp()) {
+        bf16_t* np_ = alloc_padded(h, wd, C0);
+        groupnorm_pp(x, interior(np_, wd, C0), (long)(h + 2) * wd * C0, "conv_norm_out", h, wd, C0, c.norm_eps, true, 0);
+        halo_exchange(np_, h, wd, C0);
+        conv(np_, h, wd, C0, "conv_out", o, ldo, 1, 0, 0, nullptr, 0, nullptr, 1);
+      } else {
+      bf16_t* n = alloc<bf16_t>(M * C0);
+      groupnorm(x, n, "conv_norm_out", h, wd, C0, c.norm_eps, true, level_patch(0));
       conv(n, h, wd, C0, "conv_out", o, ldo, 1, 0, level_patch(0));
+      }
       dump("conv_out", o, M * ldo);
       if (ok() && !dry && mx::launch_nhwc_to_nchw(stream, o, outp, io_dtype, B, Co, h * wd, ldo)) fail(mx_last_error());
     }
@@ -420,8 +563,14 @@ int check_cfg(const mx_unet_config* c) {
 int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
                  const void* text_embeds, const float* time_ids, void* out, int batch, int H, int W, int ctx_len, int gn_patch,
                  void* workspace, size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_bytes, bool dry,
-                 size_t* peak, bool lookup = false) {
+                 size_t* peak, bool lookup = false, const mx_pp_comm* comm = nullptr) {
   MX_CHECK(u != nullptr, "unet: null handle");
+  const bool pp = comm != nullptr && comm->world > 1;
+  if (pp) {
+    MX_CHECK(comm->rank >= 0 && comm->rank < comm->world && (dry || comm->all_gather != nullptr), "unet pp: bad communicator");
+    MX_CHECK(gn_patch == 0, "unet pp: patch-parallel runs the exact (is_sliced=False) arithmetic");
+    MX_CHECK(H % (1 << (u->cfg.n_levels - 1)) == 0, "unet pp: local rows must be divisible by 2^(levels-1)");
+  }
   MX_CHECK(batch > 0 && H > 0 && W > 0 && ctx_len > 0, "unet: bad shape");
   const int div = 1 << (u->cfg.n_levels - 1);
   MX_CHECK(H % div == 0 && W % div == 0, "unet: H, W must be divisible by 2^(levels-1)");
@@ -443,13 +592,14 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
     p.gn_patch = (gn_patch >= H && gn_patch >= W) ? 0 : gn_patch;
     p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
     p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
+    if (pp) { p.pp_rank = comm->rank; p.pp_world = comm->world; p.pp_ag = comm->all_gather; p.pp_ctx = comm->ctx; p.Htot = H * comm->world; }
     const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
     plan_peak = p.ar.peak;
     if (!okr) err = p.err;
     return okr;
   };
   bool okr;
-  if (dry || stage) {
+  if (dry || stage || pp) {     // (the all-gather callbacks of a patch-parallel forward cannot be captured)
     okr = enqueue((hipStream_t)stream);
   } else {
     const std::vector<uint64_t> key = {(uint64_t)batch, (uint64_t)H, (uint64_t)W, (uint64_t)ctx_len, (uint64_t)gn_patch, (uint64_t)io_dtype,
@@ -527,4 +677,32 @@ extern "C" int mx_unet_forward_trace(mx_unet* u, void* stream, const void* laten
   MX_CHECK(stage && stage_out, "unet_forward_trace: stage and stage_out required");
   return forward_impl(u, stream, latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out, batch, H, W, ctx_len, gn_patch,
                       workspace, workspace_bytes, stage, stage_out, stage_out_bytes, false, nullptr);
+}
+
+/* ---- patch-parallel (BASELINE configs[3]; distrifuser DistriUNetPP, models/distri_sdxl_unet_pp.py:15-216, sync mode) ---- */
+extern "C" size_t mx_unet_workspace_bytes_pp(const mx_unet* u, int batch, int H_local, int W, int ctx_len, int world) {
+  if (!u) return 0;
+  size_t peak = 0;
+  mx_pp_comm c; c.rank = 0; c.world = world; c.all_gather = nullptr; c.ctx = nullptr;
+  if (forward_impl(const_cast<mx_unet*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr, batch, H_local, W, ctx_len, 0,
+                   nullptr, 0, nullptr, nullptr, 0, true, &peak, false, &c))
+    return 0;
+  return peak + 4096;
+}
+
+extern "C" int mx_unet_forward_pp(mx_unet* u, void* stream, const void* latents_local, int io_dtype, const float* timesteps, const void* ehs,
+                                  const void* text_embeds, const float* time_ids, void* out_local, int batch, int H_local, int W, int ctx_len,
+                                  const mx_pp_comm* comm, void* workspace, size_t workspace_bytes) {
+  MX_CHECK(comm != nullptr, "unet_forward_pp: null communicator");
+  return forward_impl(u, stream, latents_local, io_dtype, timesteps, ehs, text_embeds, time_ids, out_local, batch, H_local, W, ctx_len, 0,
+                      workspace, workspace_bytes, nullptr, nullptr, 0, false, nullptr, false, comm);
+}
+
+/* host-only walk of the patch-parallel plan that calls comm->all_gather for every exchange of one forward, in order, with
+ * send / recv = 0x1000 + the byte offset the region will have inside the workspace (no launches, no GPU): what a caller needs to
+ * pre-register buffers, and what tests/test_pp_gloo.py replays over gloo to check the bookkeeping */
+extern "C" int mx_unet_pp_comm_plan(const mx_unet* u, int batch, int H_local, int W, int ctx_len, const mx_pp_comm* comm) {
+  MX_CHECK(u && comm && comm->all_gather, "unet_pp_comm_plan: bad arguments");
+  return forward_impl(const_cast<mx_unet*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr, batch, H_local, W, ctx_len, 0,
+                      nullptr, 0, nullptr, nullptr, 0, true, nullptr, false, comm);
 }

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("corner_patch", C.c_int),
         ("a_batch_rows", C.c_int), ("a_row_off", C.c_int), ("c_batch_rows", C.c_int), ("c_row_off", C.c_int),
-        ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float),
+        ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("vhalo", C.c_int),
     ]
 
 
@@ -52,6 +52,13 @@ class MMDiTConfigC(C.Structure):
         ("num_attention_heads", C.c_int), ("joint_attention_dim", C.c_int), ("pooled_projection_dim", C.c_int),
         ("pos_embed_max_size", C.c_int), ("dual_attention", C.c_int * 64), ("norm_eps", C.c_float),
     ]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class PPComm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("all_gather", ALLGATHER_FN), ("ctx", C.c_void_p)]
 
 
 class WeightEntry(C.Structure):
@@ -84,6 +91,10 @@ SYMBOLS = {
     "mx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
     "mx_unet_forward_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz,
                                    C.c_char_p, _vp, _sz]),
+    "mx_unet_workspace_bytes_pp": (_sz, [_vp, _i, _i, _i, _i, _i]),
+    "mx_unet_forward_pp": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(PPComm), _vp, _sz]),
+    "mx_unet_pp_comm_plan": (_i, [_vp, _i, _i, _i, _i, C.POINTER(PPComm)]),
+    "mx_attention_prescaled_chunked": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64]),
     "mx_layernorm_mod": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f]),
     "mx_rmsnorm_heads": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _f]),
     "mx_mmdit_create": (_vp, [C.POINTER(MMDiTConfigC)]),

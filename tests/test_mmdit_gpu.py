@@ -251,7 +251,7 @@ def _kinds_launched(fn):
         lib.check(l.mx_profile_collect(buf), "mx_profile_collect")
     finally:
         l.mx_profile_enable(0)
-    return {k: int(buf[4 * k]) for k in range(11) if buf[4 * k] > 0}
+    return {k: int(buf[4 * k]) for k in range(12) if buf[4 * k] > 0}
 
 
 @pytest.mark.parametrize("rows,n,k,kinds", [(1024, 1600, 128, {6}), (1024, 640, 192, {6, 8}), (8192, 1536, 128, {10}), (1000, 1024, 128, {8, 10}),

@@ -248,7 +248,7 @@ class _expect_v3:
         lib.check(self.l.mx_profile_collect(buf), "mx_profile_collect")
         self.l.mx_profile_enable(0)
         if exc[0] is None:
-            launches = {k: int(buf[4 * k]) for k in range(11) if buf[4 * k] > 0}
+            launches = {k: int(buf[4 * k]) for k in range(12) if buf[4 * k] > 0}
             assert set(launches) == {10}, f"expected only the 256x256 GEMM kernel, profiler saw kinds {launches}"
         return False
 

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sduss_amd import ops  # noqa: E402
 
-SHAPES = [(8, 10, 4096, 4096), (8, 20, 1024, 1024), (8, 24, 4429, 4429), (8, 20, 1024, 77)]   # (B, H, Lq, Lk)
+SHAPES = [(8, 10, 4096, 4096), (8, 20, 1024, 1024), (8, 24, 4429, 4429), (8, 20, 1024, 77), (8, 10, 4096, 77)]   # (B, H, Lq, Lk)
 
 
 def main():
