@@ -79,6 +79,11 @@ def parse():
     ap.add_argument("--stream-rates", type=str, default="1.0,0.8,1.2",
                     help="offered loads in requests/s PER GPU (the reference sweeps {0.8..1.2} x N_gpu req/s, scripts/paper/scalibility.sh:12-13); "
                          "the first is the main leg, the others run stream-requests/5 requests each")
+    ap.add_argument("--mix", type=int, default=0, help="configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
+                                                       "reference traces exp/<model>/qps_*.csv) per offered load of --mix-rates; reports the reference's metrics "
+                                                       "(scripts/draw/get_metric.py: SLO rate, average latency, goodput, throughput)")
+    ap.add_argument("--mix-rates", type=str, default="1.0,2.0")
+    ap.add_argument("--mix-max-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -125,6 +130,57 @@ def run_stream(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, wo
         active = [r for r in active if not r.done()]
     lat = [r.finish - r.arrival for r in done]
     return lat, (min(r.arrival for r in done), max(r.finish for r in done))
+
+
+REF_DEADLINES_S = {  # SLO = 5 deadlines of the reference's metric script (scripts/draw/get_metric.py:45-57), seconds
+    "sdxl": {512: 16.35, 768: 17.5, 1024: 19.31}, "sd3": {512: 11.0, 768: 18.0, 1024: 30.0}}
+REF_STEP_MIX = ((30, 0.054), (35, 0.178), (40, 0.460), (45, 0.228), (50, 0.080))   # step histogram of exp/sdxl/qps_1.0.csv
+
+
+def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world, model):
+    """configs[4]: a mixed-resolution Poisson stream with the column shape of the reference traces (arrival ms, resolution, steps;
+    tests/server/direct_test.py replays them): resolutions uniform over 512 / 768 / 1024, steps by the traces' histogram, exponential
+    inter-arrivals (numpy seed 10086), placed by the greedy least-outstanding-pixels dispatcher, continuous batching FCFS with
+    at most --mix-max-batch requests per step; a mixed step runs its resolutions as concurrent launch sequences (pipeline.py).
+    Metrics as scripts/draw/get_metric.py computes them (deadlines: its SLO = 5 table, measured on H100 by the reference)."""
+    from sduss_amd import dp
+    n_total = n_per_gpu * world
+    rng = np.random.RandomState(10086)
+    arrivals = np.cumsum(rng.exponential(1.0 / (rate_per_gpu * world), size=n_total))
+    res_all = rng.choice([512, 768, 1024], size=n_total)
+    steps_all = rng.choice([s for s, _ in REF_STEP_MIX], size=n_total, p=[p for _, p in REF_STEP_MIX])
+    mine = dp.my_share(n_total, rank, world, [int(r) for r in res_all])
+    pending = []
+    for i in mine:
+        if hasattr(cfg, "joint_attention_dim"):
+            from sduss_amd.pipeline_sd3 import synthetic_sd3_request
+            r = synthetic_sd3_request(5000 + i, int(res_all[i]), int(steps_all[i]), cfg, den, device, shared=shared)
+        else:
+            from sduss_amd.pipeline import synthetic_request
+            r = synthetic_request(5000 + i, int(res_all[i]), int(steps_all[i]), cfg, den, device, shared=shared)
+        r.arrival = float(arrivals[i])
+        pending.append(r)
+    active, done = [], []
+    t0 = time.perf_counter()
+    while pending or active:
+        now = time.perf_counter() - t0
+        while pending and len(active) < args.mix_max_batch and pending[0].arrival <= now:
+            active.append(pending.pop(0))
+        if not active:
+            time.sleep(max(0.0, pending[0].arrival - now))
+            continue
+        by_res = {}
+        for r in active:
+            by_res.setdefault(str(r.resolution), []).append(r)
+        den.denoising_step(by_res, is_sliced=args.sliced, patch_size=256)
+        torch.cuda.synchronize()
+        now = time.perf_counter() - t0
+        for r in [r for r in active if r.done()]:
+            r.finish = now
+            done.append(r)
+        active = [r for r in active if not r.done()]
+    rows = [(r.resolution, r.finish - r.arrival) for r in done]
+    return rows, (min(r.arrival for r in done), max(r.finish for r in done))
 
 
 def probe_diffusers():
@@ -299,6 +355,29 @@ def main():
             result["p50_latency_s"] = legs[0]["p50_latency_s"]
             result["p90_latency_s"] = legs[0]["p90_latency_s"]
             result["stream_throughput_images_per_s"] = legs[0]["throughput_images_per_s"]
+
+    # ---- configs[4] leg: mixed-resolution stream, the reference's metrics ----
+    if args.mix > 0:
+        legs = []
+        for rate in [float(x) for x in args.mix_rates.split(",") if x]:
+            rows, window = run_mix(den, cfg, args, device, shared, rate, args.mix, rank, world, args.model)
+            rows_all, window = dp.gather_stream_stats(rows, window, dist)
+            if rank == 0:
+                ddl = REF_DEADLINES_S[args.model]
+                lat = [l for _r, l in rows_all]
+                ok = sum(1 for r, l in rows_all if l <= ddl[int(r)])
+                span = window[1] - window[0]
+                legs.append({"offered_req_per_s_per_gpu": rate, "requests": len(rows_all), "slo_rate": ok / len(rows_all), "avg_latency_s": float(np.mean(lat)),
+                             "p50_latency_s": float(np.percentile(lat, 50)), "p90_latency_s": float(np.percentile(lat, 90)),
+                             "goodput_req_per_s": ok / span, "throughput_req_per_s": len(rows_all) / span,
+                             "p50_by_resolution_s": {str(rr): float(np.percentile([l for r, l in rows_all if int(r) == rr], 50)) for rr in (512, 768, 1024)
+                                                     if any(int(r) == rr for r, _ in rows_all)}})
+            if dist is not None:
+                dist.barrier()
+        if rank == 0:
+            result["mixed_stream"] = {"legs": legs, "trace": "synthetic, shape of exp/<model>/qps_*.csv: resolutions uniform over 512/768/1024, steps 30-50 by the "
+                                                              "traces' histogram, exponential arrivals seed 10086", "deadlines_s": REF_DEADLINES_S[args.model],
+                                      "max_batch": args.mix_max_batch, "policy": "FCFS mixed batching; resolutions of a step run as concurrent launch sequences"}
 
     # ---- CPU baseline leg ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

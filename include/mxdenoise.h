@@ -126,6 +126,11 @@ typedef struct mx_gemm_desc {
    * ([B, Hin + 2, Win, Cin], `a` pointing at the top halo row of image 0); taps that leave the image vertically read those
    * rows (the neighbour ranks' boundary rows, or zeros at the true image border) instead of zero padding. */
   int vhalo;
+  /* mx_gemm: the A operand as a concatenation along K read in place: columns [0, k_split) from a (row stride lda), columns
+   * [k_split, K) from a2 (row stride lda2); k_split % 64 == 0.  a2 == NULL: one source.  (The 1x1 shortcut conv of an up block
+   * reads torch.cat([hidden_states, res_hidden_states]); not combined with the joint-sequence row remap.) */
+  const void* a2;
+  int lda2, k_split;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -175,6 +180,12 @@ size_t mx_groupnorm_nhwc_workspace_bytes(int B, int H, int W, int C);
 int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const float* gamma, const float* beta,
                       int B, int H, int W, int C, int groups, float eps, int silu, int patch,
                       void* workspace);
+
+/* The same over a channel concatenation read in place: channels [0, C1) from x ([B, H, W, C1]), channels [C1, C) from x2
+ * ([B, H, W, C - C1]); y is [B, H, W, C].  Serves the up blocks' torch.cat([hidden_states, res_hidden_states], dim=1) feeding
+ * norm1 (unet_2d_blocks.py via unet.py:458-462) without materialising the concatenation.  x2 == NULL: mx_groupnorm_nhwc. */
+int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const void* x2, void* y, const float* gamma, const float* beta,
+                          int B, int H, int W, int C, int groups, float eps, int silu, int patch, void* workspace);
 
 /* ------------------------------------------------------------------------------------------
  * Outer boundary: the SDXL UNet in the model slot.

@@ -32,6 +32,8 @@ struct GemmArgs {
   float rms_eps;
   int stagger_ticks;   // experiment (gemm_bf16_v3.hip)
   int vhalo;           // conv: images stored with one halo row above and below (patch-parallel)
+  const bf16_t* a2;    // GEMM: columns [k_split, K) of the A operand come from a2 (row stride lda2); nullptr = one source
+  int lda2, k_split;
 };
 
 // row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)

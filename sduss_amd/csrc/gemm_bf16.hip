@@ -55,12 +55,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
   // activation row descriptors
   int xoff[4];           // GEMM: element offset of the row start (or -1 when the row is out of range)
+  int xoff2[4];          // the same inside a2 (dual-source A operand)
   int cb[4], cy[4], cx[4];  // CONV: batch, centre y/x in virtual-input coordinates (cb = -1: invalid row)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + srow + 32 * i;
     if constexpr (!CONV) {
       xoff[i] = (m < p.M) ? (int)(gemm_in_row(p, m) * p.lda) + sch * 8 : -1;
+      xoff2[i] = (p.a2 != nullptr && m < p.M) ? m * p.lda2 + sch * 8 : 0;
     } else {
       if (m < p.M) {
         const int hw = p.Hout * p.Wout;
@@ -89,8 +91,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int k0 = kt * BK;
     if constexpr (!CONV) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        rx[i] = (xoff[i] >= 0) ? *reinterpret_cast<const u32x4*>(p.a + xoff[i] + k0) : zero4;
+      for (int i = 0; i < 4; ++i) {
+        if (p.a2 != nullptr && k0 >= p.k_split) rx[i] = (xoff[i] >= 0) ? *reinterpret_cast<const u32x4*>(p.a2 + xoff2[i] + (k0 - p.k_split)) : zero4;
+        else rx[i] = (xoff[i] >= 0) ? *reinterpret_cast<const u32x4*>(p.a + xoff[i] + k0) : zero4;
+      }
     } else {
       const int tap = k0 / p.Cin;
       const int c0 = k0 - tap * p.Cin;
@@ -208,7 +212,7 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   for (int c = 0; c < 5; ++c) {
     const int bn = cands[c].bn, rows = cands[c].rows;
     if (d->N % bn != 0 || d->M < rows) continue;
-    if (bn == 256 && (conv || v3_disabled || !fits32)) continue;
+    if (bn == 256 && (conv || v3_disabled || !fits32 || d->a2)) continue;
     if (rows == 128 && small_disabled) continue;
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;
@@ -230,6 +234,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   GemmArgs a;
   a.stagger_ticks = 0;
   a.vhalo = conv ? d->vhalo : 0;
+  a.a2 = conv ? nullptr : (const bf16_t*)d->a2; a.lda2 = d->lda2; a.k_split = d->k_split;
   a.a = (const bf16_t*)d->a; a.w = (const bf16_t*)d->w; a.c = d->c;
   a.bias = d->bias; a.rowbias = d->rowbias; a.residual = (const bf16_t*)d->residual; a.vt = (bf16_t*)d->vt;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr; a.ldrb = d->ldrb;
@@ -242,7 +247,11 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   static const int xcd_map = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
   a.xcd_map = xcd_map;
 
-  if (!conv) {
+  if (!conv && d->a2) {
+    MX_CHECK(d->k_split > 0 && d->k_split < d->K && d->k_split % BK == 0, "gemm: k_split must be a multiple of 64 inside (0, K)");
+    MX_CHECK(d->lda >= d->k_split && d->lda % 8 == 0 && d->lda2 >= d->K - d->k_split && d->lda2 % 8 == 0, "gemm: bad lda / lda2 for the split A operand");
+    MX_CHECK(d->a_batch_rows <= 0 && ((uintptr_t)d->a2 & 15) == 0 && (long)d->M * d->lda2 < 2147483647L, "gemm: split A operand excludes the row remap and needs 16-byte alignment");
+  } else if (!conv) {
     MX_CHECK(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda must be >= K and a multiple of 8");
   } else {
     MX_CHECK(d->Cin % BK == 0 && d->K == 9 * d->Cin, "conv3x3: Cin must be a multiple of 64 and K = 9*Cin");

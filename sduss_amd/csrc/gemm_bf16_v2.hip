@@ -170,8 +170,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < WI; ++i) wsrc[i] += BK2 * 2;
     if constexpr (!CONV) {
+      if (p.a2 != nullptr && is_kt * BK2 == p.k_split) {       // the A operand continues in its second source (gemm_args.h)
+        int tm, tn;
+        gemm_tile_of_block(is_tile, mt, p.N / BN, p.xcd_map, tm, tn);
 #pragma unroll
-      for (int i = 0; i < XI; ++i) xsrc[i] += BK2 * 2;
+        for (int i = 0; i < XI; ++i) {
+          const int row = (i * 512 + tid) >> 3;
+          const int m = tm * BM2 + row;
+          const int mc = m < p.M ? m : p.M - 1;
+          xsrc[i] = reinterpret_cast<const char*>(p.a2) + ((long)mc * p.lda2 + swz2(row, cs) * 8) * 2;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) xsrc[i] += BK2 * 2;
+      }
     } else {
       if (++in_tap == tiles_per_tap) {
         in_tap = 0;

@@ -25,7 +25,16 @@ struct GnGeom {
   int L;        // pixel lanes per block
   int th, tw;   // spatial tile
   int tiles_y, tiles_x;
+  // channel concatenation read in place (the UNet's skip connections, unet.py:458-462): channels [0, C1) come from x (row
+  // stride C1), channels [C1, C) from x2 (row stride C - C1); x2 == nullptr: one source of C channels
+  const bf16_t* x2;
+  int C1;
 };
+
+__device__ __forceinline__ const bf16_t* gn_src(const bf16_t* x, const GnGeom& g, long pix, int ch) {
+  if (g.x2 == nullptr) return x + pix * g.C + ch;
+  return ch < g.C1 ? x + pix * g.C1 + ch : g.x2 + pix * (g.C - g.C1) + (ch - g.C1);
+}
 
 __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, GnGeom g) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [L][C][2]
@@ -42,8 +51,8 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
     const int npix = g.th * g.tw;
     for (int pi = pl; pi < npix; pi += g.L) {
       const int py = pi / g.tw, px = pi - py * g.tw;
-      const long off = (((long)b * g.H + ty * g.th + py) * g.W + tx * g.tw + px) * g.C + cv * 8;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+      const long pix = ((long)b * g.H + ty * g.th + py) * g.W + tx * g.tw + px;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(gn_src(x, g, pix, cv * 8));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float lo = bf16lo_to_f32(v[e]), hi = bf16hi_to_f32(v[e]);
@@ -135,8 +144,7 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, hw);
   for (int pi = p0 + pl; pi < p1; pi += g.L) {
-    const long off = ((long)b * hw + pi) * g.C + cv * 8;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(gn_src(x, g, (long)b * hw + pi, cv * 8));
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -192,6 +200,7 @@ __global__ __launch_bounds__(64) void gn_pp_coef_kernel(const double* __restrict
 static int gn_geom(GnGeom& g, int B, int H, int W, int C, int patch) {
   MX_CHECK(C % 8 == 0 && C / 8 <= 1024, "groupnorm: C must be a multiple of 8 and <= 8192");
   g.B = B; g.H = H; g.W = W; g.C = C;
+  g.x2 = nullptr; g.C1 = C;
   g.tpr = C / 8;
   g.L = 1024 / g.tpr;
   if (g.L > 32) g.L = 32;
@@ -226,13 +235,21 @@ extern "C" size_t mx_groupnorm_nhwc_workspace_bytes(int B, int H, int W, int C) 
 extern "C" int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const float* gamma, const float* beta,
                                  int B, int H, int W, int C, int groups, float eps, int silu, int patch,
                                  void* workspace) {
+  return mx_groupnorm_nhwc_cat(stream, x, C, nullptr, y, gamma, beta, B, H, W, C, groups, eps, silu, patch, workspace);
+}
+
+extern "C" int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const void* x2, void* y, const float* gamma, const float* beta,
+                                     int B, int H, int W, int C, int groups, float eps, int silu, int patch,
+                                     void* workspace) {
   using namespace mx;
   MX_CHECK(x && y && gamma && beta && workspace, "groupnorm: null operand");
+  MX_CHECK(x2 == nullptr || (C1 > 0 && C1 < C && C1 % 8 == 0 && (C - C1) % 8 == 0), "groupnorm: bad channel split");
   MX_CHECK(groups > 0 && C % groups == 0, "groupnorm: C % groups != 0");
   if (patch >= H && patch >= W) patch = 0;  // one patch per image == exact GroupNorm
   MX_CHECK(patch == 0 || patch >= 2, "groupnorm: patch must be 0 or >= 2");
   GnGeom g;
   if (gn_geom(g, B, H, W, C, patch)) return 1;
+  if (x2) { g.x2 = (const bf16_t*)x2; g.C1 = C1; }
   const int ntiles = g.tiles_y * g.tiles_x;
   float* part = (float*)workspace;
   float* coef = part + (size_t)B * ntiles * C * 2;
@@ -261,9 +278,10 @@ extern "C" int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const flo
 
 namespace mx {
 // local part: stats -> per-(image, group) fp64 sums.  workspace: gn_workspace_exact(B, H, W, C, 0) bytes; sums: double [B][groups][2]
-int launch_gn_pp_partial(hipStream_t s, const void* x, int B, int H, int W, int C, int groups, void* workspace, double* sums) {
+int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, int B, int H, int W, int C, int groups, void* workspace, double* sums) {
   GnGeom g;
   if (gn_geom(g, B, H, W, C, 0)) return 1;
+  if (x2) { g.x2 = (const bf16_t*)x2; g.C1 = C1; }
   const int ntiles = g.tiles_y * g.tiles_x;
   float* part = (float*)workspace;
   const int threads = ((g.tpr * g.L + 63) / 64) * 64;
@@ -275,10 +293,11 @@ int launch_gn_pp_partial(hipStream_t s, const void* x, int B, int H, int W, int 
   return 0;
 }
 // all_sums: double [world][B][groups][2]; y rows of image b start at y + b * y_img_elems; H = LOCAL rows, H_total = rows of the whole image
-int launch_gn_pp_finish(hipStream_t s, const void* x, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
+int launch_gn_pp_finish(hipStream_t s, const void* x, int C1, const void* x2, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
                         int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace) {
   GnGeom g;
   if (gn_geom(g, B, H, W, C, 0)) return 1;
+  if (x2) { g.x2 = (const bf16_t*)x2; g.C1 = C1; }
   float* coef = (float*)workspace + (size_t)B * g.tiles_y * g.tiles_x * C * 2;
   const double cnt = (double)H_total * W * (C / groups);
   hipLaunchKernelGGL(gn_pp_coef_kernel, dim3(groups, B), dim3(64), 0, s, all_sums, gamma, beta, coef, B, C, groups, world, cnt, eps);

@@ -33,8 +33,8 @@ int launch_time_embed(hipStream_t s, const float* timesteps, const void* text_em
                       void* tsin, void* addin, int B, int d0, int text_dim, int da);
 int launch_concat(hipStream_t s, const void* a, const void* b, void* out, long M, int C1, int C2);
 size_t gn_workspace_exact(int B, int H, int W, int C, int patch);
-int launch_gn_pp_partial(hipStream_t s, const void* x, int B, int H, int W, int C, int groups, void* workspace, double* sums);
-int launch_gn_pp_finish(hipStream_t s, const void* x, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
+int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, int B, int H, int W, int C, int groups, void* workspace, double* sums);
+int launch_gn_pp_finish(hipStream_t s, const void* x, int C1, const void* x2, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
                         int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace);
 }  // namespace mx
 extern "C" int mx_attention_prescaled_chunked(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
@@ -153,7 +153,8 @@ struct Plan {
     return true;
   }
   // GroupNorm over the whole image from the ranks' partial sums; y may be the interior of a padded image (y_img elements per image)
-  bool groupnorm_pp(const bf16_t* x, bf16_t* y, long y_img, const std::string& prefix, int h, int wd, int C, float eps, bool silu, int level) {
+  bool groupnorm_pp(const bf16_t* x, bf16_t* y, long y_img, const std::string& prefix, int h, int wd, int C, float eps, bool silu, int level,
+                    const bf16_t* x2 = nullptr, int C1 = 0) {
     if (!ok()) return false;
     const size_t m = ar.mark();
     const int G = u->cfg.norm_num_groups;
@@ -164,9 +165,9 @@ struct Plan {
     const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
     if (ok() && dry) all_gather(sums, all, (size_t)B * G * 2 * sizeof(double));
     if (ok() && !dry) {
-      if (mx::launch_gn_pp_partial(stream, x, B, h, wd, C, G, ws, sums)) return fail(std::string("groupnorm: ") + mx_last_error());
+      if (mx::launch_gn_pp_partial(stream, x, C1, x2, B, h, wd, C, G, ws, sums)) return fail(std::string("groupnorm: ") + mx_last_error());
       if (!all_gather(sums, all, (size_t)B * G * 2 * sizeof(double))) return false;
-      if (mx::launch_gn_pp_finish(stream, x, y, y_img, g, b, all, pp_world, B, h, wd, C, G, Htot >> level, eps, silu ? 1 : 0, ws))
+      if (mx::launch_gn_pp_finish(stream, x, C1, x2, y, y_img, g, b, all, pp_world, B, h, wd, C, G, Htot >> level, eps, silu ? 1 : 0, ws))
         return fail(std::string("groupnorm: ") + mx_last_error());
     }
     ar.release(m);
@@ -182,9 +183,10 @@ struct Plan {
     return true;
   }
   bool linear(const bf16_t* a, int lda, const std::string& wname, const std::string& bname, void* c, int ldc, int M, int N,
-              int K, const void* residual = nullptr, int ldr = 0, int flags = 0, float out_scale = 0.f) {
+              int K, const void* residual = nullptr, int ldr = 0, int flags = 0, float out_scale = 0.f, const bf16_t* a2 = nullptr, int lda2 = 0) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
     d.out_scale = out_scale;
+    if (a2) { d.a2 = a2; d.lda2 = lda2; d.k_split = lda; }      // A = [a | a2] along K, read in place
     d.a = a; d.lda = lda; d.w = wb(wname, (size_t)N * K); d.bias = bname.empty() ? nullptr : wf(bname, N);
     d.c = c; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.residual = residual; d.ldr = ldr; d.flags = flags;
     return gemm(d, false);
@@ -203,7 +205,8 @@ struct Plan {
     d.residual = residual; d.ldr = Cout;
     return gemm(d, true);
   }
-  bool groupnorm(const bf16_t* x, bf16_t* y, const std::string& prefix, int h, int wd, int C, float eps, bool silu, int patch) {
+  bool groupnorm(const bf16_t* x, bf16_t* y, const std::string& prefix, int h, int wd, int C, float eps, bool silu, int patch,
+                 const bf16_t* x2 = nullptr, int C1 = 0) {
     if (!ok()) return false;
     const size_t m = ar.mark();
     const size_t need = mx::gn_workspace_exact(B, h, wd, C, patch);
@@ -211,7 +214,7 @@ struct Plan {
     if (!ws) return fail("workspace too small");
     const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
     if (ok() && !dry) {
-      if (mx_groupnorm_nhwc(stream, x, y, g, b, B, h, wd, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, patch, ws))
+      if (mx_groupnorm_nhwc_cat(stream, x, x2 ? C1 : C, x2, y, g, b, B, h, wd, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, patch, ws))
         fail(std::string("groupnorm: ") + mx_last_error());
     }
     ar.release(m);
@@ -246,14 +249,17 @@ struct Plan {
 
   // ---- blocks ------------------------------------------------------------------------------
   // modules/resnet.py:390-460
-  bf16_t* resnet(const std::string& p, const bf16_t* x, int h, int wd, int Cin, int Cout, int level) {
+  // x2 != nullptr: the block's input is the channel concatenation [x (Cin - C2 channels) | x2 (C2 channels)] of an up block
+  // (unet.py:458-462 torch.cat), read in place by norm1 and by the 1x1 shortcut
+  bf16_t* resnet(const std::string& p, const bf16_t* x, int h, int wd, int Cin, int Cout, int level, const bf16_t* x2 = nullptr, int C2 = 0) {
     const int M = B * h * wd;
+    const int C1 = Cin - C2;
     bf16_t* out = alloc<bf16_t>((size_t)M * Cout);
     const size_t m = ar.mark();
     const int patch = level_patch(level);
     if (is_pp()) {     // row-split image: GroupNorm from gathered sums, convs on halo'd inputs (modules/pp/{groupnorm,conv2d}.py)
       bf16_t* n1p = alloc_padded(h, wd, Cin);
-      groupnorm_pp(x, interior(n1p, wd, Cin), (long)(h + 2) * wd * Cin, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, level);
+      groupnorm_pp(x, interior(n1p, wd, Cin), (long)(h + 2) * wd * Cin, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, level, x2, C1);
       halo_exchange(n1p, h, wd, Cin);
       bf16_t* h1 = alloc<bf16_t>((size_t)M * Cout);
       conv(n1p, h, wd, Cin, p + ".conv1", h1, Cout, 1, 0, 0, temb_all ? temb_all + temb_off : nullptr, temb_total, nullptr, 1);
@@ -264,7 +270,8 @@ struct Plan {
       const bf16_t* sc = x;
       if (Cin != Cout) {
         bf16_t* s2 = alloc<bf16_t>((size_t)M * Cout);
-        linear(x, Cin, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin);
+        if (x2) linear(x, C1, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin, nullptr, 0, 0, 0.f, x2, C2);
+        else linear(x, Cin, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin);
         sc = s2;
       }
       conv(n2p, h, wd, Cout, p + ".conv2", out, Cout, 1, 0, 0, nullptr, 0, sc, 1);
@@ -273,7 +280,7 @@ struct Plan {
       return out;
     }
     bf16_t* n1 = alloc<bf16_t>((size_t)M * Cin);
-    groupnorm(x, n1, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, patch);
+    groupnorm(x, n1, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, patch, x2, C1);
     bf16_t* h1 = alloc<bf16_t>((size_t)M * Cout);
     conv(n1, h, wd, Cin, p + ".conv1", h1, Cout, 1, 0, patch, temb_all ? temb_all + temb_off : nullptr, temb_total);
     temb_off += Cout;
@@ -282,7 +289,8 @@ struct Plan {
     const bf16_t* sc = x;
     if (Cin != Cout) {
       bf16_t* s2 = alloc<bf16_t>((size_t)M * Cout);
-      linear(x, Cin, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin);
+      if (x2) linear(x, C1, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin, nullptr, 0, 0, 0.f, x2, C2);
+      else linear(x, Cin, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin);
       sc = s2;
     }
     conv(n2, h, wd, Cout, p + ".conv2", out, Cout, 1, 0, patch, nullptr, 0, sc);
@@ -491,11 +499,8 @@ struct Plan {
       const int Cout = c.block_out_channels[level];
       for (int j = 0; j < c.layers_per_block + 1 && ok(); ++j) {
         const Skip sk = skips.back(); skips.pop_back();
-        const size_t M = (size_t)B * h * wd;
-        bf16_t* cat = alloc<bf16_t>(M * (Ccur + sk.C));
-        if (ok() && !dry && mx::launch_concat(stream, x, sk.t, cat, (long)M, Ccur, sk.C)) fail(mx_last_error());
         const std::string rp = "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
-        x = resnet(rp, cat, h, wd, Ccur + sk.C, Cout, level);
+        x = resnet(rp, x, h, wd, Ccur + sk.C, Cout, level, sk.t, sk.C);   // torch.cat([x, skip], dim=1) is never materialised
         Ccur = Cout;
         if (c.down_has_attn[level]) {
           const std::string ap = "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j);

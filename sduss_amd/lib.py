@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("corner_patch", C.c_int),
         ("a_batch_rows", C.c_int), ("a_row_off", C.c_int), ("c_batch_rows", C.c_int), ("c_row_off", C.c_int),
-        ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("vhalo", C.c_int),
+        ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("vhalo", C.c_int), ("a2", C.c_void_p), ("lda2", C.c_int), ("k_split", C.c_int),
     ]
 
 
@@ -83,6 +83,7 @@ SYMBOLS = {
     "mx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "mx_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mx_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "mx_groupnorm_nhwc_cat": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "mx_unet_create": (_vp, [C.POINTER(UNetConfigC)]),
     "mx_unet_destroy": (None, [_vp]),
     "mx_unet_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),

@@ -350,3 +350,41 @@ def test_gemm_out_scale(cuda_device):
         want = torch.cat([full[:, 0] * 0.18, full[:, 1]], dim=1)
         _close(c, want, 2.0 ** -7, f"qkv q_scale {dim}")
         _close(ops.unpack_vt(vt, rows), full[:, 2].reshape(nb, rows, dim), 2.0 ** -7, "qkv q_scale leaves V alone")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# channel concatenation read in place (up blocks: torch.cat([hidden, skip], dim=1) feeding norm1 and the 1x1 shortcut)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c1,c2,hw,patch", [(64, 64, 16, 0), (1280, 640, 8, 0), (320, 640, 16, 8), (640, 320, 32, 0)])
+def test_groupnorm_cat(cuda_device, c1, c2, hw, patch):
+    """groups that straddle the boundary between the two sources included (1920 / 32 = 60 channels per group, split at 1280)"""
+    from sduss_amd import lib
+    l = lib.load()
+    g = torch.Generator().manual_seed(c1 + c2 + hw)
+    c = c1 + c2
+    x = _rt(torch.randn(2, c, hw, hw, generator=g) * 1.5 + 0.7); ga = torch.randn(c, generator=g); be = torch.randn(c, generator=g)
+    want = F.silu(ref._gn(x, 32, ga, be, 1e-5, patch if patch else None))
+    xa = _bf(_nhwc(x[:, :c1])).cuda(); xb = _bf(_nhwc(x[:, c1:])).cuda()
+    y = torch.empty(2, hw, hw, c, dtype=torch.bfloat16, device="cuda")
+    ws = torch.empty(l.mx_groupnorm_nhwc_workspace_bytes(2, hw, hw, c), dtype=torch.uint8, device="cuda")
+    gg, bb = ga.cuda(), be.cuda()
+    lib.check(l.mx_groupnorm_nhwc_cat(lib.current_stream(), xa.data_ptr(), c1, xb.data_ptr(), y.data_ptr(), gg.data_ptr(), bb.data_ptr(),
+                                      2, hw, hw, c, 32, 1e-5, 1, patch, ws.data_ptr()), "mx_groupnorm_nhwc_cat")
+    _close(y.permute(0, 3, 1, 2), want, 2.0 ** -7, f"groupnorm cat {c1}+{c2}")
+
+
+@pytest.mark.parametrize("m,n,k1,k2", [(300, 320, 128, 64), (8192, 1280, 1280, 640), (2048, 640, 640, 640), (1000, 192, 64, 192)])
+def test_gemm_split_a_operand(cuda_device, m, n, k1, k2):
+    """A = [a | a2] along K read in place (generic kernel and the 256 / 128-row pipelined kernels)"""
+    from sduss_amd import lib
+    l = lib.load()
+    g = torch.Generator().manual_seed(m + n + k1)
+    a1 = _rt(torch.randn(m, k1, generator=g)); a2 = _rt(torch.randn(m, k2, generator=g))
+    w = _rt(torch.randn(n, k1 + k2, generator=g) * (k1 + k2) ** -0.5); bias = torch.randn(n, generator=g)
+    a1g, a2g, wg, bg = _bf(a1).cuda(), _bf(a2).cuda(), _bf(w).cuda(), bias.cuda()
+    out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    d = lib.GemmDesc()
+    d.a, d.w, d.c, d.bias, d.a2 = a1g.data_ptr(), wg.data_ptr(), out.data_ptr(), bg.data_ptr(), a2g.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldc, d.lda2, d.k_split = m, n, k1 + k2, k1, n, k2, k1
+    lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)), "mx_gemm split A")
+    _close(out, torch.cat([a1, a2], dim=1) @ w.t() + bias, 2.0 ** -7, f"gemm split A {m}x{n}x({k1}+{k2})")
