@@ -25,6 +25,9 @@
 #include "../../include/mxdenoise.h"
 #include "gemm_args.h"
 
+#ifndef MX_CONV_CMAJOR
+#define MX_CONV_CMAJOR 0   // 1: conv K tiles in channel-major order (experiment, see advance_cursor)
+#endif
 #ifndef MX_EXP
 #define MX_EXP 0   // tools/exp_build.sh: 1 = no MFMA, 2 = no LDS-DMA in the K loop, 3 = no fragment reads (diagnostics only)
 #endif
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   int tap_next = 0, in_tap = 0;
 
   // CONV: (re)compute the row pointers for tap `tap` at channel offset 0
-  auto conv_set_tap = [&](int tap) __attribute__((always_inline)) {
+  auto conv_set_tap = [&](int tap, int cbyte = 0) __attribute__((always_inline)) {
     const int dy = tap / 3 - 1;
     const int dx = tap - (tap / 3) * 3 - 1;
     const int Hv = p.Hin << p.up, Wv = p.Win << p.up;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       }
       const bool ok = (cb[i] >= 0) && (iy >= -p.vhalo) && (iy < Hv + p.vhalo) && (ix >= 0) && (ix < Wv);
       const long off = ((((long)cb[i] * (p.Hin + 2 * p.vhalo) + (iy >> p.up) + p.vhalo) * p.Win + (ix >> p.up)) * p.Cin) * 2;
-      xsrc[i] = (ok ? reinterpret_cast<const char*>(p.a) + off : zero) + xchb[i];
+      xsrc[i] = (ok ? reinterpret_cast<const char*>(p.a) + off + cbyte : zero) + xchb[i];
     }
   };
 
@@ -167,6 +170,22 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       park_on_zero_page();
       return;
     }
+#if MX_CONV_CMAJOR
+    if constexpr (CONV) {
+      // K tiles in channel-major order (64-channel slice outermost, the nine taps inside): the nine shifted reads of one slice of the
+      // input follow each other, so they hit the XCD's L2 instead of being re-fetched per tap (tap-major: FETCH 4.9x algorithmic)
+      if (++tap_next == 9) {
+        tap_next = 0; ++in_tap;                 // in_tap counts channel slices here
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wsrc[i] += BK2 * 2 - 8 * p.Cin * 2;
+      } else {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wsrc[i] += p.Cin * 2;
+      }
+      conv_set_tap(tap_next, in_tap * BK2 * 2);
+      return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < WI; ++i) wsrc[i] += BK2 * 2;
     if constexpr (!CONV) {

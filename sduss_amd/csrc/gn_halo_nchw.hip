@@ -3,13 +3,17 @@
 //
 // Written from the op's semantics, not from the CUDA source: 64-wide waves, fp32 statistics, an
 // out-of-place cross-patch merge (the reference merges in place and races, cu:377-384), no device
-// synchronisation, and frame-only zeroing instead of a full torch::zeros pass over the padded output.
+// synchronisation, and no zero pass over the padded output (torch::zeros in the reference).
 //
 //   moments_kernel      per (patch, group) mean / biased variance               (cu:41-81)
 //   merge_kernel        mean of patch means, rsqrt(mean of patch variances+eps) (cu:361-386)
-//   zero_frame_kernel   zero the 1-pixel frame of every [H+2, W+2] plane        (torch::zeros, cpp:71,92)
-//   apply_scatter_kernel y = x*(rstd*gamma) + (beta - rstd*gamma*mean) into the interior, and the sender-driven
-//                       scatter of edge rows / columns / corners into the neighbours' frames (cu:164-241, 285-357)
+//   apply_gather_kernel y = x*(rstd*gamma) + (beta - rstd*gamma*mean) into the interior of the [H+2, W+2] plane, and the plane's
+//                       1-pixel frame GATHERED from the neighbour patches' edge pixels (the reference scatters them from the
+//                       sender, cu:164-241, 285-357; the cells and values are the same: a neighbour belongs to the same latent, so
+//                       after the merge it has the same mean / rstd, and the same channel's gamma / beta).  Every block writes its
+//                       whole padded plane and nothing else: no zero pass (torch::zeros, cpp:71,92), no cross-block writes, and the
+//                       plane leaves as aligned 8-byte / 16-byte stores after a transpose-free staging in LDS (round 2: the round-1
+//                       form moved 2 bytes per lane).  Moments read 16 bytes per lane.
 #include "common.h"
 #include "../../include/mxdenoise.h"
 
@@ -30,10 +34,27 @@ __global__ __launch_bounds__(256) void moments_kernel(const T* __restrict__ x, f
   __shared__ double sh[8];
   const long base = (long)blockIdx.x * count;
   float s = 0.f, q = 0.f;
-  for (int i = threadIdx.x; i < count; i += 256) {
-    const float v = ldf<T>(x, base + i);
-    s += v;
-    q += v * v;
+  constexpr int VE = 16 / (int)sizeof(T);                   // elements per 16-byte load
+  if ((count % VE) == 0 && ((uintptr_t)(x + base) & 15) == 0) {
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x + base);
+    for (int i = threadIdx.x; i < count / VE; i += 256) {
+      const u32x4 w = xv[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (sizeof(T) == 4) { const float v = __uint_as_float(w[e]); s += v; q += v * v; }
+        else {
+          const T lo = __builtin_bit_cast(T, (unsigned short)(w[e] & 0xffffu)), hi = __builtin_bit_cast(T, (unsigned short)(w[e] >> 16));
+          const float a = ldf<T>(&lo, 0), b = ldf<T>(&hi, 0);
+          s += a; q += a * a; s += b; q += b * b;
+        }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < count; i += 256) {
+      const float v = ldf<T>(x, base + i);
+      s += v;
+      q += v * v;
+    }
   }
   double ds = (double)wave_sum(s), dq = (double)wave_sum(q);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -65,72 +86,107 @@ __global__ void merge_kernel(const float* __restrict__ mean, const float* __rest
   rstd2[idx] = rsqrtf(v / cnt + eps);
 }
 
-template <typename T>
-__global__ void zero_frame_kernel(T* __restrict__ y, long planes, int H, int W) {
-  const int per = 2 * (W + 2) + 2 * H;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= planes * per) return;
-  const long pl = idx / per;
-  const int k = (int)(idx - pl * per);
-  int row, col;
-  if (k < W + 2) { row = 0; col = k; }
-  else if (k < 2 * (W + 2)) { row = H + 1; col = k - (W + 2); }
-  else { const int j = k - 2 * (W + 2); row = 1 + (j >> 1); col = (j & 1) ? W + 1 : 0; }
-  y[(pl * (H + 2) + row) * (W + 2) + col] = cvt<T>(0.f);
-}
-
-// one block per (patch, channel) plane
-template <typename T, bool AFFINE, bool PAD>
-__global__ __launch_bounds__(256) void apply_scatter_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                            const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const int* __restrict__ padding_idx, int C, int H, int W,
-                                                            int cpg) {
+// one block per (patch, channel) plane: the whole [H+2, W+2] output plane is assembled in LDS and written with wide stores
+template <typename T, bool AFFINE>
+__global__ __launch_bounds__(256) void apply_gather_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ gamma,
+                                                           const T* __restrict__ beta, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const int* __restrict__ padding_idx, int C,
+                                                           int H, int W, int cpg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T* tile = reinterpret_cast<T*>(lds_raw);                  // [(H + 2) * (W + 2)] (+ pad to 16 bytes)
   const int plane = blockIdx.x;
   const int n = plane / C, c = plane - n * C;
   float scale = 1.f, shift = 0.f;
   if (AFFINE) {
-    const int G = C / cpg;
-    const int g = c / cpg;
+    const int G = C / cpg, g = c / cpg;
     const float r = rstd[n * G + g], m = mean[n * G + g];
     const float ga = gamma ? ldf<T>(gamma, c) : 1.f;
     const float be = beta ? ldf<T>(beta, c) : 0.f;
     scale = r * ga;
     shift = be - scale * m;
   }
-  int top = -1, left = -1, bottom = -1, right = -1;
-  if (PAD) {
-    top = padding_idx[n * 4]; left = padding_idx[n * 4 + 1];
-    bottom = padding_idx[n * 4 + 2]; right = padding_idx[n * 4 + 3];
-  }
-  const int HW = H * W;
-  const int W2 = W + 2;
-  const long pstride = (long)(H + 2) * W2;
+  auto tr = [&](T v) __attribute__((always_inline)) -> T { return AFFINE ? cvt<T>(ldf<T>(&v, 0) * scale + shift) : v; };
+  const int top = padding_idx[n * 4], left = padding_idx[n * 4 + 1], bottom = padding_idx[n * 4 + 2], right = padding_idx[n * 4 + 3];
+  const int HW = H * W, W2 = W + 2;
+  const int t = threadIdx.x;
   const T* xp = x + (long)plane * HW;
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    const int row = i / W, col = i - row * W;
-    float v = ldf<T>(xp, i);
-    if (AFFINE) v = v * scale + shift;
-    const T o = cvt<T>(v);
-    if (!PAD) {
-      y[(long)plane * HW + i] = o;
-      continue;
+  // ---- interior ----
+  constexpr int VE = 16 / (int)sizeof(T);
+  if ((W % VE) == 0 && ((uintptr_t)xp & 15) == 0) {
+    for (int i = t; i < HW / VE; i += 256) {
+      const u32x4 w = reinterpret_cast<const u32x4*>(xp)[i];
+      const int row = (i * VE) / W, col = (i * VE) - row * W;
+      T* dst = tile + (row + 1) * W2 + col + 1;
+      T v[VE];
+      __builtin_memcpy(v, &w, 16);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) dst[e] = tr(v[e]);
     }
-    y[(long)plane * pstride + (long)(row + 1) * W2 + col + 1] = o;
-    if (row == 0 && top != -1) y[((long)top * C + c) * pstride + (long)(H + 1) * W2 + col + 1] = o;
-    if (row == H - 1 && bottom != -1) y[((long)bottom * C + c) * pstride + col + 1] = o;
-    if (col == 0 && left != -1) {
-      T* d = y + ((long)left * C + c) * pstride;
-      d[(long)(row + 1) * W2 + W + 1] = o;
-      if (row == 0) d[W + 1] = o;                            // corner replicated by the sender (cu:210-215)
-      if (row == H - 1) d[(long)(H + 1) * W2 + W + 1] = o;   // (cu:216-221)
+  } else {
+    for (int i = t; i < HW; i += 256) { const int row = i / W, col = i - row * W; tile[(row + 1) * W2 + col + 1] = tr(xp[i]); }
+  }
+  // ---- frame: rows from the top / bottom neighbours, columns and corners from the left / right neighbours (cu:186-241) ----
+  const T zero = cvt<T>(0.f);
+  for (int k = t; k < 2 * W2 + 2 * H; k += 256) {
+    int row, col;
+    if (k < W2) { row = 0; col = k; }
+    else if (k < 2 * W2) { row = H + 1; col = k - W2; }
+    else { const int j = k - 2 * W2; row = 1 + (j >> 1); col = (j & 1) ? W + 1 : 0; }
+    T v = zero;
+    const bool corner_or_side = (col == 0 || col == W + 1);
+    if (corner_or_side) {
+      const int nb = col == 0 ? left : right;                // left neighbour's last column / right neighbour's first column;
+      if (nb != -1) {                                        // corners replicate that neighbour's corner pixel (cu:210-221, 228-239)
+        const int sr = row == 0 ? 0 : row == H + 1 ? H - 1 : row - 1;
+        v = tr(x[((long)nb * C + c) * HW + (long)sr * W + (col == 0 ? W - 1 : 0)]);
+      }
+    } else {
+      const int nb = row == 0 ? top : bottom;                // top neighbour's last row / bottom neighbour's first row, columns 1..W
+      if (nb != -1) v = tr(x[((long)nb * C + c) * HW + (long)(row == 0 ? H - 1 : 0) * W + (col - 1)]);
     }
-    if (col == W - 1 && right != -1) {
-      T* d = y + ((long)right * C + c) * pstride;
-      d[(long)(row + 1) * W2] = o;
-      if (row == 0) d[0] = o;                                // (cu:228-233)
-      if (row == H - 1) d[(long)(H + 1) * W2] = o;           // (cu:234-239)
+    tile[row * W2 + col] = v;
+  }
+  __syncthreads();
+  // ---- the padded plane leaves as one contiguous run ----
+  const int total = (H + 2) * W2;
+  T* yp = y + (long)plane * total;
+  const int bytes = total * (int)sizeof(T);
+  if ((bytes & 15) == 0 && ((uintptr_t)yp & 15) == 0) {
+    for (int i = t; i < bytes / 16; i += 256) reinterpret_cast<u32x4*>(yp)[i] = reinterpret_cast<const u32x4*>(tile)[i];
+  } else if ((bytes & 7) == 0 && ((uintptr_t)yp & 7) == 0) {
+    for (int i = t; i < bytes / 8; i += 256) reinterpret_cast<u32x2*>(yp)[i] = reinterpret_cast<const u32x2*>(tile)[i];
+  } else {
+    for (int i = t; i < total; i += 256) yp[i] = tile[i];
+  }
+}
+
+// !PAD: plain y = x * scale + shift per plane, 16 bytes per lane
+template <typename T>
+__global__ __launch_bounds__(256) void apply_plain_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ gamma,
+                                                          const T* __restrict__ beta, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, int C, int HW, int cpg) {
+  const int plane = blockIdx.x;
+  const int n = plane / C, c = plane - n * C;
+  const int G = C / cpg, g = c / cpg;
+  const float r = rstd[n * G + g], m = mean[n * G + g];
+  const float scale = r * (gamma ? ldf<T>(gamma, c) : 1.f);
+  const float shift = (beta ? ldf<T>(beta, c) : 0.f) - scale * m;
+  const T* xp = x + (long)plane * HW;
+  T* yp = y + (long)plane * HW;
+  constexpr int VE = 16 / (int)sizeof(T);
+  if ((HW % VE) == 0 && (((uintptr_t)xp | (uintptr_t)yp) & 15) == 0) {
+    for (int i = threadIdx.x; i < HW / VE; i += 256) {
+      const u32x4 w = reinterpret_cast<const u32x4*>(xp)[i];
+      T v[VE];
+      __builtin_memcpy(v, &w, 16);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = cvt<T>(ldf<T>(&v[e], 0) * scale + shift);
+      u32x4 o;
+      __builtin_memcpy(&o, v, 16);
+      reinterpret_cast<u32x4*>(yp)[i] = o;
     }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) yp[i] = cvt<T>(ldf<T>(xp, i) * scale + shift);
   }
 }
 
@@ -147,16 +203,15 @@ static int run(hipStream_t s, const void* x, const void* gamma, const void* beta
                        mean2, rstd2, latent_offset, patch_map, N, G, eps);
     MX_LAUNCH_CHECK();
   }
-  if (pad) {
-    const long planes = (long)N * C;
-    const long total = planes * (2 * (W + 2) + 2 * H);
-    hipLaunchKernelGGL((zero_frame_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, (T*)y, planes, H, W);
-    MX_LAUNCH_CHECK();
-  }
   dim3 grid(N * C), block(256);
-  if (affine && pad) hipLaunchKernelGGL((apply_scatter_kernel<T, true, true>), grid, block, 0, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, padding_idx, C, H, W, cpg);
-  else if (affine) hipLaunchKernelGGL((apply_scatter_kernel<T, true, false>), grid, block, 0, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, padding_idx, C, H, W, cpg);
-  else hipLaunchKernelGGL((apply_scatter_kernel<T, false, true>), grid, block, 0, s, (const T*)x, (T*)y, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, padding_idx, C, H, W, 1);
+  if (pad) {
+    const size_t lds = (((size_t)(H + 2) * (W + 2) * sizeof(T)) + 15) & ~(size_t)15;
+    MX_CHECK(lds <= 64 * 1024, "groupnorm_halo: patch plane too large for the LDS staging (H, W <= 126)");
+    if (affine) hipLaunchKernelGGL((apply_gather_kernel<T, true>), grid, block, lds, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, padding_idx, C, H, W, cpg);
+    else hipLaunchKernelGGL((apply_gather_kernel<T, false>), grid, block, lds, s, (const T*)x, (T*)y, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, padding_idx, C, H, W, 1);
+  } else {
+    hipLaunchKernelGGL((apply_plain_kernel<T>), grid, block, 0, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, C, H * W, cpg);
+  }
   MX_LAUNCH_CHECK();
   return 0;
 }

@@ -20,6 +20,8 @@ for M in sdxl sd3; do
   echo "write $M done"
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma_$M -- python3 $R/bench.py --model $M --steps 1 --warmup 1 $COMMON > $OUT/pmc_mfma_$M.log 2>&1
   echo "mfma $M done"
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2_$M -- python3 $R/bench.py --model $M --steps 1 --warmup 1 $COMMON > $OUT/pmc_l2_$M.log 2>&1
+  echo "l2 $M done"
 done
 cd $R
 mkdir -p $OUT/summary
@@ -29,6 +31,7 @@ for M in sdxl sd3; do
     python3 tools/trim_rocprof.py $KS $OUT/summary/${TAG}_kernel_stats_$M.txt; fi
   python3 tools/pmc_traffic.py $OUT/pmc_fetch_$M $OUT/pmc_write_$M $OUT/summary/${TAG}_pmc_traffic_${M}_step.txt
   python3 tools/pmc_mfma.py $OUT/pmc_mfma_$M $OUT/summary/${TAG}_pmc_mfma_util_$M.txt
+  python3 tools/pmc_l2.py $OUT/pmc_l2_$M $OUT/summary/${TAG}_pmc_l2_hit_$M.txt
 done
 # raw counter CSVs are large: keep only the summaries for the merge back
 rm -rf $OUT/stats_* $OUT/pmc_* 2>/dev/null || true
