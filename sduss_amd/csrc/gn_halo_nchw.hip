@@ -86,77 +86,89 @@ __global__ void merge_kernel(const float* __restrict__ mean, const float* __rest
   rstd2[idx] = rsqrtf(v / cnt + eps);
 }
 
-// one block per (patch, channel) plane: the whole [H+2, W+2] output plane is assembled in LDS and written with wide stores
+// PB consecutive (patch, channel) planes per block (PB = 1 for 32 x 32 planes, more for the small planes of the deeper levels):
+// the [H+2, W+2] output planes are assembled in LDS and leave as ONE contiguous run of wide stores
 template <typename T, bool AFFINE>
 __global__ __launch_bounds__(256) void apply_gather_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ gamma,
                                                            const T* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const int* __restrict__ padding_idx, int C,
-                                                           int H, int W, int cpg) {
+                                                           int H, int W, int cpg, int PB, long planes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  T* tile = reinterpret_cast<T*>(lds_raw);                  // [(H + 2) * (W + 2)] (+ pad to 16 bytes)
-  const int plane = blockIdx.x;
-  const int n = plane / C, c = plane - n * C;
-  float scale = 1.f, shift = 0.f;
-  if (AFFINE) {
-    const int G = C / cpg, g = c / cpg;
-    const float r = rstd[n * G + g], m = mean[n * G + g];
-    const float ga = gamma ? ldf<T>(gamma, c) : 1.f;
-    const float be = beta ? ldf<T>(beta, c) : 0.f;
-    scale = r * ga;
-    shift = be - scale * m;
-  }
-  auto tr = [&](T v) __attribute__((always_inline)) -> T { return AFFINE ? cvt<T>(ldf<T>(&v, 0) * scale + shift) : v; };
-  const int top = padding_idx[n * 4], left = padding_idx[n * 4 + 1], bottom = padding_idx[n * 4 + 2], right = padding_idx[n * 4 + 3];
-  const int HW = H * W, W2 = W + 2;
+  const int HW = H * W, W2 = W + 2, total = (H + 2) * W2;
+  T* tile = reinterpret_cast<T*>(lds_raw);                  // [PB][total]
+  float* coef = reinterpret_cast<float*>(lds_raw + (((size_t)PB * total * sizeof(T)) + 15) / 16 * 16);   // [PB][2]
+  const long plane0 = (long)blockIdx.x * PB;
+  const int npl = (int)((planes - plane0) < PB ? (planes - plane0) : PB);
   const int t = threadIdx.x;
-  const T* xp = x + (long)plane * HW;
-  // ---- interior ----
+  if (AFFINE) {
+    for (int pl = t; pl < npl; pl += 256) {
+      const long plane = plane0 + pl;
+      const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
+      const int G = C / cpg, g = c / cpg;
+      const float r = rstd[n * G + g], m = mean[n * G + g];
+      const float sc = r * (gamma ? ldf<T>(gamma, c) : 1.f);
+      coef[2 * pl] = sc;
+      coef[2 * pl + 1] = (beta ? ldf<T>(beta, c) : 0.f) - sc * m;
+    }
+    __syncthreads();
+  }
+  auto tr = [&](T v, int pl) __attribute__((always_inline)) -> T { return AFFINE ? cvt<T>(ldf<T>(&v, 0) * coef[2 * pl] + coef[2 * pl + 1]) : v; };
+  // ---- interiors: the npl input planes are one contiguous run ----
+  const T* xp = x + plane0 * HW;
   constexpr int VE = 16 / (int)sizeof(T);
   if ((W % VE) == 0 && ((uintptr_t)xp & 15) == 0) {
-    for (int i = t; i < HW / VE; i += 256) {
+    for (int i = t; i < npl * HW / VE; i += 256) {
       const u32x4 w = reinterpret_cast<const u32x4*>(xp)[i];
-      const int row = (i * VE) / W, col = (i * VE) - row * W;
-      T* dst = tile + (row + 1) * W2 + col + 1;
+      const int e0 = i * VE;
+      const int pl = e0 / HW, r0 = e0 - pl * HW;
+      const int row = r0 / W, col = r0 - row * W;
+      T* dst = tile + pl * total + (row + 1) * W2 + col + 1;
       T v[VE];
       __builtin_memcpy(v, &w, 16);
 #pragma unroll
-      for (int e = 0; e < VE; ++e) dst[e] = tr(v[e]);
+      for (int e = 0; e < VE; ++e) dst[e] = tr(v[e], pl);
     }
   } else {
-    for (int i = t; i < HW; i += 256) { const int row = i / W, col = i - row * W; tile[(row + 1) * W2 + col + 1] = tr(xp[i]); }
+    for (int i = t; i < npl * HW; i += 256) {
+      const int pl = i / HW, r0 = i - pl * HW;
+      const int row = r0 / W, col = r0 - row * W;
+      tile[pl * total + (row + 1) * W2 + col + 1] = tr(xp[i], pl);
+    }
   }
-  // ---- frame: rows from the top / bottom neighbours, columns and corners from the left / right neighbours (cu:186-241) ----
+  // ---- frames: rows from the top / bottom neighbours, columns and corners from the left / right neighbours (cu:186-241) ----
   const T zero = cvt<T>(0.f);
-  for (int k = t; k < 2 * W2 + 2 * H; k += 256) {
+  const int per = 2 * W2 + 2 * H;
+  for (int kk = t; kk < npl * per; kk += 256) {
+    const int pl = kk / per, k = kk - pl * per;
+    const long plane = plane0 + pl;
+    const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
     int row, col;
     if (k < W2) { row = 0; col = k; }
     else if (k < 2 * W2) { row = H + 1; col = k - W2; }
     else { const int j = k - 2 * W2; row = 1 + (j >> 1); col = (j & 1) ? W + 1 : 0; }
     T v = zero;
-    const bool corner_or_side = (col == 0 || col == W + 1);
-    if (corner_or_side) {
-      const int nb = col == 0 ? left : right;                // left neighbour's last column / right neighbour's first column;
-      if (nb != -1) {                                        // corners replicate that neighbour's corner pixel (cu:210-221, 228-239)
+    if (col == 0 || col == W + 1) {
+      const int nb = padding_idx[n * 4 + (col == 0 ? 1 : 3)];   // left neighbour's last column / right neighbour's first column;
+      if (nb != -1) {                                          // corners replicate that neighbour's corner pixel (cu:210-221, 228-239)
         const int sr = row == 0 ? 0 : row == H + 1 ? H - 1 : row - 1;
-        v = tr(x[((long)nb * C + c) * HW + (long)sr * W + (col == 0 ? W - 1 : 0)]);
+        v = tr(x[((long)nb * C + c) * HW + (long)sr * W + (col == 0 ? W - 1 : 0)], pl);
       }
     } else {
-      const int nb = row == 0 ? top : bottom;                // top neighbour's last row / bottom neighbour's first row, columns 1..W
-      if (nb != -1) v = tr(x[((long)nb * C + c) * HW + (long)(row == 0 ? H - 1 : 0) * W + (col - 1)]);
+      const int nb = padding_idx[n * 4 + (row == 0 ? 0 : 2)];   // top neighbour's last row / bottom neighbour's first row, columns 1..W
+      if (nb != -1) v = tr(x[((long)nb * C + c) * HW + (long)(row == 0 ? H - 1 : 0) * W + (col - 1)], pl);
     }
-    tile[row * W2 + col] = v;
+    tile[pl * total + row * W2 + col] = v;
   }
   __syncthreads();
-  // ---- the padded plane leaves as one contiguous run ----
-  const int total = (H + 2) * W2;
-  T* yp = y + (long)plane * total;
-  const int bytes = total * (int)sizeof(T);
+  // ---- the padded planes leave as one contiguous run ----
+  T* yp = y + plane0 * total;
+  const long bytes = (long)npl * total * (long)sizeof(T);
   if ((bytes & 15) == 0 && ((uintptr_t)yp & 15) == 0) {
     for (int i = t; i < bytes / 16; i += 256) reinterpret_cast<u32x4*>(yp)[i] = reinterpret_cast<const u32x4*>(tile)[i];
   } else if ((bytes & 7) == 0 && ((uintptr_t)yp & 7) == 0) {
     for (int i = t; i < bytes / 8; i += 256) reinterpret_cast<u32x2*>(yp)[i] = reinterpret_cast<const u32x2*>(tile)[i];
   } else {
-    for (int i = t; i < total; i += 256) yp[i] = tile[i];
+    for (int i = t; i < npl * total; i += 256) yp[i] = tile[i];
   }
 }
 
@@ -205,10 +217,16 @@ static int run(hipStream_t s, const void* x, const void* gamma, const void* beta
   }
   dim3 grid(N * C), block(256);
   if (pad) {
-    const size_t lds = (((size_t)(H + 2) * (W + 2) * sizeof(T)) + 15) & ~(size_t)15;
+    const int total = (H + 2) * (W + 2);
+    int PB = 2048 / (H * W);                   // ~2k input elements per block
+    if (PB < 1) PB = 1;
+    if (PB > 32) PB = 32;
+    const size_t lds = (((size_t)PB * total * sizeof(T)) + 15) / 16 * 16 + (size_t)PB * 2 * sizeof(float);
     MX_CHECK(lds <= 64 * 1024, "groupnorm_halo: patch plane too large for the LDS staging (H, W <= 126)");
-    if (affine) hipLaunchKernelGGL((apply_gather_kernel<T, true>), grid, block, lds, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, padding_idx, C, H, W, cpg);
-    else hipLaunchKernelGGL((apply_gather_kernel<T, false>), grid, block, lds, s, (const T*)x, (T*)y, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, padding_idx, C, H, W, 1);
+    const long planes = (long)N * C;
+    dim3 pgrid((unsigned)cdiv64(planes, PB));
+    if (affine) hipLaunchKernelGGL((apply_gather_kernel<T, true>), pgrid, block, lds, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, padding_idx, C, H, W, cpg, PB, planes);
+    else hipLaunchKernelGGL((apply_gather_kernel<T, false>), pgrid, block, lds, s, (const T*)x, (T*)y, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, padding_idx, C, H, W, 1, PB, planes);
   } else {
     hipLaunchKernelGGL((apply_plain_kernel<T>), grid, block, 0, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, C, H * W, cpg);
   }
