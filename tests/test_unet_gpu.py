@@ -229,3 +229,33 @@ def test_plumbing_config0_four_steps_512(tiny):
         lat = lat.to(torch.bfloat16).float()
     assert req.done()
     _check(req.latents, lat, "config0 plumbing: 4 steps at 512x512", max_rel=0.10, l2_rel=0.06)
+
+
+def test_unet_per_stage_error_budget(tiny):
+    """The end-to-end bound of the tests above, broken down: every block output of the step plan (mx_unet_forward_trace) against the
+    same stage of the fp32 oracle.  Budget: each fused stage stores its result in bf16 (relative rounding 2^-9 per element, ~0.2 % rms)
+    and reads inputs that already carry the error of the stages before, so the relative L2 error after n stages is allowed
+    0.35 % * sqrt(n) (independent roundings add in quadrature; GroupNorm / LayerNorm keep the scale at 1 so the error neither dies out
+    nor compounds) and no single stage may add more than 1 % on top of its input's error.  A kernel that is wrong in one stage shows as a
+    jump at that stage instead of hiding in a 4 % end-to-end bound."""
+    ocfg, P, net = tiny
+    s, t, e, te, ti = ref.make_inputs(ocfg, 2, 32)
+    tr = {}
+    ref.unet_forward(P, ocfg, s, t, e, te, ti, trace=tr)
+    x = s.cuda().to(torch.bfloat16)
+    prev = 0.0
+    rows = []
+    for k, (name, want) in enumerate(tr.items()):
+        if want.ndim != 4:
+            continue
+        b, c, h, w = want.shape
+        got = net.forward_one(x, t.cuda(), e.cuda(), te.cuda(), ti.cuda(), stage=name, stage_shape=(b, h, w, c))
+        got = got.float().cpu().permute(0, 3, 1, 2)
+        l2 = ((got - want).norm() / want.norm()).item()
+        rows.append((name, l2))
+        budget = 0.0035 * (len(rows) ** 0.5) + 0.002
+        assert l2 <= budget, f"stage {name} (#{len(rows)}): rel L2 {l2:.4f} > budget {budget:.4f}; previous stage {prev:.4f}"
+        assert l2 <= prev + 0.01, f"stage {name} adds {l2 - prev:.4f} to the relative error in one step"
+        prev = l2
+    print("per-stage rel L2:", ", ".join(f"{n.split('.')[-3] if n.count('.') > 2 else n}={v:.4f}" for n, v in rows[:6]), "...", f"{rows[-1][0]}={rows[-1][1]:.4f}")
+    assert len(rows) >= 20
