@@ -11,4 +11,8 @@ restatement of the published diffusers SDXL ``UNet2DConditionModel`` forward bui
 from the torch functional primitives that package bottoms out in, plus a literal
 restatement of the reference's own patch/halo/scheduler code; it is anchored on the
 reference's call sites (file:line cited per function), not on reference outputs.
+
+Pinned by running the reference itself (round 2, tests/golden/make_ref_fixtures.py -> tests/golden/ref_*): the SD3 token
+re-chunk (sd3_mmdit_ref.split_sample_sd3 / concat_sample_tokens vs modules/utils.py:86-136) and the latency predictor's
+feature map (predictor_ref.py vs policy/ESyMReD.py:46-53).  The UNet / MMDiT arithmetic itself stays unpinned.
 """
