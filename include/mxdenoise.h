@@ -303,6 +303,30 @@ int mx_mmdit_forward_trace(mx_mmdit* u, void* stream, const void* latents, int i
                            size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * The step after the loop: the SDXL VAE decoder (AutoencoderKL.decode as post_inference calls it,
+ * pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl_esymred.py:406-463).  SURVEY.md section 8f rank 2.
+ * latents [batch, latent_channels, H, W] of io_dtype (NCHW, NOT yet divided by the scaling factor: 1 / scaling_factor is folded
+ * into the packed post_quant_conv weight) -> images [batch, out_channels, 8H, 8W] of out_dtype in [-1, 1] (before the pipeline's
+ * image_processor.postprocess).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mx_vae_config {
+  int latent_channels, out_channels;
+  int n_levels;                   /* <= 4 */
+  int block_out_channels[4];      /* encoder order, e.g. 128, 256, 512, 512: the decoder walks them backwards */
+  int layers_per_block;           /* the decoder has layers_per_block + 1 resnets per up block */
+  int norm_num_groups;
+  float norm_eps;
+} mx_vae_config;
+typedef struct mx_vae mx_vae;
+mx_vae* mx_vae_create(const mx_vae_config* cfg);
+void mx_vae_destroy(mx_vae* v);
+int mx_vae_set_weights(mx_vae* v, const void* blob, uint64_t blob_bytes, const mx_weight_entry* table, int n_entries);
+size_t mx_vae_workspace_bytes(const mx_vae* v, int batch, int H, int W);
+int mx_vae_validate(const mx_vae* v, int batch, int H, int W);
+int mx_vae_decode(mx_vae* v, void* stream, const void* latents, int io_dtype, void* out, int out_dtype, int batch, int H, int W,
+                  void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------
  * The element-wise steps either side of the model call.
  * ------------------------------------------------------------------------------------------ */
 /* out[b] = x[b mod n_lat] / sqrt(sigma[b mod n_lat]^2 + 1) for b in [0, n_rows)   (batch_scale_model_input, CFG

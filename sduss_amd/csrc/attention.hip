@@ -340,6 +340,251 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 
 
 // ----------------------------------------------------------------------------------------------------------------------
+// The same kernel with K / V^T tiles staged by LDS-DMA two tiles ahead (round 2), for key counts that are whole tiles.
+// attn_fwd_kernel fetches tile kt + 1 into registers while it computes tile kt and writes it to LDS at the end of the iteration:
+// one tile of compute (~1.2k cycles per wave) has to cover an L2 / Infinity-Cache round trip under load, and 16 VGPRs hold the
+// staged tile.  Here the tile goes L2 -> LDS directly (global_load_lds_dwordx4, swizzle on the source address) into a ring of
+// three 16-KB buffers, issued right after the barrier of tile kt for tile kt + 2; one counted s_waitcnt vmcnt(4) + one raw
+// s_barrier per tile.  The compute body is attn_fwd_kernel's.
+// ----------------------------------------------------------------------------------------------------------------------
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * kBufBytes];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31;   // query column owned by this lane (and fragment row)
+  const int hh = lane >> 5;  // half-wave
+  // workgroup -> (query block, head, batch).  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (one L2 each):
+  // with the plain x-fastest order the query blocks of one head land on all 8 XCDs and each L2 fetches that head's K / V^T
+  // (rocprofv3 FETCH_SIZE: 4.4x the algorithmic bytes at Lk = 4429).  When the number of (batch, head) pairs is a multiple
+  // of 8, XCD x instead owns the pairs == x (mod 8) and walks their query blocks consecutively.
+  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
+  if (p.xcd_map) {
+    const int lin = blockIdx.x + gridDim.x * bh;
+    const int local = lin >> 3;
+    qb = local % (int)gridDim.x;
+    bh = ((local / (int)gridDim.x) << 3) + (lin & 7);
+  }
+  const int head = bh % p.H;
+  const int b = bh / p.H;
+  const int q0 = qb * 128 + wave * 32;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): Q[q0 + r][16*ks + 8*hh .. +7] ----
+  bf16x8 qf[4];
+  {
+    int qi = q0 + r;
+    if (qi > p.Lq - 1) qi = p.Lq - 1;
+    const bf16_t* qp = p.q + ((long)b * p.Lq + qi) * p.ldq + head * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  }
+
+  // ---- staging by LDS-DMA into a three-buffer ring, two tiles ahead: 512 16-byte chunks per tile per operand, 2 per thread.
+  //      Chunk c = i * 256 + tid lands at byte 16 c of the image (an LDS-DMA writes base + 16 * lane); it is row c >> 3, slot c & 7,
+  //      and holds logical chunk slot ^ ((row >> 1) & 7) of that row: the swizzle is applied on the SOURCE address. ----
+  const bf16_t* kbase = p.k + (long)b * p.k_bstride + head * 64;
+  const bf16_t* vbase = p.vt + (long)b * p.vt_bstride + ((long)head * 64) * p.ldvt;
+  auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
+    int key0 = kt * KT;
+    const bf16_t* kb_ = kbase;
+    const bf16_t* vb_ = vbase;
+    if (p.key_chunk > 0) {                     // tiles never straddle a chunk (key_chunk % 64 == 0)
+      const int ch = key0 / p.key_chunk;
+      key0 -= ch * p.key_chunk;
+      kb_ += ch * p.k_cstride;
+      vb_ += ch * p.vt_cstride;
+    }
+    char* img = smem + buf * kBufBytes;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i * 256 + tid;
+      const int row = c >> 3, ch = (c & 7) ^ ((row >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb_ + (long)(key0 + row) * p.ldk + ch * 8),
+                                       (__attribute__((address_space(3))) void*)(img + (i * 256 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb_ + (long)row * p.ldvt + key0 + ch * 8),
+                                       (__attribute__((address_space(3))) void*)(img + 8192 + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane LDS read offsets for buffer 0 (loop invariant; the buffer bit is XOR-toggled per tile) ----
+  // row r, chunk 2*step + hh: the K fragment of k-step `step` and (at +8192) the V^T fragment of 16-key step `step`
+  unsigned koff[4];
+  {
+    const int swz = (r >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(r * 128 + (((2 * ks + hh) ^ swz) * 16));
+  }
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+  float m_run = -INFINITY;  // !PRE: running max of s*scale_log2 for query column r (identical in both halves)
+  float l_run = 0.f;        // this half-wave's partial row sum
+  // PRE: the reference k-step.  A operand: K column of ones = element k == 0 of the step (held by the hh == 0 lanes);
+  // B operand: -m_ref (bf16-representable) in the same element of query column r.
+  const unsigned one_lo = hh == 0 ? 0x3F80u : 0u;
+  const bf16x8 kone = __builtin_bit_cast(bf16x8, u32x4{one_lo, 0u, 0u, 0u});
+  u32x4 qm = {0u, 0u, 0u, 0u};
+  float m_ref = 0.f;
+
+  const int ntiles = (p.Lk + KT - 1) / KT;
+  const bool ragged = false;                   // the launcher sends ragged key counts to attn_fwd_kernel
+  const float c = p.scale_log2;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  issue_tile(0, 0);
+  if (ntiles > 1) issue_tile(1, 1);
+  int buf = 0;                                 // ring buffer of the tile being computed
+  unsigned bofs = 0;                           // its byte offset
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const bool has_next = kt + 1 < ntiles;
+    // tile kt has landed (this thread's part; the next tile's four DMAs may stay in flight) ...
+    if (has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // ... for every thread, and every wave has left the buffer of tile kt - 1
+    asm volatile("" ::: "memory");
+    if (kt + 2 < ntiles) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);   // (kt + 2) % 3
+
+    // ---- S^T = K Q^T : two 32-key blocks.  All eight K fragments are requested before the first MFMA and the two
+    //      accumulator chains alternate, so neither LDS latency nor the MFMA dependency sits between issues. ----
+    bf16x8 fr[8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fr[kb * 4 + ks] = *reinterpret_cast<const bf16x8*>(smem + bofs + koff[ks] + kb * 4096);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 s[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
+    }
+    if constexpr (PRE) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm), s[kb], 0, 0, 0);
+    }
+    // V^T fragments (same registers): in flight while the softmax runs on the vector ALU
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) fr[sidx * 2 + db] = *reinterpret_cast<const bf16x8*>(smem + bofs + koff[sidx] + 8192 + db * 4096);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ragged && !has_next) {          // mask keys beyond Lk (tail tile only)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (key >= p.Lk) s[kb][e] = -INFINITY;
+        }
+    }
+    // ---- online softmax (log2 domain) ----
+    float mx_ = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx_ = fmaxf(mx_, s[kb][e]);
+    mx_ = max_across_halves(mx_);
+    float psum = 0.f;
+    if constexpr (PRE) {
+      // s already holds s*c - m_ref.  Move the reference only on the first tile or when a row ran more than 8 above it.
+      const bool first = kt == 0;
+      if (first || __any(mx_ > 8.0f)) {
+        float delta = 0.f;
+        if (first || mx_ > 8.0f) {
+          const float nr = bf16lo_to_f32(pack2(m_ref + mx_, 0.f));        // new reference, bf16-representable
+          delta = nr - m_ref;
+          m_ref = nr;
+        }
+        qm[0] = hh == 0 ? (pack2(-m_ref, 0.f) & 0xffffu) : 0u;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[kb][e] -= delta;
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(s[kb][e]);
+          s[kb][e] = pe;
+          psum += pe;
+        }
+      l_run += psum;
+    } else {
+      const float m_new = fmaxf(m_run, mx_ * c);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      // (packed v_pk_fma_f32 / v_pk_add_f32 forms of this loop measured 0-3 % SLOWER in same-run A/B: scalar kept)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(s[kb][e] * c - m_new);
+          s[kb][e] = pe;
+          psum += pe;
+        }
+      l_run = l_run * alpha + psum;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+      }
+    }
+    // ---- O^T += V^T P^T : P fragments straight from the S^T accumulators ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4 pw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pw[e] = pack2(s[kb][8 * s2 + 2 * e], s[kb][8 * s2 + 2 * e + 1]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        const int sidx = 2 * kb + s2;  // 16-key step inside the tile
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[sidx * 2 + db], pf, oacc[db], 0, 0, 0);
+      }
+    }
+    buf = buf == 2 ? 0 : buf + 1;
+    bofs = (unsigned)buf * kBufBytes;
+  }
+
+  // ---- normalise and store O[q][d] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qi = q0 + r;
+  if (qi < p.Lq) {
+    bf16_t* op = p.o + ((long)b * p.Lq + qi) * p.ldo + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hh;
+        u32x2 o = {pack2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv),
+                   pack2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + d) = o;
+      }
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------------
 // Cross-attention with a SHORT key sequence (Lk <= 96: the 77 text tokens of SDXL; PatchCrossAttention.forward,
 // modules/attention.py:59-110).  Half of the attention launches of a UNet step (70 of 140) are this shape, and the general
 // kernel above spends them on machinery they do not need: two 64-key LDS tiles (the second 13/64 valid), a barrier per
@@ -545,7 +790,11 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
   dim3 grid(cdiv(Lq, 128), H, B);
   prof_begin((hipStream_t)stream, PROF_ATTN, 4.0 * B * H * (double)Lq * Lk * 64.0,
              2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
-  if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  static const bool dma_off = [] { const char* e = getenv("MX_ATTN_DMA"); return e && e[0] == '0'; }();
+  if (Lk % KT == 0 && Lk >= 3 * KT && !dma_off) {      // whole tiles: LDS-DMA staging two tiles ahead
+    if (pre) hipLaunchKernelGGL(attn_fwd_dma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_dma_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
   prof_end((hipStream_t)stream);
   MX_LAUNCH_CHECK();

@@ -352,3 +352,48 @@ extern "C" int mx_cfg_flow_step(void* stream, const void* noise, void* latents, 
   MX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Row softmax in place on a bf16 [rows, L] score matrix (fp32 math): the VAE decoder's single-head, 512-wide mid-block
+// attention (diffusers Attention with heads = 1; AutoencoderKL decoder) is computed as GEMM -> softmax -> GEMM.
+// ------------------------------------------------------------------------------------------
+namespace mx {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ s, int L, long ld) {
+  __shared__ float red[8];
+  bf16_t* row = s + (long)blockIdx.x * ld;
+  const int t = threadIdx.x;
+  float mx_ = -INFINITY;
+  for (int i = t; i < L / 8; i += 256) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(row)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mx_ = fmaxf(mx_, fmaxf(bf16lo_to_f32(v[e]), bf16hi_to_f32(v[e])));
+  }
+  mx_ = wave_max(mx_);
+  if ((t & 63) == 0) red[t >> 6] = mx_;
+  __syncthreads();
+  mx_ = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = t; i < L / 8; i += 256) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(row)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum += __expf(bf16lo_to_f32(v[e]) - mx_) + __expf(bf16hi_to_f32(v[e]) - mx_);
+  }
+  sum = wave_sum(sum);
+  if ((t & 63) == 0) red[4 + (t >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int i = t; i < L / 8; i += 256) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(row)[i];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(__expf(bf16lo_to_f32(v[e]) - mx_) * inv, __expf(bf16hi_to_f32(v[e]) - mx_) * inv);
+    reinterpret_cast<u32x4*>(row)[i] = o;
+  }
+}
+int launch_softmax_rows(hipStream_t s, void* scores, long rows, int L, long ld) {
+  MX_CHECK(L % 8 == 0 && ld % 8 == 0 && rows > 0, "softmax_rows: L and ld must be multiples of 8");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, (bf16_t*)scores, L, ld);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mx

@@ -61,6 +61,11 @@ class PPComm(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("all_gather", ALLGATHER_FN), ("ctx", C.c_void_p)]
 
 
+class VAEConfigC(C.Structure):
+    _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("n_levels", C.c_int), ("block_out_channels", C.c_int * 4),
+                ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int), ("norm_eps", C.c_float)]
+
+
 class WeightEntry(C.Structure):
     _fields_ = [("name", C.c_char_p), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
 
@@ -105,6 +110,12 @@ SYMBOLS = {
     "mx_mmdit_validate": (_i, [_vp, _i, _i, _i, _i]),
     "mx_mmdit_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz]),
     "mx_mmdit_forward_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, C.c_char_p, _vp, _sz]),
+    "mx_vae_create": (_vp, [C.POINTER(VAEConfigC)]),
+    "mx_vae_destroy": (None, [_vp]),
+    "mx_vae_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),
+    "mx_vae_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "mx_vae_validate": (_i, [_vp, _i, _i, _i]),
+    "mx_vae_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz]),
     "mx_cfg_flow_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),
     "mx_euler_scale_input": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i]),
     "mx_cfg_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),

@@ -318,3 +318,34 @@ def test_hf_layout_directories_load_into_the_step_plans(tmp_path):
     assert h and l.mx_mmdit_set_weights(h, pw.blob.data_ptr(), pw.blob.numel(), pw.table, len(pw.names)) == 0
     assert l.mx_mmdit_validate(h, 2, 16, 16, 37) == 0, l.mx_last_error()
     l.mx_mmdit_destroy(h)
+
+
+def test_vae_plan_resolves_packed_weights_on_host():
+    """mx_vae_validate walks the decoder's step plan on the host: every packed tensor name / size it asks for is what pack_vae produced;
+    the inventory equals the oracle's; a missing tensor is reported."""
+    from oracle import vae_ref
+    from sduss_amd import lib
+    from sduss_amd.vae import VAEConfig, pack_vae
+    from sduss_amd import weights
+    l = lib.load()
+    for cfg, ocfg in ((VAEConfig.tiny(), vae_ref.VAEConfig.tiny()), (VAEConfig.sdxl(), vae_ref.VAEConfig.sdxl())):
+        shapes = vae_ref.param_shapes(ocfg)
+        P = {k: torch.zeros(v) for k, v in shapes.items()}
+        pw = weights.PackedWeights(pack_vae(cfg, P), "cpu")
+        cc = lib.VAEConfigC()
+        cc.latent_channels, cc.out_channels, cc.n_levels = cfg.latent_channels, cfg.out_channels, len(cfg.block_out_channels)
+        for i, v in enumerate(cfg.block_out_channels):
+            cc.block_out_channels[i] = v
+        cc.layers_per_block, cc.norm_num_groups, cc.norm_eps = cfg.layers_per_block, cfg.norm_num_groups, cfg.norm_eps
+        h = l.mx_vae_create(C.byref(cc))
+        assert h and l.mx_vae_set_weights(h, pw.blob.data_ptr(), pw.blob.numel(), pw.table, len(pw.names)) == 0
+        assert l.mx_vae_validate(h, 1, 16, 16) == 0, l.mx_last_error()
+        assert l.mx_vae_workspace_bytes(h, 1, 16, 16) > 0
+        bad = [e for e in pack_vae(cfg, P) if e[0] != "decoder.mid_block.attentions.0.to_k.bias"]
+        pw2 = weights.PackedWeights(bad, "cpu")
+        assert l.mx_vae_set_weights(h, pw2.blob.data_ptr(), pw2.blob.numel(), pw2.table, len(pw2.names)) == 0
+        assert l.mx_vae_validate(h, 1, 16, 16) != 0 and b"to_k.bias" in l.mx_last_error()
+        l.mx_vae_destroy(h)
+    # SDXL VAE decoder: 49.5 M parameters
+    total = sum(torch.Size(v).numel() for k, v in vae_ref.param_shapes(vae_ref.VAEConfig.sdxl()).items())
+    assert 49.0e6 < total < 50.0e6, total
