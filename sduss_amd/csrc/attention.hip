@@ -30,6 +30,10 @@
 //     that was 41 % busy while the vector ALU was 72 % busy (rocprofv3 SQ_ACTIVE_INST_VALU).
 #include <cstdlib>
 
+#ifndef MX_AEXP
+#define MX_AEXP 0   // ablation builds of attn_fwd_dma_kernel (tools/exp/build_attn_variants.sh): timing only
+#endif
+
 #include "common.h"
 #include "../../include/mxdenoise.h"
 
@@ -349,7 +353,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 // ----------------------------------------------------------------------------------------------------------------------
 template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) {
+  #if (MX_AEXP & 32)
+  __shared__ __attribute__((aligned(16))) char smem[3 * kBufBytes + 40 * 1024];
+#elif (MX_AEXP & 64)
+  __shared__ __attribute__((aligned(16))) char smem[3 * kBufBytes + 12 * 1024];
+#else
   __shared__ __attribute__((aligned(16))) char smem[3 * kBufBytes];
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -444,10 +454,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
   for (int kt = 0; kt < ntiles; ++kt) {
     const bool has_next = kt + 1 < ntiles;
     // tile kt has landed (this thread's part; the next tile's four DMAs may stay in flight) ...
+#if !(MX_AEXP & 2)
     if (has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if !(MX_AEXP & 4)
     __builtin_amdgcn_s_barrier();              // ... for every thread, and every wave has left the buffer of tile kt - 1
+#endif
     asm volatile("" ::: "memory");
+#if !(MX_AEXP & 2)
     if (kt + 2 < ntiles) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);   // (kt + 2) % 3
+#endif
 
     // ---- S^T = K Q^T : two 32-key blocks.  All eight K fragments are requested before the first MFMA and the two
     //      accumulator chains alternate, so neither LDS latency nor the MFMA dependency sits between issues. ----
@@ -458,6 +474,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
       for (int ks = 0; ks < 4; ++ks) fr[kb * 4 + ks] = *reinterpret_cast<const bf16x8*>(smem + bofs + koff[ks] + kb * 4096);
     __builtin_amdgcn_sched_barrier(0);
     f32x16 s[2];
+#if (MX_AEXP & 8)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kb][e] = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, fr[kb * 4 + (e & 3)])[e & 3] << 16) + oacc[kb][e];
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -469,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
       for (int kb = 0; kb < 2; ++kb)
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm), s[kb], 0, 0, 0);
     }
+#endif
     // V^T fragments (same registers): in flight while the softmax runs on the vector ALU
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx)
@@ -520,7 +543,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
+#if (MX_AEXP & 1)
+          const float pe = s[kb][e];
+#else
           const float pe = __builtin_amdgcn_exp2f(s[kb][e]);
+#endif
           s[kb][e] = pe;
           psum += pe;
         }
@@ -556,9 +583,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
         for (int e = 0; e < 4; ++e) pw[e] = pack2(s[kb][8 * s2 + 2 * e], s[kb][8 * s2 + 2 * e + 1]);
         const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
         const int sidx = 2 * kb + s2;  // 16-key step inside the tile
+#if (MX_AEXP & 16)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) oacc[db][(4 * sidx + e) & 15] += __builtin_bit_cast(float, pw[e] ^ __builtin_bit_cast(u32x4, fr[sidx * 2 + db])[e]);
+#else
 #pragma unroll
         for (int db = 0; db < 2; ++db)
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[sidx * 2 + db], pf, oacc[db], 0, 0, 0);
+#endif
       }
     }
     buf = buf == 2 ? 0 : buf + 1;
@@ -580,6 +614,310 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
                    pack2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
         *reinterpret_cast<u32x2*>(op + d) = o;
       }
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------------
+// 64 query rows per wave (round 2).  Ablation builds of attn_fwd_dma_kernel (tools/exp/build_attn_variants.sh, MX_AEXP) priced
+// its parts at Lk = 4096: the four LDS-DMA pieces a wave issues per tile cost 19 % of the launch (an LDS-DMA instruction holds
+// the wave's issue for 60-185 cycles, MI355X_MICROARCH.md), exp2 12 %, the S^T MFMAs 9 %, the barrier 4 %; a lone workgroup per CU
+// runs at 57 % of three, i.e. one wave's tile is a serial chain (fragment reads -> S^T -> softmax -> O^T) that other waves must cover.
+// Here a wave owns TWO 32-query blocks: the K / V^T fragments it reads from LDS and the DMA pieces it issues serve twice the MFMAs,
+// and the two blocks are independent, so block 1's S^T MFMAs sit beside block 0's softmax and block 0's O^T MFMAs beside block 1's
+// softmax in ONE instruction stream (sched_group_barrier pins the interleave).  A workgroup = 4 waves = 256 query rows, two
+// workgroups per CU; O leaves through the (idle) K / V^T ring as whole 128-byte rows.
+// ----------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * kBufBytes];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31;   // query column owned by this lane (and fragment row)
+  const int hh = lane >> 5;  // half-wave
+  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
+  if (p.xcd_map) {                             // XCD x owns the (batch, head) pairs == x (mod 8) (see attn_fwd_kernel)
+    const int lin = blockIdx.x + gridDim.x * bh;
+    const int local = lin >> 3;
+    qb = local % (int)gridDim.x;
+    bh = ((local / (int)gridDim.x) << 3) + (lin & 7);
+  }
+  const int head = bh % p.H;
+  const int b = bh / p.H;
+  const int q0 = qb * 256 + wave * 64;
+
+  // ---- Q fragments of the two blocks (B operand of S^T = K Q^T): Q[q0 + 32 blk + r][16*ks + 8*hh .. +7] ----
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    int qi = q0 + blk * 32 + r;
+    if (qi > p.Lq - 1) qi = p.Lq - 1;
+    const bf16_t* qp = p.q + ((long)b * p.Lq + qi) * p.ldq + head * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[blk][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  }
+
+  // ---- LDS-DMA staging, three-buffer ring, two tiles ahead (layout of attn_fwd_dma_kernel).  Addresses are a wave-uniform
+  //      base that moves with the tile plus a per-lane 32-bit offset fixed for the whole kernel: no vector work per tile. ----
+  const char* kbase = (const char*)(p.k + (long)b * p.k_bstride + head * 64);
+  const char* vbase = (const char*)(p.vt + (long)b * p.vt_bstride + ((long)head * 64) * p.ldvt);
+  // A ragged last tile (rem = Lk % 64 keys) is fetched whole: its K rows >= Lk and its all-padding V^T chunks are redirected to
+  // addresses inside the operands (row Lk - 1; chunk 0 of the V^T row), and masked after they leave LDS.
+  const int rem = p.Lk % KT;
+  unsigned voffk[2], voffv[2], toffk[2], toffv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 3, ch = (c & 7) ^ ((row >> 1) & 7);
+    voffk[i] = (unsigned)(row * p.ldk * 2 + ch * 16);
+    voffv[i] = (unsigned)(row * p.ldvt * 2 + ch * 16);
+    toffk[i] = (unsigned)((row < rem ? row : rem - 1) * p.ldk * 2 + ch * 16);
+    toffv[i] = (unsigned)(row * p.ldvt * 2 + ((ch >> 1) * 16 < rem ? ch * 16 : 0));    // chunk ch = positions 8 ch ..: 16-key group ch >> 1
+  }
+  // the next tile to issue: uniform pointers advanced per tile (a chunk boundary of the patch-parallel layout jumps them)
+  const char* knext = kbase;
+  const char* vnext = vbase;
+  int chunk_left = p.key_chunk > 0 ? p.key_chunk : 0x7fffffff;
+  int chunk_id = 0;
+  const unsigned wave_img = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+  auto issue_tile = [&](int buf, bool tail) __attribute__((always_inline)) {
+    char* img = smem + buf * kBufBytes + wave_img;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(knext + (tail ? toffk[i] : voffk[i])),
+                                       (__attribute__((address_space(3))) void*)(img + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vnext + (tail ? toffv[i] : voffv[i])),
+                                       (__attribute__((address_space(3))) void*)(img + 8192 + i * 4096), 16, 0, 0);
+    }
+    knext += (long)KT * p.ldk * 2;
+    vnext += KT * 2;
+    chunk_left -= KT;
+    if (chunk_left == 0) {                     // tiles never straddle a chunk (key_chunk % 64 == 0)
+      ++chunk_id;
+      chunk_left = p.key_chunk;
+      knext = kbase + (long)chunk_id * p.k_cstride * 2;
+      vnext = vbase + (long)chunk_id * p.vt_cstride * 2;
+    }
+  };
+
+  unsigned koff[4];                            // per-lane LDS read offsets inside a buffer (see attn_fwd_kernel)
+  {
+    const int swz = (r >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(r * 128 + (((2 * ks + hh) ^ swz) * 16));
+  }
+
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 oacc[2][2] = {{zero16, zero16}, {zero16, zero16}};
+  float l_run[2] = {0.f, 0.f};                 // this half-wave's partial row sums
+  // the reference k-step (see attn_fwd_kernel): A operand = a K column of ones, B operand = -m_ref of query column r
+  const unsigned one_lo = hh == 0 ? 0x3F80u : 0u;
+  const bf16x8 kone = __builtin_bit_cast(bf16x8, u32x4{one_lo, 0u, 0u, 0u});
+  u32x4 qm[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  float m_ref[2] = {0.f, 0.f};
+
+  const int ntiles = (p.Lk + KT - 1) / KT;     // >= 3 (launcher)
+
+  auto read_k = [&](bf16x8 (&fr)[8], unsigned bofs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fr[kb * 4 + ks] = *reinterpret_cast<const bf16x8*>(smem + bofs + koff[ks] + kb * 4096);
+  };
+  auto read_v = [&](bf16x8 (&fr)[8], unsigned bofs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) fr[sidx * 2 + db] = *reinterpret_cast<const bf16x8*>(smem + bofs + koff[sidx] + 8192 + db * 4096);
+  };
+  auto mask_scores = [&](f32x16 (&s)[2]) __attribute__((always_inline)) {        // ragged last tile: keys >= Lk never count
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh >= rem) s[kb][e] = -INFINITY;
+  };
+  auto mask_v = [&](bf16x8 (&fr)[8]) __attribute__((always_inline)) {            // ... and their V^T entries (any bit pattern) are zero
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        u32x4 w = __builtin_bit_cast(u32x4, fr[sidx * 2 + db]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // word j = elements 2j, 2j + 1 = keys k0, k0 + 1
+          const int k0 = 16 * sidx + 4 * hh + ((2 * j) & 3) + 8 * (j >> 1);
+          if (k0 >= rem) w[j] &= 0xffff0000u;
+          if (k0 + 1 >= rem) w[j] &= 0x0000ffffu;
+        }
+        fr[sidx * 2 + db] = __builtin_bit_cast(bf16x8, w);
+      }
+  };
+  auto qk = [&](f32x16 (&s)[2], const bf16x8 (&fr)[8], int blk) __attribute__((always_inline)) {   // s = (K Q^T) - m_ref
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[blk][ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+      s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm[blk]), s[kb], 0, 0, 0);
+  };
+  auto col_max = [&](const f32x16 (&s)[2]) __attribute__((always_inline)) {
+    float mx_ = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx_ = fmaxf(mx_, fmaxf(s[0][e], s[1][e]));
+    return max_across_halves(mx_);
+  };
+  // p = exp2(s) in place, packed to the four B fragments of O^T += V^T P^T; returns this half-wave's sum
+  auto exp_pack = [&](f32x16 (&s)[2], u32x4 (&pw)[4]) __attribute__((always_inline)) {
+    float ps = 0.f;                            // ONE chain: two would be SLP-packed into v_pk_add_f32, which costs more beside MFMAs
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float p0 = __builtin_amdgcn_exp2f(s[0][e]);
+      const float p1 = __builtin_amdgcn_exp2f(s[1][e]);
+      s[0][e] = p0; s[1][e] = p1;
+      ps += p0; ps += p1;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pw[sidx][e] = pack2(s[sidx >> 1][8 * (sidx & 1) + 2 * e], s[sidx >> 1][8 * (sidx & 1) + 2 * e + 1]);
+    return ps;
+  };
+  // The softmax reference m_ref is lazy (attn_fwd_kernel): it only has to keep p = exp2(s - m_ref) in range.  The loop computes p
+  // speculatively and looks at the sums: a score more than 8 above the reference makes its p, hence the lane's sum, exceed 256.
+  // Then (rarely) this path redoes the block exactly: scores again from the K fragments, reference raised to the new maximum, p,
+  // and O / l rescaled.  No false negatives; a false positive (32 scores averaging > 3 above the reference) costs time only.
+  auto redo = [&](f32x16 (&s)[2], u32x4 (&pw)[4], const bf16x8 (&fr)[8], int blk, const bool tail) __attribute__((always_inline)) {
+    qk(s, fr, blk);
+    if (tail) mask_scores(s);
+    const float mx_ = col_max(s);
+    float delta = 0.f;
+    if (mx_ > 8.0f) {
+      const float nr = bf16lo_to_f32(pack2(m_ref[blk] + mx_, 0.f));          // new reference, bf16-representable
+      delta = nr - m_ref[blk];
+      m_ref[blk] = nr;
+    }
+    qm[blk][0] = hh == 0 ? (pack2(-m_ref[blk], 0.f) & 0xffffu) : 0u;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kb][e] -= delta;
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    l_run[blk] *= alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[blk][i][e] *= alpha;
+    return exp_pack(s, pw);
+  };
+
+  issue_tile(0, false);
+  issue_tile(1, false);
+  // ---- the reference starts at the maximum of tile 0 (a whole tile; its scores are computed again by the loop) ----
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    bf16x8 fr[8];
+    read_k(fr, 0);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      f32x16 s[2];
+      qk(s, fr, blk);
+      m_ref[blk] = bf16lo_to_f32(pack2(col_max(s), 0.f));
+      qm[blk][0] = hh == 0 ? (pack2(-m_ref[blk], 0.f) & 0xffffu) : 0u;
+    }
+  }
+  int buf = 0;
+  unsigned bofs = 0;
+
+  // one tile: fragments of buffer `bofs`; TAIL = the ragged last tile
+  auto tile = [&](const bool TAIL) __attribute__((always_inline)) {
+    bf16x8 fr[8];
+    f32x16 s0[2], s1[2];
+    u32x4 pw0[4], pw1[4];
+    read_k(fr, bofs);
+    qk(s0, fr, 0);                             // S^T of block 0
+    if (TAIL) mask_scores(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    qk(s1, fr, 1);                             // S^T of block 1 beside the exponentials of block 0
+    float ps = exp_pack(s0, pw0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (TAIL) mask_scores(s1);
+    if (__any(ps > 256.0f)) {
+      ps = redo(s0, pw0, fr, 0, TAIL);
+    }
+    l_run[0] += ps;
+    read_v(fr, bofs);                          // V^T fragments (the K fragments are dead: same registers)
+    if (TAIL) mask_v(fr);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)       // O^T of block 0 beside the exponentials of block 1
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+        oacc[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[sidx * 2 + db], __builtin_bit_cast(bf16x8, pw0[sidx]), oacc[0][db], 0, 0, 0);
+    ps = exp_pack(s1, pw1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (__any(ps > 256.0f)) {
+      read_k(fr, bofs);
+      ps = redo(s1, pw1, fr, 1, TAIL);
+      read_v(fr, bofs);
+      if (TAIL) mask_v(fr);
+    }
+    l_run[1] += ps;
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)       // O^T of block 1
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+        oacc[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[sidx * 2 + db], __builtin_bit_cast(bf16x8, pw1[sidx]), oacc[1][db], 0, 0, 0);
+  };
+
+  const int nfull = rem ? ntiles - 1 : ntiles;  // whole tiles
+  for (int kt = 0; kt < nfull; ++kt) {
+    if (kt > 0) {
+      if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // tile kt has landed for every thread; every wave has left the buffer of tile kt - 1
+      asm volatile("" ::: "memory");
+    }
+    if (kt + 2 < ntiles) issue_tile(buf == 0 ? 2 : buf - 1, rem && kt + 3 == ntiles);   // tile kt + 2 into buffer (kt + 2) % 3
+    tile(false);
+    buf = buf == 2 ? 0 : buf + 1;
+    bofs = (unsigned)buf * kBufBytes;
+  }
+  if (rem) {                                   // the ragged last tile (never tile 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    tile(true);
+  }
+
+  // ---- normalise; O[q][d] through the wave's 8 KB of the ring (rows = queries, 128 B, 16-byte chunk ^= row & 7) so that the
+  //      global stores are whole rows.  Lane (r, hh) holds d = 32 db + 8 g + 4 hh + {0..3} of query 32 blk + r. ----
+  __syncthreads();                             // every wave has left the last tile
+  char* patch = smem + wave * 8192;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const float inv = 1.0f / (l_run[blk] + __shfl_xor(l_run[blk], 32, 64));
+    const int row = blk * 32 + r;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2 o = {pack2(oacc[blk][db][4 * g] * inv, oacc[blk][db][4 * g + 1] * inv),
+                         pack2(oacc[blk][db][4 * g + 2] * inv, oacc[blk][db][4 * g + 3] * inv)};
+        const int chunk = (4 * db + g) ^ (row & 7);
+        *reinterpret_cast<u32x2*>(patch + row * 128 + chunk * 16 + hh * 8) = o;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (lane >> 3) + 8 * i;
+    const int ch = lane & 7;
+    const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * 128 + ((ch ^ (row & 7)) * 16));
+    const int qi = q0 + row;
+    if (qi < p.Lq) *reinterpret_cast<u32x4*>(p.o + ((long)b * p.Lq + qi) * p.ldo + head * 64 + ch * 8) = o;
   }
 }
 
@@ -791,7 +1129,11 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
   prof_begin((hipStream_t)stream, PROF_ATTN, 4.0 * B * H * (double)Lq * Lk * 64.0,
              2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
   static const bool dma_off = [] { const char* e = getenv("MX_ATTN_DMA"); return e && e[0] == '0'; }();
-  if (Lk % KT == 0 && Lk >= 3 * KT && !dma_off) {      // whole tiles: LDS-DMA staging two tiles ahead
+  static const int w64_min = [] { const char* e = getenv("MX_ATTN_W64_MIN_LQ"); return e ? atoi(e) : 2048; }();   // (a tie with the 32-row kernels at Lq 1024)
+  if (pre && Lk > 2 * KT && !dma_off && Lq >= w64_min && ldo % 8 == 0) {   // 64 query rows per wave
+    dim3 grid64(cdiv(Lq, 256), H, B);
+    hipLaunchKernelGGL(attn_fwd64_kernel, grid64, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (Lk % KT == 0 && Lk >= 3 * KT && !dma_off) {      // whole tiles: LDS-DMA staging two tiles ahead
     if (pre) hipLaunchKernelGGL(attn_fwd_dma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_fwd_dma_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
   } else if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -308,7 +308,8 @@ def _prescaled_case(q, k, v, heads, what, tol=2.0 ** -6):
     _close(got.reshape(b, lq, c), want, tol, what)
 
 
-@pytest.mark.parametrize("lq,lk,heads", [(256, 256, 2), (1024, 1024, 1), (64, 77, 4), (200, 77, 1), (4096, 4096, 1), (333, 4429, 1)])
+@pytest.mark.parametrize("lq,lk,heads", [(256, 256, 2), (1024, 1024, 1), (64, 77, 4), (200, 77, 1), (4096, 4096, 1), (333, 4429, 1), (600, 320, 2), (777, 192, 8), (2125, 1101, 1), (2048, 192, 2),
+                                           (2300, 141, 1)])
 def test_attention_prescaled(cuda_device, lq, lk, heads):
     g = torch.Generator().manual_seed(lq * 3 + lk + heads)
     b, c = 2, heads * 64
@@ -316,12 +317,13 @@ def test_attention_prescaled(cuda_device, lq, lk, heads):
     _prescaled_case(q, k, v, heads, f"attention prescaled {lq}x{lk}")
 
 
+@pytest.mark.parametrize("l", [512, 2112])     # 32-row-per-wave kernels / the 64-row-per-wave kernel (Lq >= 2048)
 @pytest.mark.parametrize("case", ["late_spikes", "first_tile_max", "very_negative_start", "huge_logits"])
-def test_attention_prescaled_reference_moves(cuda_device, case):
+def test_attention_prescaled_reference_moves(cuda_device, case, l):
     """the lazy softmax reference: raised at late tiles, never needed again, started far below zero, and logits whose
     exp2 would overflow fp32 without a reference."""
     g = torch.Generator().manual_seed(17)
-    b, l, c = 1, 512, 64
+    b, c = 1, 64
     q = _rt(torch.randn(b, l, c, generator=g)); k = _rt(torch.randn(b, l, c, generator=g)); v = _rt(torch.randn(b, l, c, generator=g))
     if case == "late_spikes":
         k[0, 300] = q[0, 5] * 4.0; k[0, 450] = q[0, 77] * 6.0; k[0, 451] = q[0, 77] * 9.0

@@ -22,7 +22,9 @@ def main():
         k = torch.randn(b * lk, c, device=dev, generator=g).to(torch.bfloat16)
         ldvt = ops.vt_ld(lk)
         vt = torch.randn(b, c, ldvt, device=dev, generator=g).to(torch.bfloat16)
+        qs = (q.float() * ops.ATTN_QSCALE).to(torch.bfloat16)        # what the producing GEMM epilogue hands to the prescaled entry point
         for pre in (False, True):
+            q = qs if pre else q
             for _ in range(2):
                 ops.attention(q, k, vt, h, lq, lk, prescaled=pre)
             torch.cuda.synchronize()
