@@ -131,9 +131,31 @@ typedef struct mx_gemm_desc {
    * reads torch.cat([hidden_states, res_hidden_states]); not combined with the joint-sequence row remap.) */
   const void* a2;
   int lda2, k_split;
+  /* LayerNorm folded into the GEMM that consumes it (the SDXL BasicTransformerBlock's norm1 / norm2 / norm3, modules/transformer.py:191,
+   * 239, 266: each feeds exactly one linear).  With W' = W * gamma (per input feature, packed in `w`), colsum[n] = sum_k W'[n][k] (fp32, of
+   * the bf16-rounded W') and bias' = bias + W beta (in `bias`):
+   *     LayerNorm(x) W^T + bias  ==  rstd_m * (x W'^T - mean_m * colsum) + bias'
+   * so the GEMM reads the UN-normalised x and its epilogue applies the row statistics: no LayerNorm pass, no rounding of the normalised
+   * activations.  ln_stats != NULL selects it: fp32 pairs (sum x, sum x^2) per row and slab, ln_stats[(m * pitch + slab) * 2 + {0, 1}] with
+   * pitch = MX_STATS_PITCH(ln_slabs), summed over ln_slabs slabs (written by the producing GEMM through stats_out, or by mx_row_stats
+   * with one slab; entries past the last slab are never read); 16-byte aligned; the LN width is K.  Not combined with MX_EPI_RMSNORM or
+   * the row remaps.
+   * stats_out != NULL (plain bf16 output, no GEGLU / QKV / remap): the epilogue also writes, for every output row, the sum and the sum of
+   * squares of the values it stores, one slab per wave column panel; mx_gemm_stats_slabs(d) tells how many slabs THIS launch writes
+   * (0: the kernel chosen for d cannot, use mx_row_stats). */
+  const float* ln_stats;
+  const float* ln_colsum;
+  int ln_slabs;
+  float ln_eps;
+  float* stats_out;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
+int mx_gemm_stats_slabs(const mx_gemm_desc* d);        /* slabs d->stats_out receives from mx_gemm(d); 0 = not supported for this shape */
+#define MX_STATS_PITCH(slabs) (((slabs) + 3) & ~3)     /* slabs per row of a statistics buffer: [M][pitch][2] floats */
+/* stats[m * 4 * 2 + {0, 1}] = (sum_c x[m][c], sum_c x[m][c]^2), x bf16 [M, C] with row stride ldx: the one-slab input of ln_stats
+ * (buffer of M * MX_STATS_PITCH(1) * 2 floats) */
+int mx_row_stats(void* stream, const void* x, int ldx, float* stats, int M, int C);
 int mx_conv3x3(void* stream, const mx_gemm_desc* d);   /* implicit GEMM, pad 1 */
 
 /* V^T key order.  The attention kernel feeds its softmax accumulator straight back to the matrix core as the

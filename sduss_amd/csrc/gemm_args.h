@@ -34,7 +34,95 @@ struct GemmArgs {
   int vhalo;           // conv: images stored with one halo row above and below (patch-parallel)
   const bf16_t* a2;    // GEMM: columns [k_split, K) of the A operand come from a2 (row stride lda2); nullptr = one source
   int lda2, k_split;
+  const float* ln_stats;   // folded LayerNorm (mxdenoise.h): (sum, sum of squares) per row and slab; nullptr = off
+  const float* ln_colsum;
+  int ln_slabs;
+  float ln_eps;
+  float* stats_out;        // row statistics of the stored values, one slab per wave column panel; nullptr = off
 };
+
+// sum over the four lanes of a token (lane bits 4 and 5) without the LDS crossbar: v_permlane16_swap / v_permlane32_swap exchange
+// 16-lane rows / wave halves between two registers (inline asm: the builtins fold their two results when both inputs are one value)
+__device__ __forceinline__ float sum_over_fq(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  a += b; b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+// Folded LayerNorm in the 256 / 128-row kernels, accumulator side.  Before the K loop the accumulators start at -mean_m * colsum_n, so
+// the loop leaves x W'^T - mean colsum and the epilogue only multiplies by rstd_m (returned; 1 without the fold) before the bias: the
+// statistics and column sums are fetched while the first operand tiles are in flight, and the epilogue carries no extra vectors.
+// (First version: everything in the epilogue -- eight serial round trips to the statistics per 256 x 256 tile and 60 spilled registers
+// cost 37 us per launch.)  The four lanes of a token split the slabs; the slab loop is the OUTER loop so that each round has MI
+// independent loads in flight.
+template <int NI, int MI>
+__device__ __forceinline__ void gemm_ln_init(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0, const int fr,
+                                             const int fq, float (&rstd)[MI]) {
+  // statistics layout: row m holds its slabs side by side, ln_stats[(m * pitch + slab) * 2 + {0, 1}], pitch = slabs rounded up to 4: lane
+  // (token, fq) reads slabs 4 fq .. 4 fq + 3 (of every group of 16) as two 16-byte loads -- one round trip for up to 16 slabs
+  const int slabs = p.ln_slabs;
+  const int pitch = (slabs + 3) & ~3;
+  float s1[MI], s2[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  for (int g = 4 * fq; g < slabs; g += 16) {
+    constexpr int JC = MI > 4 ? 4 : MI;        // token blocks per round (registers: 8 per block in flight)
+#pragma unroll
+    for (int j0 = 0; j0 < MI; j0 += JC) {
+      f32x4 va[JC], vb[JC];
+#pragma unroll
+      for (int j = 0; j < JC; ++j) {
+        const int m = m_wave0 + (j0 + j) * 16 + fr;
+        const float* src = p.ln_stats + ((long)(m < p.M ? m : p.M - 1) * pitch + g) * 2;
+        va[j] = *reinterpret_cast<const f32x4*>(src);
+        vb[j] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < JC; ++j) {           // entries past the last slab were never written
+        s1[j0 + j] += va[j][0] + (g + 1 < slabs ? va[j][2] : 0.f) + (g + 2 < slabs ? vb[j][0] : 0.f) + (g + 3 < slabs ? vb[j][2] : 0.f);
+        s2[j0 + j] += va[j][1] + (g + 1 < slabs ? va[j][3] : 0.f) + (g + 2 < slabs ? vb[j][1] : 0.f) + (g + 3 < slabs ? vb[j][3] : 0.f);
+      }
+    }
+  }
+  const float inv = 1.0f / (float)p.K;
+  float nmean[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const float a = sum_over_fq(s1[j]), b = sum_over_fq(s2[j]);
+    const float mean = a * inv;
+    const float var = fmaxf(b * inv - mean * mean, 0.f);
+    rstd[j] = rsqrtf(var + p.ln_eps);
+    nmean[j] = -mean;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int n = wave_n0 + i * 16 + fq * 4;
+    const f32x4 cs = n < p.N ? *reinterpret_cast<const f32x4*>(p.ln_colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = cs * nmean[j];
+  }
+}
+
+// one row: (rstd, rstd * mean) of row m from the slabs of partial sums.  Called by all 64 lanes; the four lanes of a token
+// (lane & 15 equal) split the slabs and combine by shuffles.
+__device__ __forceinline__ void gemm_ln_row(const GemmArgs& p, const int m, const int fq, float& rstd, float& rm) {
+  const int mc = m < p.M ? m : p.M - 1;
+  const int pitch = (p.ln_slabs + 3) & ~3;
+  float s1 = 0.f, s2 = 0.f;
+  for (int s = fq; s < p.ln_slabs; s += 4) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(p.ln_stats + ((long)mc * pitch + s) * 2);
+    s1 += v[0]; s2 += v[1];
+  }
+  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+  const float inv = 1.0f / (float)p.K;
+  const float mean = s1 * inv;
+  const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+  rstd = rsqrtf(var + p.ln_eps);
+  rm = rstd * mean;
+}
 
 // row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)
 __device__ __forceinline__ long gemm_in_row(const GemmArgs& p, int m) {
@@ -67,10 +155,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
   // MX_EPI_RMSNORM: the wave's 64 features are one head (BN = 128).  A token's head is spread over the NI = 4 blocks of a
   // lane and the 4 lanes fr, fr+16, fr+32, fr+48.
   const bool rms = qkv && (flags & MX_EPI_RMSNORM) && !to_vt;
+  const bool ln = p.ln_stats != nullptr;
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = m_wave0 + j * 16 + fr;
     float rms_mul = 1.0f;
+    float ln_rstd = 1.0f, ln_rm = 0.f;
+    if (ln) gemm_ln_row(p, m, fq, ln_rstd, ln_rm);   // before the row mask: the shuffles need every lane
     if (rms) {                                   // before the row mask: the shuffles need every lane
       float ss = 0.f;
 #pragma unroll
@@ -95,6 +186,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
       float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q];
+      if (ln) {
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * ln_rstd - ln_rm * c4[q];
+      }
       if (p.bias) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
@@ -113,6 +209,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
         const int ng = n + (NI / 2) * 16;  // gate blocks follow the hidden blocks inside the wave tile
 #pragma unroll
         for (int q = 0; q < 4; ++q) g[q] = acc[i + NI / 2][j][q];
+        if (ln) {
+          const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.ln_colsum + ng);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) g[q] = g[q] * ln_rstd - ln_rm * c4[q];
+        }
         if (p.bias) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + ng);
 #pragma unroll
@@ -455,9 +556,10 @@ __device__ __forceinline__ u32x4 lane_xor1(const u32x4 x) {
 }
 
 // VPF: per-sample vectors are loaded one token block ahead (costs 8 * NIO registers; off in the persistent 256 x 256 kernel)
-template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true>
+// STATS: can write row statistics (stats_out); off in the 256 x 256 kernels, whose register budget is spent
+template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true>
 __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
-                                                   const int fr, const int fq) {
+                                                   const int fr, const int fq, const float (&ln_rstd_a)[MI]) {
   constexpr int NIO = GEGLU ? NI / 2 : NI;     // output blocks per wave
   constexpr int NP = NIO / 2;                  // exchanged pairs
   constexpr bool ODD = (NIO & 1) != 0;         // a last block stored from the accumulator layout
@@ -492,6 +594,9 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
     for (int i = 0; i < NI; ++i) rmsw_r[i] = *reinterpret_cast<const f32x4*>(w + ((wave_n0 - seg_idx * p.seg + i * 16 + fq * 4) & 63));
   }
+  // folded LayerNorm: the accumulators arrive as x W'^T - mean_m colsum_n (gemm_ln_init) and ln_rstd_a holds rstd_m (1 without the fold,
+  // and acc * 1 + bias is acc + bias exactly)
+  const bool stats = STATS && !GEGLU && !qkv && p.stats_out != nullptr;
 
   // row addressing of token block j: accumulator layout (token = lane & 15) and row layout are the same token
   auto token = [&](int j) __attribute__((always_inline)) { return m_wave0 + j * 16 + fr; };
@@ -564,6 +669,8 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
     float v[NIO][4];
     float rms_mul = 1.0f;
     if constexpr (!VPF) { if (has_rb || has_gate) load_batch_vectors(j); }
+    const float ln_rstd = ln_rstd_a[j];
+    float st1 = 0.f, st2 = 0.f;                // stats_out: this lane's part of the token's sums
     if (rms) {                                 // every lane takes part in the shuffles (masking happens at the store)
       float ss = 0.f;
 #pragma unroll
@@ -576,9 +683,9 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
     }
 #pragma unroll
     for (int i = 0; i < NIO; ++i) {
-      f32x4 t = acc[i][j] + bias_r[i];
+      f32x4 t = acc[i][j] * ln_rstd + bias_r[i];
       if constexpr (GEGLU) {
-        const f32x4 g = acc[i + NI / 2][j] + bias_r[i + NI / 2];
+        const f32x4 g = acc[i + NI / 2][j] * ln_rstd + bias_r[i + NI / 2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) t[q] = t[q] * gelu_fast(g[q]);
       } else {
@@ -626,6 +733,10 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       if (flags & MX_EPI_GELU_TANH) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = gelu_tanh_f(o[q]);
+      }
+      if (stats) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { st1 += o[q]; st2 += o[q] * o[q]; }
       }
     };
     if constexpr (fullmode) {
@@ -697,9 +808,21 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = gelu_tanh_f(o[q]);
       }
+      if (stats) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { st1 += o[q]; st2 += o[q] * o[q]; }
+      }
       if (m < p.M) {
         const int col = col0 + NP * 32 + fq * 4;
         *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+      }
+    }
+    if (stats) {                               // the token's four lanes hold disjoint columns of the wave's panel: slab = panel index
+      st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
+      st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
+      if (fq == 0 && m < p.M) {
+        const int slab = wave_n0 / (16 * NI), pitch = (p.N / (16 * NI) + 3) & ~3;
+        *reinterpret_cast<f32x2*>(p.stats_out + ((long)m * pitch + slab) * 2) = f32x2{st1, st2};
       }
     }
   }

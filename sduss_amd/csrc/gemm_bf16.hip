@@ -225,6 +225,16 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   return best;
 }
 
+// slabs of row statistics the launch of d writes: one per wave column panel of the register-exchange epilogue (gemm_epilogue_regs);
+// 0 when the generic kernel serves d or the epilogue is not a plain bf16 store
+static int stats_slabs_of(const mx_gemm_desc* d, bool conv, const TileChoice& tc) {
+  if (conv || tc.bn == 0 || tc.bn == 256) return 0;     // (the 256 x 256 kernels are built without it)
+  if (d->flags & (MX_EPI_GEGLU | MX_EPI_QKV | MX_EPI_OUT_F32)) return 0;
+  if (d->a_batch_rows > 0 || d->c_batch_rows > 0) return 0;
+  const int panel = tc.bn / 2;                          // 4 x 2 waves of (16 MI) x (BN / 2)
+  return d->N / panel;
+}
+
 static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   MX_CHECK(d != nullptr, "gemm: null descriptor");
   MX_CHECK(d->a && d->w && (d->c || (d->flags & MX_EPI_QKV)), "gemm: null operand");
@@ -244,6 +254,12 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   a.a_batch_rows = d->a_batch_rows; a.a_row_off = d->a_row_off; a.c_batch_rows = d->c_batch_rows; a.c_row_off = d->c_row_off;
   a.gate = d->gate; a.ldg = d->ldg; a.out_scale = d->out_scale;
   a.rms_wq = d->rms_wq; a.rms_wk = d->rms_wk; a.rms_eps = d->rms_eps;
+  a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum; a.ln_slabs = d->ln_slabs; a.ln_eps = d->ln_eps; a.stats_out = nullptr;
+  if (d->ln_stats) {
+    MX_CHECK(!conv && d->ln_colsum && d->ln_slabs > 0, "gemm: folded LayerNorm needs ln_colsum and ln_slabs > 0 (mx_gemm only)");
+    MX_CHECK(!(d->flags & MX_EPI_RMSNORM) && d->a_batch_rows <= 0 && d->c_batch_rows <= 0 && !d->a2, "gemm: folded LayerNorm excludes RMSNORM, the row remaps and the split A operand");
+    MX_CHECK((((uintptr_t)d->ln_stats & 15) | ((uintptr_t)d->ln_colsum & 15)) == 0, "gemm: ln_stats / ln_colsum must be 16-byte aligned");
+  }
   static const int xcd_map = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
   a.xcd_map = xcd_map;
 
@@ -285,6 +301,11 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   const bool use128 = (d->N % 128 == 0);
   const TileChoice tc = pick_tile(d, conv);
   const int v2bn = tc.bn;
+  if (d->stats_out) {
+    MX_CHECK(stats_slabs_of(d, conv, tc) > 0, "gemm: stats_out is not supported for this shape / epilogue (see mx_gemm_stats_slabs)");
+    MX_CHECK(((uintptr_t)d->stats_out & 15) == 0, "gemm: stats_out must be 16-byte aligned");
+    a.stats_out = d->stats_out;
+  }
   if (d->flags & MX_EPI_GEGLU) {
     MX_CHECK(use128, "gemm: GEGLU needs N % 128 == 0");
     MX_CHECK(!(d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32)) && !d->residual && !d->rowbias && d->out_scale == 0.f, "gemm: GEGLU excludes other epilogues");
@@ -333,4 +354,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
 }  // namespace mx
 
 extern "C" int mx_gemm(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, false); }
+extern "C" int mx_gemm_stats_slabs(const mx_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  return mx::stats_slabs_of(d, false, mx::pick_tile(d, false));
+}
 extern "C" int mx_conv3x3(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, true); }

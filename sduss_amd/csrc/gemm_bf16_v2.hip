@@ -78,6 +78,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   int is_tile = blockIdx.x;     // tile id the cursor is in (>= total_tiles: past the end)
   int is_kt = 0;
   const char* xsrc[XI];         // source of the thread's X chunks for the next group
+  long xjump[XI];               // split A operand: extra byte step of the thread's X chunks when K reaches k_split (into the second source)
   const char* wsrc[WI];
   int cb[XI], cy[XI], cx[XI];   // CONV: image, y, x of the row's output pixel (input coordinates of the centre tap)
   unsigned xchb[XI];            // CONV: byte offset of the thread's swizzled chunk inside a K tile
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       if constexpr (!CONV) {
         const int mc = m < p.M ? m : p.M - 1; // clamped rows are computed and discarded by the epilogue mask
         xsrc[i] = reinterpret_cast<const char*>(p.a) + (gemm_in_row(p, mc) * p.lda + ch * 8) * 2;
+        xjump[i] = p.a2 != nullptr ? (reinterpret_cast<const char*>(p.a2) + ((long)mc * p.lda2 + ch * 8) * 2) - (xsrc[i] + (long)p.k_split * 2) : 0;
       } else {
         xchb[i] = ch * 16;
         if (m < p.M) {
@@ -189,20 +191,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < WI; ++i) wsrc[i] += BK2 * 2;
     if constexpr (!CONV) {
-      if (p.a2 != nullptr && is_kt * BK2 == p.k_split) {       // the A operand continues in its second source (gemm_args.h)
-        int tm, tn;
-        gemm_tile_of_block(is_tile, mt, p.N / BN, p.xcd_map, tm, tn);
+      // at K = k_split the A operand continues in its second source (gemm_args.h): one more byte step, selected without a branch
+      // (the branchy form of this switch was miscompiled once the epilogue grew: the prologue's second advance lost its increment)
+      const bool to_a2 = p.a2 != nullptr && is_kt * BK2 == p.k_split;
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-          const int row = (i * 512 + tid) >> 3;
-          const int m = tm * BM2 + row;
-          const int mc = m < p.M ? m : p.M - 1;
-          xsrc[i] = reinterpret_cast<const char*>(p.a2) + ((long)mc * p.lda2 + swz2(row, cs) * 8) * 2;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < XI; ++i) xsrc[i] += BK2 * 2;
-      }
+      for (int i = 0; i < XI; ++i) xsrc[i] += BK2 * 2 + (to_a2 ? xjump[i] : 0L);
     } else {
       if (++in_tap == tiles_per_tap) {
         in_tap = 0;
@@ -247,6 +240,16 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ln_rstd[MI];                          // folded LayerNorm (gemm_ln_init): while the first operand tiles are in flight
+#pragma unroll
+    for (int j = 0; j < MI; ++j) ln_rstd[j] = 1.0f;
+    if constexpr (!CONV) {
+      if (p.ln_stats != nullptr) {
+        int tm_, tn_;
+        gemm_tile_of_block(tile, mt, p.N / BN, p.xcd_map, tm_, tn_);
+        gemm_ln_init<NI, MI>(p, acc, tm_ * BM2 + wm * 16 * MI, tn_ * BN + wn * (BN / 2), fr, fq, ln_rstd);
+      }
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
       // all but the youngest DMA group (and anything younger) of this thread has completed => stream position g landed
@@ -312,9 +315,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
 #else
     // register-exchange epilogue (gemm_args.h): no LDS, no barrier; the past-the-end DMAs are drained before the workgroup retires
     if (p.flags & MX_EPI_GEGLU) {
-      if constexpr (NI % 4 == 0 && !CONV) gemm_epilogue_regs<NI, MI, true>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq);
+      if constexpr (NI % 4 == 0 && !CONV) gemm_epilogue_regs<NI, MI, true>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
     } else {
-      gemm_epilogue_regs<NI, MI, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq);
+      gemm_epilogue_regs<NI, MI, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

@@ -184,6 +184,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ln_rstd[MI];                         // folded LayerNorm (gemm_ln_init)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) ln_rstd[j] = 1.0f;
+    if (p.ln_stats != nullptr) {
+      int tm_, tn_;
+      gemm_tile_of_block(tile, mt, nt, p.xcd_map, tm_, tn_);
+      gemm_ln_init<NI, MI>(p, acc, tm_ * BM3 + wm * 16 * MI, tn_ * BN3 + wn * 16 * NI, fr, fq, ln_rstd);
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
       // all but the youngest group (the X half-tile of the next stream position) has landed => X and W of this position are in
@@ -259,8 +267,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
     // Register-exchange epilogue (gemm_args.h): no LDS, no barrier.  The ring keeps receiving the first half-tiles of the
     // workgroup's next tile meanwhile; a wave that finishes early waits at the next K loop's first barrier, behind which
     // the slots its slower siblings are still reading get re-issued.
-    if (p.flags & MX_EPI_GEGLU) gemm_epilogue_regs<NI, MI, true, VEC, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq);
-    else gemm_epilogue_regs<NI, MI, false, VEC, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq);
+    if (p.flags & MX_EPI_GEGLU) gemm_epilogue_regs<NI, MI, true, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
+    else gemm_epilogue_regs<NI, MI, false, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
     MX_STAMP(stamp_i + 2);
     stamp_i += 3;
     // the cursors' per-thread offsets are recomputed from (tile, K tile) rather than kept in registers across the epilogue

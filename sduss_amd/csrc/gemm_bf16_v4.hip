@@ -221,6 +221,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ln_rstd[MI];                         // folded LayerNorm (gemm_ln_init): fetched in the hand-over between two tiles
+#pragma unroll
+    for (int j = 0; j < MI; ++j) ln_rstd[j] = 1.0f;
+    if (p.ln_stats != nullptr) {
+      int tm_, tn_;
+      gemm_tile_of_block(tile, mt, nt, p.xcd_map, tm_, tn_);
+      gemm_ln_init<NI, MI>(p, acc, tm_ * BM4 + wm * 16 * MI, tn_ * BN4 + wn * 16 * NI, fr, fq, ln_rstd);
+    }
 
     if (wm == 1) MX_BAR();                     // wave row 1 runs one barrier behind row 0
 
@@ -309,8 +317,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
     int tm, tn;
     gemm_tile_of_block(tile, mt, nt, p.xcd_map, tm, tn);
     const int m0 = tm * BM4, n0 = tn * BN4;
-    if (p.flags & MX_EPI_GEGLU) gemm_epilogue_regs<NI, MI, true, VEC, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq);
-    else gemm_epilogue_regs<NI, MI, false, VEC, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq);
+    if (p.flags & MX_EPI_GEGLU) gemm_epilogue_regs<NI, MI, true, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
+    else gemm_epilogue_regs<NI, MI, false, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end DMAs before the workgroup retires
 #if MX_EXP == 7

@@ -407,6 +407,27 @@ extern "C" int mx_layernorm(void* stream, const void* x, void* y, const float* g
 // ------------------------------------------------------------------------------------------
 namespace mx {
 
+// (sum, sum of squares) of every row: the one-slab statistics of the LayerNorm folded into its consumer GEMM (mx_gemm_desc.ln_stats)
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, int ldx, float* __restrict__ stats, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C / 8;
+  const bf16_t* xr = x + (long)row * ldx;
+  float s1 = 0.f, s2 = 0.f;
+  for (int ch = lane; ch < nch; ch += 64) {
+    const u32x4 u = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = bf16lo_to_f32(u[e]), b = bf16hi_to_f32(u[e]);
+      s1 += a + b;
+      s2 += a * a + b * b;
+    }
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) *reinterpret_cast<f32x2*>(stats + (long)row * 8) = f32x2{s1, s2};     // one slab, row pitch 4 (mxdenoise.h)
+}
+
 template <int VPL>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                             bf16_t* __restrict__ y2, const float* __restrict__ scale,
@@ -548,6 +569,15 @@ extern "C" int mx_rmsnorm_heads(void* stream, void* x, int ld, int nbatch, int r
   const long waves = (long)nbatch * rows_per_batch * ((heads_total + 7) / 8);
   hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((unsigned)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld,
                      nbatch, rows_per_batch, batch_rows, row_off, heads_total, heads_q, wq, wk, eps, q_scale);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mx_row_stats(void* stream, const void* x, int ldx, float* stats, int M, int C) {
+  using namespace mx;
+  MX_CHECK(x && stats && M > 0, "row_stats: null operand");
+  MX_CHECK(C % 8 == 0 && ldx >= C && ldx % 8 == 0 && (((uintptr_t)x & 15) | ((uintptr_t)stats & 7)) == 0, "row_stats: C and ldx must be multiples of 8, pointers aligned");
+  hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, stats, M, C);
   MX_LAUNCH_CHECK();
   return 0;
 }

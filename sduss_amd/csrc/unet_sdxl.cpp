@@ -182,13 +182,33 @@ struct Plan {
     if (rc) return fail(std::string("gemm/conv: ") + mx_last_error());
     return true;
   }
+  // row statistics (sum, sum of squares per row and slab) of the hidden states: what the folded LayerNorms read (mx_gemm_desc.ln_stats)
+  struct RowStats { float* buf = nullptr; int slabs = 0; };
+  // launch d; the statistics of its output rows go to st (from the epilogue when the chosen kernel can, else a pass over the output)
+  bool gemm_with_stats(mx_gemm_desc& d, RowStats& st) {
+    if (!ok()) return false;
+    const int slabs = mx_gemm_stats_slabs(&d);
+    if (slabs > 0) { d.stats_out = st.buf; st.slabs = slabs; return gemm(d, false); }
+    st.slabs = 1;
+    if (!gemm(d, false)) return false;
+    if (!dry && mx_row_stats(stream, d.c, d.ldc, st.buf, d.M, d.N)) return fail(std::string("row_stats: ") + mx_last_error());
+    return true;
+  }
+  void use_ln(mx_gemm_desc& d, const RowStats& st, const std::string& csname) {
+    d.ln_stats = st.buf; d.ln_slabs = st.slabs; d.ln_colsum = wf(csname, d.N); d.ln_eps = u->cfg.layer_norm_eps;
+  }
+  // ln: the A operand is the UN-normalised hidden state and the LayerNorm in front of this linear is folded into it (weights.py
+  // fold_layernorm): statistics ln, column sums `wname`-stem + ".colsum".  stats_out: also produce the statistics of the output rows.
   bool linear(const bf16_t* a, int lda, const std::string& wname, const std::string& bname, void* c, int ldc, int M, int N,
-              int K, const void* residual = nullptr, int ldr = 0, int flags = 0, float out_scale = 0.f, const bf16_t* a2 = nullptr, int lda2 = 0) {
+              int K, const void* residual = nullptr, int ldr = 0, int flags = 0, float out_scale = 0.f, const bf16_t* a2 = nullptr, int lda2 = 0,
+              const RowStats* ln = nullptr, RowStats* stats_out = nullptr) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
     d.out_scale = out_scale;
     if (a2) { d.a2 = a2; d.lda2 = lda2; d.k_split = lda; }      // A = [a | a2] along K, read in place
     d.a = a; d.lda = lda; d.w = wb(wname, (size_t)N * K); d.bias = bname.empty() ? nullptr : wf(bname, N);
     d.c = c; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.residual = residual; d.ldr = ldr; d.flags = flags;
+    if (ln) use_ln(d, *ln, wname.substr(0, wname.size() - 6) + "colsum");      // "<stem>.weight" -> "<stem>.colsum"
+    if (stats_out) return gemm_with_stats(d, *stats_out);
     return gemm(d, false);
   }
   bool conv(const bf16_t* x, int Hin, int Win, int Cin, const std::string& prefix, bf16_t* out, int Cout, int stride, int up,
@@ -218,14 +238,6 @@ struct Plan {
         fail(std::string("groupnorm: ") + mx_last_error());
     }
     ar.release(m);
-    return ok();
-  }
-  bool layernorm(const bf16_t* x, bf16_t* y, const std::string& prefix, int M, int C) {
-    if (!ok()) return false;
-    const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
-    if (ok() && !dry) {
-      if (mx_layernorm(stream, x, y, g, b, M, C, u->cfg.layer_norm_eps)) fail(std::string("layernorm: ") + mx_last_error());
-    }
     return ok();
   }
   bool attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int ldvt, long vt_bstride, bf16_t* o,
@@ -315,8 +327,12 @@ struct Plan {
     if (is_pp()) groupnorm_pp(x, n, (long)L * C, p + ".norm", h, wd, C, u->cfg.transformer_norm_eps, false, level);
     else groupnorm(x, n, p + ".norm", h, wd, C, u->cfg.transformer_norm_eps, false, level_patch(level));
     bf16_t* y = alloc<bf16_t>((size_t)M * C);
-    linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C);
-    bf16_t* ln = n;  // reuse
+    // the BasicTransformerBlock's three LayerNorms are folded into the linears they feed: every GEMM that writes the hidden state y also
+    // leaves the row statistics of what it wrote (one slab per 64 / 80 columns), and the consuming GEMM normalises in its epilogue
+    RowStats st;
+    st.buf = (float*)ar.alloc((size_t)M * MX_STATS_PITCH(C / 64) * 2 * sizeof(float));
+    if (!st.buf) fail("workspace too small");
+    linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, &st);
     const int ldvt = MX_VT_LD(L);
     bf16_t* qk = alloc<bf16_t>((size_t)M * 2 * C);
     bf16_t* vt = alloc<bf16_t>((size_t)B * C * ldvt);
@@ -334,13 +350,14 @@ struct Plan {
     if (!kvp && ok()) fail("no cross-attention K/V buffer for width " + std::to_string(C));
     for (int k = 0; k < layers && ok(); ++k) {
       const std::string b = p + ".transformer_blocks." + std::to_string(k);
-      // self-attention
-      layernorm(y, ln, b + ".norm1", M, C);
+      // self-attention (norm1 folded into the fused q / k / v projection)
       {
         mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
-        d.a = ln; d.lda = C; d.w = wb(b + ".attn1.to_qkv.weight", (size_t)3 * C * C); d.c = qk; d.ldc = 2 * C;
+        d.a = y; d.lda = C; d.w = wb(b + ".attn1.to_qkv.weight", (size_t)3 * C * C); d.bias = wf(b + ".attn1.to_qkv.bias", 3 * C);
+        d.c = qk; d.ldc = 2 * C;
         d.M = M; d.N = 3 * C; d.K = C; d.flags = MX_EPI_QKV; d.seg = C; d.period = 3; d.vt = vt; d.ldvt = ldvt;
         d.rows_per_batch = L; d.out_scale = MX_ATTN_QSCALE(0.125f);   // q segment only
+        use_ln(d, st, b + ".attn1.to_qkv.colsum");
         gemm(d, false);
       }
       if (is_pp()) {
@@ -353,20 +370,19 @@ struct Plan {
       } else {
         attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
       }
-      linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", y, C, M, C, C, y, C);
-      // cross-attention (K/V of encoder_hidden_states precomputed for all layers of this width)
-      layernorm(y, ln, b + ".norm2", M, C);
-      linear(ln, C, b + ".attn2.to_q.weight", "", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f));
+      linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, &st);
+      // cross-attention (K/V of encoder_hidden_states precomputed for all layers of this width; norm2 folded into to_q)
+      linear(y, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f), nullptr, 0, &st);
       if (ok()) {
         const int li = kvp->next++;
         attention(q2, C, kvp->k + (size_t)li * C, kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, kvp->ldvt, kvp->vt_bstride,
                   ao, C, heads, L, ctx_len);
       }
-      linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", y, C, M, C, C, y, C);
-      // GEGLU feed-forward
-      layernorm(y, ln, b + ".norm3", M, C);
-      linear(ln, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU);
-      linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C);
+      linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, &st);
+      // GEGLU feed-forward (norm3 folded into the GEGLU projection)
+      linear(y, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU, 0.f, nullptr, 0, &st);
+      if (k + 1 < layers) linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C, 0, 0.f, nullptr, 0, nullptr, &st);
+      else linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C);
     }
     linear(y, C, p + ".proj_out.weight", p + ".proj_out.bias", out, C, M, C, C, x, C);
     ar.release(m0);

@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("up", C.c_int), ("corner_patch", C.c_int),
         ("a_batch_rows", C.c_int), ("a_row_off", C.c_int), ("c_batch_rows", C.c_int), ("c_row_off", C.c_int),
         ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("vhalo", C.c_int), ("a2", C.c_void_p), ("lda2", C.c_int), ("k_split", C.c_int),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_slabs", C.c_int), ("ln_eps", C.c_float), ("stats_out", C.c_void_p),
     ]
 
 
@@ -83,6 +84,8 @@ SYMBOLS = {
     "mx_halo_only": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i]),
     "mx_gemm": (_i, [_vp, C.POINTER(GemmDesc)]),
     "mx_conv3x3": (_i, [_vp, C.POINTER(GemmDesc)]),
+    "mx_gemm_stats_slabs": (_i, [C.POINTER(GemmDesc)]),
+    "mx_row_stats": (_i, [_vp, _vp, _i, _vp, _i, _i]),
     "mx_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _f]),
     "mx_attention_prescaled": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i]),
     "mx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),

@@ -22,9 +22,13 @@ def _bf16(t):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, silu: bool = False, geglu: bool = False,
-         out_f32: bool = False, out_scale: float = 0.0) -> torch.Tensor:
+         out_f32: bool = False, out_scale: float = 0.0, ln_stats: Optional[torch.Tensor] = None, ln_colsum: Optional[torch.Tensor] = None,
+         ln_eps: float = 1e-5, want_stats: bool = False):
     """C[M,N] = (A[M,K] W[N,K]^T + bias) * out_scale (+rowbias +residual, silu | geglu).  With ``geglu`` the weight/bias rows must be
-    interleaved as weights._geglu_interleave does; the output is [M, N/2]."""
+    interleaved as weights._geglu_interleave does; the output is [M, N/2].
+    ``ln_stats`` = (stats [M, pitch, 2], slabs) + ``ln_colsum`` [N]: LayerNorm folded into this GEMM (w, bias folded by
+    weights.fold_layernorm).  ``want_stats``: also return the row statistics of C as such a pair (from the epilogue when the kernel can,
+    else mx_row_stats); entries past ``slabs`` of a row are not initialised."""
     l = _lib.load()
     _bf16(a); _bf16(w)
     m, k = a.shape
@@ -39,8 +43,37 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     d.ldr = residual.shape[1] if residual is not None else 0
     d.ldrb = rowbias.shape[1] if rowbias is not None else 0
     d.rows_per_batch, d.flags, d.out_scale = rows_per_batch, flags, out_scale
+    if ln_stats is not None:
+        st_, slabs_ = ln_stats
+        assert st_.dtype == torch.float32 and ln_colsum.dtype == torch.float32 and st_.shape == (m, stats_pitch(slabs_), 2)
+        d.ln_stats, d.ln_colsum, d.ln_slabs, d.ln_eps = st_.data_ptr(), ln_colsum.data_ptr(), slabs_, ln_eps
+    stats = None
+    if want_stats:
+        slabs = l.mx_gemm_stats_slabs(C.byref(d))
+        stats = torch.full((m, stats_pitch(max(slabs, 1)), 2), float("nan"), dtype=torch.float32, device=a.device)
+        if slabs > 0:
+            d.stats_out = stats.data_ptr()
     _lib.check(l.mx_gemm(_lib.current_stream(), C.byref(d)), "mx_gemm")
+    if want_stats:
+        if not d.stats_out:
+            _lib.check(l.mx_row_stats(_lib.current_stream(), c.data_ptr(), nout, stats.data_ptr(), m, nout), "mx_row_stats")
+        return c, (stats, max(slabs, 1))
     return c
+
+
+def stats_pitch(slabs: int) -> int:
+    """MX_STATS_PITCH: slabs per row of a statistics buffer."""
+    return (slabs + 3) & ~3
+
+
+def row_stats(x: torch.Tensor) -> torch.Tensor:
+    """(sum, sum of squares) of every row of a bf16 [M, C] matrix -> (fp32 [M, 4, 2] with slab 0 filled, 1): the one-slab ``ln_stats``."""
+    l = _lib.load()
+    _bf16(x)
+    m, c = x.shape
+    st = torch.full((m, 4, 2), float("nan"), dtype=torch.float32, device=x.device)
+    _lib.check(l.mx_row_stats(_lib.current_stream(), x.data_ptr(), c, st.data_ptr(), m, c), "mx_row_stats")
+    return st, 1
 
 
 def vt_ld(lk: int) -> int:
@@ -67,7 +100,9 @@ def unpack_vt(vt: torch.Tensor, lk: int) -> torch.Tensor:
     return vt[:, :, vt_pos(lk).to(vt.device)].permute(0, 2, 1)
 
 
-def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_batch: int, q_scale: float = 0.0):
+def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_batch: int, q_scale: float = 0.0,
+             ln_stats: Optional[torch.Tensor] = None, ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+             bias: Optional[torch.Tensor] = None):
     """Fused projection with the V segments written transposed.  Returns (c [M, N/period*(period-1)],
     vt [M/rows_per_batch, N/period, ldvt] in MX_VT_POS key order; see unpack_vt)."""
     l = _lib.load()
@@ -83,6 +118,9 @@ def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_b
     d.M, d.N, d.K, d.lda, d.ldc = m, n, k, k, c.shape[1]
     d.rows_per_batch, d.flags, d.seg, d.period, d.ldvt = rows_per_batch, _lib.EPI_QKV, seg, period, ldvt
     d.out_scale = q_scale                       # scales the q segment only (mx_attention_prescaled)
+    d.bias = _p(bias)
+    if ln_stats is not None:
+        d.ln_stats, d.ln_colsum, d.ln_slabs, d.ln_eps = ln_stats[0].data_ptr(), ln_colsum.data_ptr(), ln_stats[1], ln_eps
     _lib.check(l.mx_gemm(_lib.current_stream(), C.byref(d)), "mx_gemm(qkv)")
     return c, vt
 

@@ -11,13 +11,15 @@ packed ONCE into a single device blob in the layouts the gfx950 kernels read:
   ff.net.0.proj (GEGLU)-> rows interleaved in groups of 32 hidden | 32 gate so that the GEMM epilogue finds the
                           pair in the same lane (gemm_bf16.hip)
   time_emb_proj        -> bf16 [sum C_out, T] for all resnets in execution order (one GEMM per step)
-  biases / norm affine -> fp32
+  norm1 / norm2 / norm3 of a BasicTransformerBlock -> folded into attn1.to_qkv / attn2.to_q / ff.net.0.proj (fold_layernorm):
+                          weight * gamma (bf16), ".colsum" (fp32 row sums of the rounded product), ".bias" = bias + W beta (fp32)
+  biases / GroupNorm affine -> fp32
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -84,6 +86,39 @@ def _conv_pack(w: torch.Tensor, pad_in: int = 0) -> torch.Tensor:
     return w.reshape(o, -1).contiguous()
 
 
+def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm(x; gamma, beta) W^T + bias == rstd (x W'^T - mean colsum) + bias' with W' = W * gamma (bf16, what the matrix core reads),
+    colsum = row sums of the ROUNDED W' (fp32), bias' = bias + W beta (fp32): the operands of mx_gemm_desc.ln_stats (include/mxdenoise.h).
+    w [N, K], gamma / beta [K] -> (W' bf16 [N, K], colsum fp32 [N], bias' fp32 [N])."""
+    w32 = w.to(torch.float32)
+    wf = (w32 * gamma.to(torch.float32)[None, :]).to(torch.bfloat16)
+    colsum = wf.to(torch.float32).sum(dim=1)
+    b = w32 @ beta.to(torch.float32)
+    if bias is not None:
+        b = b + bias.to(torch.float32)
+    return wf.contiguous(), colsum.contiguous(), b.contiguous()
+
+
+def params_as_held(cfg: UNetConfig, P: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """HF-named parameters with the values the device actually multiplies by.  Folding norm1 / norm2 / norm3 rounds the PRODUCT W * gamma to
+    bf16 once -- the rounding any checkpoint weight gets -- instead of W alone, so for parameters that were bf16-exact to begin with (the
+    synthetic ones of the parity tests) the folded linears see a 2^-9 relative perturbation the un-folded path would not.  A parity test
+    of the kernels' arithmetic hands the oracle these weights (W' / gamma in fp32), the same way it hands it bf16-rounded weights."""
+    out = dict(P)
+    for p, _dim, _h, layers in transformer_names(cfg):
+        for k in range(layers):
+            b = f"{p}.transformer_blocks.{k}"
+            for names, nn in (((f"{b}.attn1.to_q.weight", f"{b}.attn1.to_k.weight", f"{b}.attn1.to_v.weight"), "norm1"),
+                              ((f"{b}.attn2.to_q.weight",), "norm2"), ((f"{b}.ff.net.0.proj.weight",), "norm3")):
+                g = P[f"{b}.{nn}.weight"].to(torch.float32)
+                safe = torch.where(g.abs() > 1e-6, g, torch.ones_like(g))
+                for n in names:
+                    w = P[n].to(torch.float32)
+                    held = (w * g[None, :]).to(torch.bfloat16).to(torch.float32) / safe[None, :]
+                    out[n] = torch.where(g.abs()[None, :] > 1e-6, held, w).to(P[n].dtype)
+    return out
+
+
 def _geglu_interleave(t: torch.Tensor) -> torch.Tensor:
     """rows [hidden(4C) ; gate(4C)] -> groups of [32 hidden | 32 gate]."""
     half = t.shape[0] // 2
@@ -130,16 +165,17 @@ def pack(cfg: UNetConfig, P: Dict[str, torch.Tensor]) -> List[Tuple[str, torch.T
             mat(f"{p}.{l}.weight", P[f"{p}.{l}.weight"].reshape(dim, dim)); vec(f"{p}.{l}.bias", P[f"{p}.{l}.bias"])
         for k in range(layers):
             b = f"{p}.transformer_blocks.{k}"
-            for nn in ("norm1", "norm2", "norm3"):
-                vec(f"{b}.{nn}.weight", P[f"{b}.{nn}.weight"]); vec(f"{b}.{nn}.bias", P[f"{b}.{nn}.bias"])
-            mat(f"{b}.attn1.to_qkv.weight", torch.cat([P[f"{b}.attn1.to_q.weight"], P[f"{b}.attn1.to_k.weight"],
-                                                       P[f"{b}.attn1.to_v.weight"]], dim=0))
+            # norm1 / norm2 / norm3 are folded into the one linear each of them feeds (fold_layernorm)
+            def folded(name, w, bias, nn):
+                wf, cs, bf_ = fold_layernorm(w, bias, P[f"{b}.{nn}.weight"], P[f"{b}.{nn}.bias"])
+                mat(f"{name}.weight", wf); vec(f"{name}.colsum", cs); vec(f"{name}.bias", bf_)
+            folded(f"{b}.attn1.to_qkv", torch.cat([P[f"{b}.attn1.to_q.weight"], P[f"{b}.attn1.to_k.weight"], P[f"{b}.attn1.to_v.weight"]], dim=0),
+                   None, "norm1")
             mat(f"{b}.attn1.to_out.0.weight", P[f"{b}.attn1.to_out.0.weight"]); vec(f"{b}.attn1.to_out.0.bias", P[f"{b}.attn1.to_out.0.bias"])
-            mat(f"{b}.attn2.to_q.weight", P[f"{b}.attn2.to_q.weight"])
+            folded(f"{b}.attn2.to_q", P[f"{b}.attn2.to_q.weight"], None, "norm2")
             kv_by_dim.setdefault(dim, []).append(torch.cat([P[f"{b}.attn2.to_k.weight"], P[f"{b}.attn2.to_v.weight"]], dim=0))
             mat(f"{b}.attn2.to_out.0.weight", P[f"{b}.attn2.to_out.0.weight"]); vec(f"{b}.attn2.to_out.0.bias", P[f"{b}.attn2.to_out.0.bias"])
-            mat(f"{b}.ff.net.0.proj.weight", _geglu_interleave(P[f"{b}.ff.net.0.proj.weight"]))
-            vec(f"{b}.ff.net.0.proj.bias", _geglu_interleave(P[f"{b}.ff.net.0.proj.bias"]))
+            folded(f"{b}.ff.net.0.proj", _geglu_interleave(P[f"{b}.ff.net.0.proj.weight"]), _geglu_interleave(P[f"{b}.ff.net.0.proj.bias"]), "norm3")
             mat(f"{b}.ff.net.2.weight", P[f"{b}.ff.net.2.weight"]); vec(f"{b}.ff.net.2.bias", P[f"{b}.ff.net.2.bias"])
     for dim, lst in kv_by_dim.items():
         mat(f"attn2_kv_all.{dim}.weight", torch.cat(lst, dim=0))

@@ -1,0 +1,117 @@
+"""LayerNorm folded into its consumer GEMM (mx_gemm_desc.ln_stats / stats_out; include/mxdenoise.h), every kernel family, against
+LayerNorm -> linear in fp32 (the reference's BasicTransformerBlock norm1 / norm2 / norm3 -> attn / ff linears, modules/transformer.py:191,
+239, 266).  Inputs with a row mean well away from zero (the cancellation the rank-one correction has to survive) and per-row scales."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rt(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _close(got, want, rel, what):
+    got = got.float().cpu()
+    assert torch.isfinite(got).all(), f"{what}: non-finite"
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    print(f"{what}: max err {err:.5f} of range {scale:.3f}")
+    assert err <= rel * scale, f"{what}: max err {err:.5f} > {rel} * {scale:.4f}"
+
+
+def _hidden(g, m, c):
+    """hidden states with row means up to 3 sigma away from zero and row scales over two octaves"""
+    x = torch.randn(m, c, generator=g) * (0.5 + 1.5 * torch.rand(m, 1, generator=g)) + 3.0 * torch.randn(m, 1, generator=g)
+    return _rt(x)
+
+
+def _ln_params(g, c):
+    return 1.0 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+
+
+@pytest.mark.parametrize("m,c,n", [(100, 128, 192),        # generic kernel
+                                   (600, 640, 640),        # 256 x 160
+                                   (256, 1280, 1280),      # 128-row tiles
+                                   (4096, 1280, 1280),     # 256 x 160 at a step shape's width
+                                   (2048, 640, 1024)])     # 256 x 256 persistent kernel
+def test_ln_folded_linear(cuda_device, m, c, n):
+    from sduss_amd import ops
+    from sduss_amd.weights import fold_layernorm
+    g = torch.Generator().manual_seed(m + c + n)
+    x = _hidden(g, m, c)
+    gamma, beta = _ln_params(g, c)
+    w = _rt(torch.randn(n, c, generator=g) * c ** -0.5); bias = 0.1 * torch.randn(n, generator=g)
+    want = F.layer_norm(x, (c,), gamma, beta, 1e-5) @ w.t() + bias
+    wf, colsum, bf_ = fold_layernorm(w, bias, gamma, beta)
+    st = ops.row_stats(_bf(x).cuda())
+    got = ops.gemm(_bf(x).cuda(), wf.cuda(), bf_.cuda(), ln_stats=st, ln_colsum=colsum.cuda(), ln_eps=1e-5)
+    _close(got, want, 2.0 ** -7, f"ln-folded linear {m}x{c}->{n}")
+
+
+@pytest.mark.parametrize("m,dim", [(192, 64), (600, 128), (2048, 640)])
+def test_ln_folded_geglu(cuda_device, m, dim):
+    from sduss_amd import ops
+    from sduss_amd.weights import _geglu_interleave, fold_layernorm
+    g = torch.Generator().manual_seed(5 + m)
+    x = _hidden(g, m, dim)
+    gamma, beta = _ln_params(g, dim)
+    w = _rt(torch.randn(8 * dim, dim, generator=g) * dim ** -0.5); b = torch.randn(8 * dim, generator=g)
+    hid, gate = (F.layer_norm(x, (dim,), gamma, beta, 1e-5) @ w.t() + b).chunk(2, dim=-1)
+    want = hid * F.gelu(gate)
+    wf, colsum, bf_ = fold_layernorm(_geglu_interleave(w), _geglu_interleave(b), gamma, beta)
+    st = ops.row_stats(_bf(x).cuda())
+    got = ops.gemm(_bf(x).cuda(), wf.cuda(), bf_.cuda(), geglu=True, ln_stats=st, ln_colsum=colsum.cuda())
+    _close(got, want, 2.0 ** -7, f"ln-folded geglu {m}x{dim}")
+
+
+@pytest.mark.parametrize("rows,dim", [(256, 64), (512, 640), (1024, 1280)])
+def test_ln_folded_qkv(cuda_device, rows, dim):
+    """norm1 folded into the fused q / k / v projection: q scaled, k plain, V^T transposed -- all from the un-normalised hidden state"""
+    from sduss_amd import ops
+    from sduss_amd.weights import fold_layernorm
+    g = torch.Generator().manual_seed(rows + dim)
+    b = 2
+    x = _hidden(g, b * rows, dim)
+    gamma, beta = _ln_params(g, dim)
+    w = _rt(torch.randn(3 * dim, dim, generator=g) * dim ** -0.5)
+    y = F.layer_norm(x, (dim,), gamma, beta, 1e-5) @ w.t()
+    wf, colsum, bf_ = fold_layernorm(w, None, gamma, beta)
+    st = ops.row_stats(_bf(x).cuda())
+    c, vt = ops.gemm_qkv(_bf(x).cuda(), wf.cuda(), dim, 3, rows, q_scale=0.25, ln_stats=st, ln_colsum=colsum.cuda(), bias=bf_.cuda())
+    _close(c[:, :dim], y[:, :dim] * 0.25, 2.0 ** -7, "ln-folded q")
+    _close(c[:, dim:], y[:, dim:2 * dim], 2.0 ** -7, "ln-folded k")
+    _close(ops.unpack_vt(vt, rows).reshape(b * rows, dim), y[:, 2 * dim:], 2.0 ** -7, "ln-folded v^T")
+
+
+@pytest.mark.parametrize("m,k,n", [(600, 640, 640), (256, 1280, 1280), (8192, 1280, 1280), (100, 128, 192), (2048, 5120, 1280), (333, 640, 1280)])
+def test_row_stats_from_the_producing_epilogue(cuda_device, m, k, n):
+    """stats_out: the (sum, sum of squares) slabs a producing GEMM (to_out / ff.net.2 with the residual) leaves equal those of the rows it
+    stored, and feed a folded consumer to the same result as LayerNorm -> linear on the stored rows"""
+    from sduss_amd import ops
+    from sduss_amd.weights import fold_layernorm
+    g = torch.Generator().manual_seed(m + k)
+    a = _rt(torch.randn(m, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5); bias = torch.randn(n, generator=g)
+    res = _hidden(g, m, n)
+    y, st = ops.gemm(_bf(a).cuda(), _bf(w).cuda(), bias.cuda(), residual=_bf(res).cuda(), want_stats=True)
+    yf = y.float().cpu()
+    buf, slabs = st
+    s = buf.cpu()[:, :slabs].sum(dim=1)          # entries past the last slab are not initialised (NaN-filled by ops.gemm)
+    print(f"stats slabs {slabs} for {m}x{k}->{n}")
+    ref1, ref2 = yf.sum(dim=1), (yf * yf).sum(dim=1)
+    # the epilogue sums the fp32 values before their rounding to bf16: agreement to the rounding noise of a row
+    assert (s[:, 0] - ref1).abs().max().item() <= 2.0 ** -8 * yf.abs().sum(dim=1).max().item()
+    assert ((s[:, 1] - ref2).abs() / ref2).max().item() <= 2.0 ** -7
+    gamma, beta = _ln_params(g, n)
+    w2 = _rt(torch.randn(256, n, generator=g) * n ** -0.5)
+    wf, colsum, bf_ = fold_layernorm(w2, None, gamma, beta)
+    got = ops.gemm(y, wf.cuda(), bf_.cuda(), ln_stats=st, ln_colsum=colsum.cuda())
+    want = F.layer_norm(yf, (n,), gamma, beta, 1e-5) @ w2.t()
+    _close(got, want, 2.0 ** -7, f"producer stats -> folded consumer {m}x{k}->{n}")
