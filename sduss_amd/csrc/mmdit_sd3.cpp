@@ -142,8 +142,10 @@ struct Plan {
     const int h = H / ps, wd = W / ps;
     const int L = h * wd;
     const int Lj = L + Lt;
-    const int ldvt_j = MX_VT_LD(Lj);
-    const int ldvt_i = MX_VT_LD(L);
+    // V^T rows padded to whole 128-byte lines: with the minimal MX_VT_LD(4429) = 4432 every 64-key tile row straddles two lines and the
+    // joint attention ran at 850 TFLOP/s against 1000 at an aligned length (tools/exp/attn_shapes_probe.py)
+    const int ldvt_j = (MX_VT_LD(Lj) + 63) / 64 * 64;
+    const int ldvt_i = (MX_VT_LD(L) + 63) / 64 * 64;
     const int Kp = ps * ps * c.in_channels;
     const int MI = B * L, MT = B * Lt;
 
