@@ -152,6 +152,11 @@ typedef struct mx_gemm_desc {
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
 int mx_gemm_stats_slabs(const mx_gemm_desc* d);        /* slabs d->stats_out receives from mx_gemm(d); 0 = not supported for this shape */
+/* 1 when mx_gemm(d) with ln_stats would run on the persistent 256 x 256 kernel, where applying the statistics costs more than a separate
+ * normalisation pass saves (10-20 us per launch in the hand-over between two tiles against an 11-us pass at M = 8192); the step plan then
+ * normalises with mx_layernorm(gamma = NULL) and launches d without ln_stats.  The 256 / 128-row kernels hide the statistics behind their
+ * first operand fetch: 0. */
+int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d);
 #define MX_STATS_PITCH(slabs) (((slabs) + 3) & ~3)     /* slabs per row of a statistics buffer: [M][pitch][2] floats */
 /* stats[m * 4 * 2 + {0, 1}] = (sum_c x[m][c], sum_c x[m][c]^2), x bf16 [M, C] with row stride ldx: the one-slab input of ln_stats
  * (buffer of M * MX_STATS_PITCH(1) * 2 floats) */
@@ -180,7 +185,8 @@ int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, c
 int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk);
 
-/* y = LayerNorm(x) * gamma + beta over the last dim C; x,y bf16 [M, C]; gamma/beta fp32 [C] */
+/* y = LayerNorm(x) * gamma + beta over the last dim C; x,y bf16 [M, C]; gamma/beta fp32 [C], or both NULL: plain (x - mean) * rstd, the
+ * input of a linear whose weights carry the affine (weights folded for mx_gemm_desc.ln_stats work unchanged on it, without ln_stats) */
 int mx_layernorm(void* stream, const void* x, void* y, const float* gamma, const float* beta,
                  int M, int C, float eps);
 

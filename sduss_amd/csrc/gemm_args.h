@@ -556,7 +556,8 @@ __device__ __forceinline__ u32x4 lane_xor1(const u32x4 x) {
 }
 
 // VPF: per-sample vectors are loaded one token block ahead (costs 8 * NIO registers; off in the persistent 256 x 256 kernel)
-// STATS: can write row statistics (stats_out); off in the 256 x 256 kernels, whose register budget is spent
+// STATS: can write row statistics (stats_out) and apply the folded LayerNorm's rstd (ln_rstd_a); off in the 256 x 256 kernels, whose
+// register budget is spent (pick_tile keeps launches with ln_stats / stats_out away from them)
 template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true>
 __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
                                                    const int fr, const int fq, const float (&ln_rstd_a)[MI]) {
@@ -669,7 +670,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
     float v[NIO][4];
     float rms_mul = 1.0f;
     if constexpr (!VPF) { if (has_rb || has_gate) load_batch_vectors(j); }
-    const float ln_rstd = ln_rstd_a[j];
+    const float ln_rstd = STATS ? ln_rstd_a[j] : 1.0f;
     float st1 = 0.f, st2 = 0.f;                // stats_out: this lane's part of the token's sums
     if (rms) {                                 // every lane takes part in the shuffles (masking happens at the store)
       float ss = 0.f;
@@ -683,9 +684,9 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
     }
 #pragma unroll
     for (int i = 0; i < NIO; ++i) {
-      f32x4 t = acc[i][j] * ln_rstd + bias_r[i];
+      f32x4 t = STATS ? acc[i][j] * ln_rstd + bias_r[i] : acc[i][j] + bias_r[i];
       if constexpr (GEGLU) {
-        const f32x4 g = acc[i + NI / 2][j] * ln_rstd + bias_r[i + NI / 2];
+        const f32x4 g = STATS ? acc[i + NI / 2][j] * ln_rstd + bias_r[i + NI / 2] : acc[i + NI / 2][j] + bias_r[i + NI / 2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) t[q] = t[q] * gelu_fast(g[q]);
       } else {

@@ -212,7 +212,7 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   for (int c = 0; c < 5; ++c) {
     const int bn = cands[c].bn, rows = cands[c].rows;
     if (d->N % bn != 0 || d->M < rows) continue;
-    if (bn == 256 && (conv || v3_disabled || !fits32 || d->a2)) continue;
+    if (bn == 256 && (conv || v3_disabled || !fits32 || d->a2 || d->ln_stats || d->stats_out)) continue;   // (built without those hooks)
     if (rows == 128 && small_disabled) continue;
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;
@@ -228,7 +228,8 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
 // slabs of row statistics the launch of d writes: one per wave column panel of the register-exchange epilogue (gemm_epilogue_regs);
 // 0 when the generic kernel serves d or the epilogue is not a plain bf16 store
 static int stats_slabs_of(const mx_gemm_desc* d, bool conv, const TileChoice& tc) {
-  if (conv || tc.bn == 0 || tc.bn == 256) return 0;     // (the 256 x 256 kernels are built without it)
+  if (conv || tc.bn == 0 || tc.bn == 256) return 0;     // (the 256 x 256 kernels are built without it: asking for stats_out moves the launch
+                                                        //  to a 256 / 128-row tile, see pick_tile)
   if (d->flags & (MX_EPI_GEGLU | MX_EPI_QKV | MX_EPI_OUT_F32)) return 0;
   if (d->a_batch_rows > 0 || d->c_batch_rows > 0) return 0;
   const int panel = tc.bn / 2;                          // 4 x 2 waves of (16 MI) x (BN / 2)
@@ -356,6 +357,14 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
 extern "C" int mx_gemm(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, false); }
 extern "C" int mx_gemm_stats_slabs(const mx_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
-  return mx::stats_slabs_of(d, false, mx::pick_tile(d, false));
+  mx_gemm_desc q = *d;
+  if (!q.stats_out) q.stats_out = reinterpret_cast<float*>(16);      // the tile choice of the launch that asks for statistics
+  return mx::stats_slabs_of(&q, false, mx::pick_tile(&q, false));
+}
+extern "C" int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  mx_gemm_desc plain = *d;
+  plain.ln_stats = nullptr; plain.stats_out = nullptr;
+  return mx::pick_tile(&plain, false).bn == 256;
 }
 extern "C" int mx_conv3x3(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, true); }

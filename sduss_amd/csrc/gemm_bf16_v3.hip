@@ -184,14 +184,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v3_kernel(const GemmArgs p) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ln_rstd[MI];                         // folded LayerNorm (gemm_ln_init)
-#pragma unroll
-    for (int j = 0; j < MI; ++j) ln_rstd[j] = 1.0f;
-    if (p.ln_stats != nullptr) {
-      int tm_, tn_;
-      gemm_tile_of_block(tile, mt, nt, p.xcd_map, tm_, tn_);
-      gemm_ln_init<NI, MI>(p, acc, tm_ * BM3 + wm * 16 * MI, tn_ * BN3 + wn * 16 * NI, fr, fq, ln_rstd);
-    }
+    const float ln_rstd[MI] = {};              // (no folded LayerNorm in this kernel: pick_tile, gemm_bf16.hip)
 
     for (int kt = 0; kt < nk; ++kt) {
       // all but the youngest group (the X half-tile of the next stream position) has landed => X and W of this position are in

@@ -221,14 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ln_rstd[MI];                         // folded LayerNorm (gemm_ln_init): fetched in the hand-over between two tiles
-#pragma unroll
-    for (int j = 0; j < MI; ++j) ln_rstd[j] = 1.0f;
-    if (p.ln_stats != nullptr) {
-      int tm_, tn_;
-      gemm_tile_of_block(tile, mt, nt, p.xcd_map, tm_, tn_);
-      gemm_ln_init<NI, MI>(p, acc, tm_ * BM4 + wm * 16 * MI, tn_ * BN4 + wn * 16 * NI, fr, fq, ln_rstd);
-    }
+    const float ln_rstd[MI] = {};              // (no folded LayerNorm in this kernel: pick_tile, gemm_bf16.hip)
 
     if (wm == 1) MX_BAR();                     // wave row 1 runs one barrier behind row 0
 

@@ -362,10 +362,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   for (int i = 0; i < VPL; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
+      const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};     // gamma == nullptr: plain normalisation (affine folded elsewhere)
+      const f32x4 g0 = gamma ? *reinterpret_cast<const f32x4*>(gamma + ch * 8) : one4;
+      const f32x4 g1 = gamma ? *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4) : one4;
+      const f32x4 b0 = gamma ? *reinterpret_cast<const f32x4*>(beta + ch * 8) : zero4;
+      const f32x4 b1 = gamma ? *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4) : zero4;
       float o[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 extern "C" int mx_layernorm(void* stream, const void* x, void* y, const float* gamma, const float* beta,
                             int M, int C, float eps) {
   using namespace mx;
-  MX_CHECK(x && y && gamma && beta, "layernorm: null operand");
+  MX_CHECK(x && y && ((gamma == nullptr) == (beta == nullptr)), "layernorm: null operand (gamma and beta are given together or not at all)");
   MX_CHECK(C % 8 == 0 && C <= 64 * 8 * 8, "layernorm: C must be a multiple of 8 and <= 4096");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(M, 4)), block(256);

@@ -327,18 +327,44 @@ struct Plan {
     if (is_pp()) groupnorm_pp(x, n, (long)L * C, p + ".norm", h, wd, C, u->cfg.transformer_norm_eps, false, level);
     else groupnorm(x, n, p + ".norm", h, wd, C, u->cfg.transformer_norm_eps, false, level_patch(level));
     bf16_t* y = alloc<bf16_t>((size_t)M * C);
-    // the BasicTransformerBlock's three LayerNorms are folded into the linears they feed: every GEMM that writes the hidden state y also
-    // leaves the row statistics of what it wrote (one slab per 64 / 80 columns), and the consuming GEMM normalises in its epilogue
+    // The BasicTransformerBlock's three LayerNorms are folded into the linears they feed (weights.py fold_layernorm).  Where the consuming
+    // GEMM hides the statistics behind its first operand fetch (the 256 / 128-row kernels) the GEMM that wrote the hidden state y also left
+    // the row statistics and no normalisation pass runs; where it would run on the persistent 256 x 256 kernel (mx_gemm_ln_prefers_pass)
+    // a plain (x - mean) * rstd pass feeds the same folded weights.
     RowStats st;
     st.buf = (float*)ar.alloc((size_t)M * MX_STATS_PITCH(C / 64) * 2 * sizeof(float));
     if (!st.buf) fail("workspace too small");
-    linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, &st);
+    bf16_t* ln = n;  // the GroupNorm output is dead after proj_in
     const int ldvt = MX_VT_LD(L);
     bf16_t* qk = alloc<bf16_t>((size_t)M * 2 * C);
     bf16_t* vt = alloc<bf16_t>((size_t)B * C * ldvt);
     bf16_t* ao = alloc<bf16_t>((size_t)M * C);
     bf16_t* q2 = alloc<bf16_t>((size_t)M * C);
     bf16_t* ff = alloc<bf16_t>((size_t)M * 4 * C);
+    auto qkv_desc = [&](const std::string& b, const bf16_t* a) {
+      mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+      d.a = a; d.lda = C; d.w = wb(b + ".attn1.to_qkv.weight", (size_t)3 * C * C); d.bias = wf(b + ".attn1.to_qkv.bias", 3 * C);
+      d.c = qk; d.ldc = 2 * C;
+      d.M = M; d.N = 3 * C; d.K = C; d.flags = MX_EPI_QKV; d.seg = C; d.period = 3; d.vt = vt; d.ldvt = ldvt;
+      d.rows_per_batch = L; d.out_scale = MX_ATTN_QSCALE(0.125f);   // q segment only
+      return d;
+    };
+    auto lin_desc = [&](const bf16_t* a, void* c, int ldc, int N, int flags, float out_scale) {
+      mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+      d.a = a; d.lda = C; d.w = a; d.c = c; d.ldc = ldc; d.M = M; d.N = N; d.K = C; d.flags = flags; d.out_scale = out_scale;
+      return d;
+    };
+    bool pass1, pass2, pass3;     // LayerNorm as a pass (true) or through the statistics (false), per consumer shape
+    {
+      mx_gemm_desc d1 = qkv_desc(p + ".transformer_blocks.0", y);
+      mx_gemm_desc d2 = lin_desc(y, q2, C, C, 0, MX_ATTN_QSCALE(0.125f));
+      mx_gemm_desc d3 = lin_desc(y, ff, 4 * C, 8 * C, MX_EPI_GEGLU, 0.f);
+      pass1 = mx_gemm_ln_prefers_pass(&d1) != 0; pass2 = mx_gemm_ln_prefers_pass(&d2) != 0; pass3 = mx_gemm_ln_prefers_pass(&d3) != 0;
+    }
+    auto normalise = [&]() {      // ln = (y - mean) * rstd, no affine (it lives in the folded weights)
+      if (ok() && !dry && mx_layernorm(stream, y, ln, nullptr, nullptr, M, C, u->cfg.layer_norm_eps)) fail(std::string("layernorm: ") + mx_last_error());
+    };
+    linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, pass1 ? nullptr : &st);
     // patch-parallel: every rank gathers the other ranks' K rows and V^T columns (modules/pp/attn.py:137: all_gather(kv))
     bf16_t* qk_all = nullptr; bf16_t* vt_all = nullptr;
     if (is_pp()) {
@@ -350,14 +376,11 @@ struct Plan {
     if (!kvp && ok()) fail("no cross-attention K/V buffer for width " + std::to_string(C));
     for (int k = 0; k < layers && ok(); ++k) {
       const std::string b = p + ".transformer_blocks." + std::to_string(k);
-      // self-attention (norm1 folded into the fused q / k / v projection)
+      // self-attention (norm1 in the fused q / k / v projection)
       {
-        mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
-        d.a = y; d.lda = C; d.w = wb(b + ".attn1.to_qkv.weight", (size_t)3 * C * C); d.bias = wf(b + ".attn1.to_qkv.bias", 3 * C);
-        d.c = qk; d.ldc = 2 * C;
-        d.M = M; d.N = 3 * C; d.K = C; d.flags = MX_EPI_QKV; d.seg = C; d.period = 3; d.vt = vt; d.ldvt = ldvt;
-        d.rows_per_batch = L; d.out_scale = MX_ATTN_QSCALE(0.125f);   // q segment only
-        use_ln(d, st, b + ".attn1.to_qkv.colsum");
+        if (pass1) normalise();
+        mx_gemm_desc d = qkv_desc(b, pass1 ? ln : y);
+        if (!pass1) use_ln(d, st, b + ".attn1.to_qkv.colsum"); else wf(b + ".attn1.to_qkv.colsum", 3 * C);
         gemm(d, false);
       }
       if (is_pp()) {
@@ -370,19 +393,23 @@ struct Plan {
       } else {
         attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
       }
-      linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, &st);
-      // cross-attention (K/V of encoder_hidden_states precomputed for all layers of this width; norm2 folded into to_q)
-      linear(y, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f), nullptr, 0, &st);
+      linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, pass2 ? nullptr : &st);
+      // cross-attention (K/V of encoder_hidden_states precomputed for all layers of this width; norm2 in to_q)
+      if (pass2) normalise();
+      linear(pass2 ? ln : y, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f), nullptr, 0,
+             pass2 ? nullptr : &st);
       if (ok()) {
         const int li = kvp->next++;
         attention(q2, C, kvp->k + (size_t)li * C, kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, kvp->ldvt, kvp->vt_bstride,
                   ao, C, heads, L, ctx_len);
       }
-      linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, &st);
-      // GEGLU feed-forward (norm3 folded into the GEGLU projection)
-      linear(y, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU, 0.f, nullptr, 0, &st);
-      if (k + 1 < layers) linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C, 0, 0.f, nullptr, 0, nullptr, &st);
-      else linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C);
+      linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, pass3 ? nullptr : &st);
+      // GEGLU feed-forward (norm3 in the GEGLU projection)
+      if (pass3) normalise();
+      linear(pass3 ? ln : y, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU, 0.f, nullptr, 0,
+             pass3 ? nullptr : &st);
+      linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C, 0, 0.f, nullptr, 0, nullptr,
+             (k + 1 < layers && !pass1) ? &st : nullptr);
     }
     linear(y, C, p + ".proj_out.weight", p + ".proj_out.bias", out, C, M, C, C, x, C);
     ar.release(m0);

@@ -85,6 +85,7 @@ SYMBOLS = {
     "mx_gemm": (_i, [_vp, C.POINTER(GemmDesc)]),
     "mx_conv3x3": (_i, [_vp, C.POINTER(GemmDesc)]),
     "mx_gemm_stats_slabs": (_i, [C.POINTER(GemmDesc)]),
+    "mx_gemm_ln_prefers_pass": (_i, [C.POINTER(GemmDesc)]),
     "mx_row_stats": (_i, [_vp, _vp, _i, _vp, _i, _i]),
     "mx_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _f]),
     "mx_attention_prescaled": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i]),
