@@ -84,7 +84,9 @@ enum {
                                 is written transposed into vt[b][vcol][key]; others row-major, compacted */
   MX_EPI_GELU_TANH = 1 << 4, /* out = gelu(v), tanh approximation (diffusers FeedForward "gelu-approximate") */
   MX_EPI_RES_BCAST = 1 << 5, /* residual row = output row modulo rows_per_batch (positional table broadcast over the batch) */
-  MX_EPI_RMSNORM  = 1 << 6   /* with MX_EPI_QKV: RMS-normalise every 64-wide head of the q and k segments (see rms_wq below) */
+  MX_EPI_RMSNORM  = 1 << 6,  /* with MX_EPI_QKV: RMS-normalise every 64-wide head of the q and k segments (see rms_wq below) */
+  MX_EPI_GELU     = 1 << 7,  /* out = gelu(v), exact (erf) form: the OpenCLIP text encoder's MLP */
+  MX_EPI_QUICK_GELU = 1 << 8 /* out = v * sigmoid(1.702 v): the CLIP ViT-L text encoder's MLP */
 };
 
 typedef struct mx_gemm_desc {
@@ -184,6 +186,9 @@ int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, c
 #define MX_ATTN_QSCALE(scale) ((scale) * 1.4426950408889634f)
 int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk);
+/* the same with the causal mask (key j counts for query i only when j <= i), Lq == Lk == L: the CLIP text encoders */
+int mx_attention_prescaled_causal(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                  int64_t vt_batch_stride, void* o, int ldo, int B, int H, int L);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim C; x,y bf16 [M, C]; gamma/beta fp32 [C], or both NULL: plain (x - mean) * rstd, the
  * input of a linear whose weights carry the affine (weights folded for mx_gemm_desc.ln_stats work unchanged on it, without ln_stats) */
@@ -353,6 +358,33 @@ size_t mx_vae_workspace_bytes(const mx_vae* v, int batch, int H, int W);
 int mx_vae_validate(const mx_vae* v, int batch, int H, int W);
 int mx_vae_decode(mx_vae* v, void* stream, const void* latents, int io_dtype, void* out, int out_dtype, int batch, int H, int W,
                   void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * CLIP text encoder (csrc/clip_text.cpp): what diffusers' encode_prompt runs per prompt before the denoising loop
+ * (prepare_inference, pipeline_stable_diffusion_xl_esymred.py:118-140): transformers CLIPTextModel (SDXL text_encoder: ViT-L, quick_gelu,
+ * no projection) and CLIPTextModelWithProjection (text_encoder_2: OpenCLIP bigG, gelu, text_projection).  Packed weights keep the
+ * transformers names except q_proj / k_proj / v_proj, fused into "<layer>.self_attn.qkv_proj.{weight [3H, H], bias [3H]}".
+ *   ids: int32 [batch, max_position_embeddings] token ids (the tokenizer stays on the host);
+ *   hidden_out: bf16 [batch, L, H] = transformers' hidden_states[hidden_layer] (-2 for SDXL: the output of the last-but-one layer; -1 =
+ *               the last layer's output, before final_layer_norm), or NULL;
+ *   pooled_out: fp32 [batch, projection_dim] = text_projection(final_layer_norm(last)[eos position]), or NULL.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mx_clip_config {
+  int vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, max_position_embeddings;
+  int hidden_act;                 /* 0 = quick_gelu, 1 = gelu (erf) */
+  int projection_dim;             /* 0: no text_projection */
+  int eos_token_id;               /* 2 = the legacy configs: pooled row = position of the largest id */
+  int hidden_layer;               /* which hidden state hidden_out receives, a negative index as in Python: -2 (SDXL, clip_skip None), -1 ... */
+  float layer_norm_eps;
+} mx_clip_config;
+typedef struct mx_clip mx_clip;
+mx_clip* mx_clip_create(const mx_clip_config* cfg);
+void mx_clip_destroy(mx_clip* c);
+int mx_clip_set_weights(mx_clip* c, const void* blob, uint64_t blob_bytes, const mx_weight_entry* table, int n_entries);
+size_t mx_clip_workspace_bytes(const mx_clip* c, int batch);
+int mx_clip_validate(const mx_clip* c, int batch);
+int mx_clip_encode(mx_clip* c, void* stream, const int32_t* ids, void* hidden_out, void* pooled_out, int batch, void* workspace,
+                   size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * The element-wise steps either side of the model call.

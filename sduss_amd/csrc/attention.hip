@@ -50,6 +50,7 @@ struct AttnArgs {
   // chunk c of batch b starts at k + c * k_cstride + b * k_bstride (rows of ldk) and vt + c * vt_cstride + b * vt_bstride
   int key_chunk;     // 0: one contiguous key range per batch
   long k_bstride, k_cstride, vt_cstride;
+  int causal;        // 1: key j counts for query i only when j <= i (text encoders; attn_fwd_kernel only)
 };
 
 constexpr int KT = 64;                 // keys per tile
@@ -237,6 +238,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
         for (int e = 0; e < 16; ++e) {
           const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
           if (key >= p.Lk) s[kb][e] = -INFINITY;
+        }
+    }
+    if (p.causal) {                     // keys after the query never count (every tile: short sequences only)
+      const int qi = q0 + r;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (key > qi) s[kb][e] = -INFINITY;
         }
     }
     // ---- online softmax (log2 domain) ----
@@ -1092,7 +1103,7 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnArgs p) {
 
 static int launch_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                             int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale, bool pre,
-                            int key_chunk = 0, int64_t k_bstride = 0, int64_t k_cstride = 0, int64_t vt_cstride = 0) {
+                            int key_chunk = 0, int64_t k_bstride = 0, int64_t k_cstride = 0, int64_t vt_cstride = 0, bool causal = false) {
   using namespace mx;
   MX_CHECK(q && k && vt && o, "attention: null operand");
   MX_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
@@ -1111,11 +1122,13 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
   a.vt_bstride = (long)vt_batch_stride;
   a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale_log2 = scale * 1.4426950408889634f;
+  a.causal = causal ? 1 : 0;
+  if (causal) MX_CHECK(Lq == Lk && key_chunk == 0 && Lk <= 4096, "attention: causal form is for Lq == Lk <= 4096, one key range");
   a.key_chunk = key_chunk; a.k_bstride = key_chunk > 0 ? (long)k_bstride : (long)Lk * ldk; a.k_cstride = (long)k_cstride; a.vt_cstride = (long)vt_cstride;
   static const int xcd_env = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
   a.xcd_map = (xcd_env && ((B * H) % 8 == 0)) ? 1 : 0;
   static const bool cross_off = [] { const char* e = getenv("MX_ATTN_CROSS"); return e && e[0] == '0'; }();
-  if (Lk <= 32 * XK_MAXBLK && Lq >= 2048 && !cross_off && key_chunk == 0) {   // (at Lq 1024 the general kernel is 7 % faster: both are latency-bound)    // short key sequence: every wave keeps K / V^T in registers (attn_cross_kernel)
+  if (Lk <= 32 * XK_MAXBLK && Lq >= 2048 && !cross_off && key_chunk == 0 && !causal) {   // (at Lq 1024 the general kernel is 7 % faster: both are latency-bound)    // short key sequence: every wave keeps K / V^T in registers (attn_cross_kernel)
     MX_CHECK(ldo % 8 == 0, "attention: ldo must be a multiple of 8 elements");
     dim3 xgrid(cdiv(Lq, 4 * XK_QPW), H, B);
     prof_begin((hipStream_t)stream, PROF_ATTN_CROSS, 4.0 * B * H * (double)Lq * Lk * 64.0, 2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
@@ -1130,7 +1143,10 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
              2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
   static const bool dma_off = [] { const char* e = getenv("MX_ATTN_DMA"); return e && e[0] == '0'; }();
   static const int w64_min = [] { const char* e = getenv("MX_ATTN_W64_MIN_LQ"); return e ? atoi(e) : 2048; }();   // (a tie with the 32-row kernels at Lq 1024)
-  if (pre && Lk > 2 * KT && !dma_off && Lq >= w64_min && ldo % 8 == 0) {   // 64 query rows per wave
+  if (causal) {                                        // the masked form lives in the register-staged kernel
+    if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (pre && Lk > 2 * KT && !dma_off && Lq >= w64_min && ldo % 8 == 0) {   // 64 query rows per wave
     dim3 grid64(cdiv(Lq, 256), H, B);
     hipLaunchKernelGGL(attn_fwd64_kernel, grid64, dim3(256), 0, (hipStream_t)stream, a);
   } else if (Lk % KT == 0 && Lk >= 3 * KT && !dma_off) {      // whole tiles: LDS-DMA staging two tiles ahead
@@ -1151,6 +1167,12 @@ extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k,
 extern "C" int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                                       int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk) {
   return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, 1.0f, true);
+}
+
+/* causal self-attention of a short sequence (the CLIP text encoders: 77 tokens), q prescaled as for mx_attention_prescaled */
+extern "C" int mx_attention_prescaled_causal(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                             int64_t vt_batch_stride, void* o, int ldo, int B, int H, int L) {
+  return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, L, L, 1.0f, true, 0, 0, 0, 0, true);
 }
 
 /* patch-parallel form (mx_unet_forward_pp): K rows and V^T columns of the `world` ranks arrive rank-major from the all-gather.

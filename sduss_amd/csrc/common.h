@@ -50,6 +50,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   return x / (1.0f + __expf(-2.0f * u));
 }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

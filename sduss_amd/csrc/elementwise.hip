@@ -397,3 +397,61 @@ int launch_softmax_rows(hipStream_t s, void* scores, long rows, int L, long ld) 
   return 0;
 }
 }  // namespace mx
+
+// ----------------------------------------------------------------------------------------------------------------------
+// CLIP text encoder glue (clip_text.cpp): token + position embedding lookup, and the pooled row of each prompt
+// ----------------------------------------------------------------------------------------------------------------------
+namespace mx {
+// out[b, t, :] = tok[ids[b, t], :] + pos[t, :]   (bf16 tables, fp32 add, one rounding); ids outside the vocabulary are an error upstream
+__global__ void clip_embed_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ tok, const bf16_t* __restrict__ pos,
+                                  bf16_t* __restrict__ out, int rows, int L, int H, int vocab) {
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const bf16_t* tr = tok + (long)id * H;
+  const bf16_t* pr = pos + (long)(row % L) * H;
+  bf16_t* orow = out + (long)row * H;
+  for (int c = threadIdx.x * 8; c < H; c += blockDim.x * 8) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(tr + c), b = *reinterpret_cast<const u32x4*>(pr + c);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16lo_to_f32(a[e]) + bf16lo_to_f32(b[e]), bf16hi_to_f32(a[e]) + bf16hi_to_f32(b[e]));
+    *reinterpret_cast<u32x4*>(orow + c) = o;
+  }
+}
+// pooled[b, :] = x[b, eos(b), :], eos(b) = first position holding eos_id, or (eos_id < 0: the legacy CLIP configs with eos_token_id == 2)
+// the position of the largest id (transformers CLIPTextTransformer.forward)
+__global__ void clip_pool_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int L, int H, int eos_id) {
+  const int b = blockIdx.x;
+  __shared__ int pos_s;
+  if (threadIdx.x == 0) {
+    int best = 0;
+    if (eos_id >= 0) {
+      best = L - 1;                                      // (argmax of an all-false mask is 0 in the reference; a prompt always has its EOS)
+      for (int t = 0; t < L; ++t) if (ids[b * L + t] == eos_id) { best = t; break; }
+      bool any = false;
+      for (int t = 0; t < L; ++t) any |= ids[b * L + t] == eos_id;
+      if (!any) best = 0;
+    } else {
+      int mx_id = ids[b * L];
+      for (int t = 1; t < L; ++t) if (ids[b * L + t] > mx_id) { mx_id = ids[b * L + t]; best = t; }
+    }
+    pos_s = best;
+  }
+  __syncthreads();
+  const bf16_t* src = x + ((long)b * L + pos_s) * H;
+  for (int c = threadIdx.x * 8; c < H; c += blockDim.x * 8) *reinterpret_cast<u32x4*>(out + (long)b * H + c) = *reinterpret_cast<const u32x4*>(src + c);
+}
+int launch_clip_embed(hipStream_t s, const int* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* out, int rows, int L, int H, int vocab) {
+  MX_CHECK(H % 8 == 0, "clip_embed: hidden size must be a multiple of 8");
+  hipLaunchKernelGGL(clip_embed_kernel, dim3(rows), dim3(128), 0, s, ids, tok, pos, out, rows, L, H, vocab);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_clip_pool(hipStream_t s, const int* ids, const bf16_t* x, bf16_t* out, int B, int L, int H, int eos_id) {
+  hipLaunchKernelGGL(clip_pool_kernel, dim3(B), dim3(128), 0, s, ids, x, out, L, H, eos_id);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mx

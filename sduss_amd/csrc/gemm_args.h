@@ -249,6 +249,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = gelu_tanh_f(v[q]);
       }
+      if (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (flags & MX_EPI_GELU) ? gelu_fast(v[q]) : quick_gelu_f(v[q]);
+      }
       if (qkv) {
         const int nin = n - seg_idx * p.seg;  // position inside the segment
         if (to_vt) {
@@ -735,6 +739,10 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = gelu_tanh_f(o[q]);
       }
+      if (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (flags & MX_EPI_GELU) ? gelu_fast(o[q]) : quick_gelu_f(o[q]);
+      }
       if (stats) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { st1 += o[q]; st2 += o[q] * o[q]; }
@@ -808,6 +816,10 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       if (flags & MX_EPI_GELU_TANH) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = gelu_tanh_f(o[q]);
+      }
+      if (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (flags & MX_EPI_GELU) ? gelu_fast(o[q]) : quick_gelu_f(o[q]);
       }
       if (stats) {
 #pragma unroll

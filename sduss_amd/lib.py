@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmxdenoise.so")
 
 MX_F32, MX_F16, MX_BF16 = 0, 1, 2
-EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV, EPI_GELU_TANH, EPI_RES_BCAST, EPI_RMSNORM = 1, 2, 4, 8, 16, 32, 64
+EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV, EPI_GELU_TANH, EPI_RES_BCAST, EPI_RMSNORM, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class MxError(RuntimeError):
@@ -60,6 +60,12 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void
 
 class PPComm(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("all_gather", ALLGATHER_FN), ("ctx", C.c_void_p)]
+
+
+class CLIPConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int), ("hidden_size", C.c_int), ("intermediate_size", C.c_int), ("num_hidden_layers", C.c_int),
+                ("num_attention_heads", C.c_int), ("max_position_embeddings", C.c_int), ("hidden_act", C.c_int), ("projection_dim", C.c_int),
+                ("eos_token_id", C.c_int), ("hidden_layer", C.c_int), ("layer_norm_eps", C.c_float)]
 
 
 class VAEConfigC(C.Structure):
@@ -120,6 +126,13 @@ SYMBOLS = {
     "mx_vae_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "mx_vae_validate": (_i, [_vp, _i, _i, _i]),
     "mx_vae_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz]),
+    "mx_clip_create": (_vp, [C.POINTER(CLIPConfigC)]),
+    "mx_clip_destroy": (None, [_vp]),
+    "mx_clip_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),
+    "mx_clip_workspace_bytes": (_sz, [_vp, _i]),
+    "mx_clip_validate": (_i, [_vp, _i]),
+    "mx_clip_encode": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "mx_attention_prescaled_causal": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i]),
     "mx_cfg_flow_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),
     "mx_euler_scale_input": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i]),
     "mx_cfg_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),

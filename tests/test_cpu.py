@@ -349,3 +349,73 @@ def test_vae_plan_resolves_packed_weights_on_host():
     # SDXL VAE decoder: 49.5 M parameters
     total = sum(torch.Size(v).numel() for k, v in vae_ref.param_shapes(vae_ref.VAEConfig.sdxl()).items())
     assert 49.0e6 < total < 50.0e6, total
+
+
+def test_layernorm_fold_algebra_and_tile_policy():
+    """weights.fold_layernorm: LayerNorm(x) W^T + b == rstd (x W'^T - mean colsum) + b' (checked in fp64 with the rounded W' on both sides);
+    the host-side tile policy of the fold: launches that carry ln_stats / stats_out never take the 256 x 256 kernel (built without the
+    hooks), mx_gemm_stats_slabs / mx_gemm_ln_prefers_pass answer from the same chooser the launch uses."""
+    from sduss_amd import lib
+    from sduss_amd.weights import fold_layernorm
+    g = torch.Generator().manual_seed(3)
+    m, c, n = 37, 128, 96
+    x = torch.randn(m, c, generator=g, dtype=torch.float64) * 2 + 1.5
+    w = torch.randn(n, c, generator=g); bias = torch.randn(n, generator=g); gamma = 1 + 0.2 * torch.randn(c, generator=g); beta = 0.1 * torch.randn(c, generator=g)
+    wf, colsum, bf_ = fold_layernorm(w, bias, gamma, beta)
+    assert wf.dtype == torch.bfloat16 and colsum.dtype == torch.float32 and bf_.dtype == torch.float32
+    mean = x.mean(dim=1, keepdim=True); var = x.var(dim=1, unbiased=False, keepdim=True); rstd = (var + 1e-5).rsqrt()
+    w_eff = wf.double() / gamma.double()[None, :]                       # the weight the folded form realises
+    want = ((x - mean) * rstd * gamma.double() + beta.double()) @ w_eff.t() + bias.double() + (w.double() - w_eff) @ beta.double()
+    got = rstd * (x @ wf.double().t() - mean * colsum.double()[None, :]) + bf_.double()[None, :]
+    assert (got - want).abs().max().item() < 1e-5 * want.abs().max().item()
+
+    l = lib.load()
+    def desc(m, n, k, flags=0, aligned=True):
+        d = lib.GemmDesc()
+        d.a, d.w, d.c = 4096, 8192, 16384 if aligned else 16386
+        d.M, d.N, d.K, d.lda, d.ldc, d.flags = m, n, k, k, (n // 2 if flags & lib.EPI_GEGLU else n), flags
+        return d
+    # headline batch: GEGLU and QKV-sized launches would take the 256 x 256 kernel -> normalisation pass; to_q hides the statistics
+    assert l.mx_gemm_ln_prefers_pass(C.byref(desc(8192, 10240, 1280, lib.EPI_GEGLU))) == 1
+    assert l.mx_gemm_ln_prefers_pass(C.byref(desc(8192, 1280, 1280))) == 0
+    assert l.mx_gemm_ln_prefers_pass(C.byref(desc(2048, 3840, 1280))) in (0, 1)
+    # producers: one slab per wave column panel (80 columns of a 160-wide tile, 64 of a 128-wide one); none from the generic kernel
+    assert l.mx_gemm_stats_slabs(C.byref(desc(8192, 1280, 1280))) == 16
+    assert l.mx_gemm_stats_slabs(C.byref(desc(2048, 1280, 5120))) == 20
+    assert l.mx_gemm_stats_slabs(C.byref(desc(64, 1280, 1280))) == 0             # M < 128: generic kernel
+    assert l.mx_gemm_stats_slabs(C.byref(desc(8192, 1280, 1280, lib.EPI_GEGLU))) == 0
+    # a shape whose plain launch takes 256 x 256 tiles still yields statistics: asking for them moves it to a 256 / 128-row tile
+    assert l.mx_gemm_ln_prefers_pass(C.byref(desc(32768, 5120, 640))) == 1 and l.mx_gemm_stats_slabs(C.byref(desc(32768, 5120, 640))) > 0
+
+
+def test_clip_plan_resolves_packed_weights_on_host():
+    """mx_clip_validate walks the text-encoder plan on the host against what pack_clip produces from a transformers-named state dict"""
+    from sduss_amd import lib, weights
+    from sduss_amd.clip import CLIPTextConfig, pack_clip
+    l = lib.load()
+    for cfg in (CLIPTextConfig.tiny(), CLIPTextConfig.tiny(projection_dim=64, hidden_act="gelu")):
+        h, i = cfg.hidden_size, cfg.intermediate_size
+        P = {"text_model.embeddings.token_embedding.weight": torch.zeros(cfg.vocab_size, h), "text_model.embeddings.position_embedding.weight": torch.zeros(77, h),
+             "text_model.final_layer_norm.weight": torch.zeros(h), "text_model.final_layer_norm.bias": torch.zeros(h)}
+        for k in range(cfg.num_hidden_layers):
+            p = f"text_model.encoder.layers.{k}"
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                P[f"{p}.self_attn.{n}.weight"] = torch.zeros(h, h); P[f"{p}.self_attn.{n}.bias"] = torch.zeros(h)
+            for n in ("layer_norm1", "layer_norm2"):
+                P[f"{p}.{n}.weight"] = torch.zeros(h); P[f"{p}.{n}.bias"] = torch.zeros(h)
+            P[f"{p}.mlp.fc1.weight"] = torch.zeros(i, h); P[f"{p}.mlp.fc1.bias"] = torch.zeros(i)
+            P[f"{p}.mlp.fc2.weight"] = torch.zeros(h, i); P[f"{p}.mlp.fc2.bias"] = torch.zeros(h)
+        if cfg.projection_dim:
+            P["text_projection.weight"] = torch.zeros(cfg.projection_dim, h)
+        pw = weights.PackedWeights(pack_clip(cfg, P), "cpu")
+        cc = lib.CLIPConfigC()
+        cc.vocab_size, cc.hidden_size, cc.intermediate_size, cc.num_hidden_layers = cfg.vocab_size, h, i, cfg.num_hidden_layers
+        cc.num_attention_heads, cc.max_position_embeddings, cc.hidden_act = cfg.num_attention_heads, 77, 0 if cfg.hidden_act == "quick_gelu" else 1
+        cc.projection_dim, cc.eos_token_id, cc.hidden_layer, cc.layer_norm_eps = cfg.projection_dim, 2, -2, 1e-5
+        hnd = l.mx_clip_create(C.byref(cc))
+        assert hnd and l.mx_clip_set_weights(hnd, pw.blob.data_ptr(), pw.blob.numel(), pw.table, len(pw.names)) == 0
+        assert l.mx_clip_validate(hnd, 2) == 0, l.mx_last_error()
+        assert l.mx_clip_workspace_bytes(hnd, 2) > 0
+        l.mx_clip_destroy(hnd)
+    cc.num_attention_heads = 3                                   # heads of 64 only
+    assert not l.mx_clip_create(C.byref(cc)) and b"bad config" in l.mx_last_error()

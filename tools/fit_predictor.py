@@ -10,7 +10,7 @@ batch compositions the reference sampled (counts of 512 / 768 / 1024 px requests
 FCFS_Mixed.py:69-70 forces) and fits the same model.  Outputs (profiles/):
   unet_time_<model>_mi355x.csv, schedule_predictor_<model>_mi355x.pkl, predictor_<model>_mi355x.txt (fit report)
 
-Usage (GPU box): python tools/fit_predictor.py [--model sdxl|sd3] [--steps 3] [--max-total 8]
+Usage (GPU box): python tools/fit_predictor.py [--model sdxl|sd3] [--steps 5] [--max-total 8] [--caps 12,8,5] --out-dir gpurun_out/pred
 The composition list is seeded (numpy seed 10086) and capped by --max-total requests per batch.
 """
 import argparse
@@ -25,20 +25,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def compositions(max_total: int, n: int, seed: int = 10086):
-    """every single-resolution batch up to max_total plus a seeded sample of mixed ones (the reference's table has 221 rows
-    with up to 12 / 8 / 5 requests of 512 / 768 / 1024 px)"""
+def compositions(max_total: int, n: int, seed: int = 10086, caps=(12, 8, 5)):
+    """every single-resolution batch up to its cap plus a seeded sample of mixed ones.  The reference's table
+    (exp/profile/unet_time_sdxl.csv) has 221 rows with up to 12 / 8 / 5 requests of 512 / 768 / 1024 px: `caps`; max_total bounds the
+    pixel load of a mixed batch in units of 1024 px requests (4 a + 9 b + 16 c <= 16 max_total), as a batch the scheduler would form."""
     out = []
     for res_idx in range(3):
-        for k in range(1, max_total + 1):
+        for k in range(1, caps[res_idx] + 1):
             c = [0, 0, 0]
             c[res_idx] = k
             out.append(tuple(c))
     rng = np.random.RandomState(seed)
     seen = set(out)
-    while len(out) < n:
-        a, b, c = (int(rng.randint(0, max_total + 1)) for _ in range(3))
-        if 0 < a + b + c <= max_total and (a, b, c) not in seen:
+    tries = 0
+    while len(out) < n and tries < 100000:
+        tries += 1
+        a, b, c = (int(rng.randint(0, caps[i] + 1)) for i in range(3))
+        if a + b + c > 0 and 4 * a + 9 * b + 16 * c <= 16 * max_total and (a, b, c) not in seen:
             seen.add((a, b, c))
             out.append((a, b, c))
     return out
@@ -52,12 +55,15 @@ def features(t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", choices=["sdxl", "sd3"], default="sdxl")
-    ap.add_argument("--steps", type=int, default=3, help="timed denoising steps per composition (after one warm-up step)")
+    ap.add_argument("--steps", type=int, default=5, help="timed denoising steps per composition (after one warm-up step)")
     ap.add_argument("--max-total", type=int, default=8)
-    ap.add_argument("--rows", type=int, default=120)
+    ap.add_argument("--rows", type=int, default=221)
+    ap.add_argument("--caps", default="12,8,5", help="largest single-resolution batch per resolution (the reference table's range)")
+    ap.add_argument("--out-dir", default=None, help="where the table and the fit go (default profiles/; on the GPU box use gpurun_out/pred)")
     ap.add_argument("--fit-only", action="store_true", help="re-fit from the committed profiles/unet_time_<model>_mi355x.csv (no GPU)")
     args = ap.parse_args()
-    out_dir = os.path.join(ROOT, "profiles")
+    out_dir = args.out_dir or os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
     csv_path = os.path.join(out_dir, f"unet_time_{args.model}_mi355x.csv")
     if args.fit_only:
         rows = [tuple(float(x) for x in l.split(",")) for l in open(csv_path).read().splitlines()[1:]]
@@ -82,7 +88,7 @@ def main():
         net = MxSD3Transformer(cfg, synthetic_mmdit_params(cfg, device=dev), device=dev)
         den = SD3Denoiser(net, guidance_scale=7.0)
     shared = {}
-    comps = compositions(args.max_total, args.rows)
+    comps = compositions(args.max_total, args.rows, caps=tuple(int(x) for x in args.caps.split(",")))
     rows = []
     t_start = time.time()
     for idx, (a, b, c) in enumerate(comps):
@@ -137,7 +143,7 @@ def fit(args, rows, out_dir):
     singles = {res: next(t for a, b, c, t in rows if (a, b, c) == tuple(1 if i == j else 0 for j in range(3))) / 50.0
                for i, res in enumerate((512, 768, 1024))}
     with open(os.path.join(out_dir, f"predictor_{args.model}_mi355x.txt"), "w") as f:
-        f.write(f"{args.model} on MI355X: {len(rows)} batch compositions (<= {max(sum(r[:3]) for r in rows)} requests), 3 timed steps each, "
+        f.write(f"{args.model} on MI355X: {len(rows)} batch compositions (<= {max(sum(r[:3]) for r in rows)} requests), {args.steps} timed steps each, "
                 f"is_sliced=True patch 256, CFG, bf16, synthetic weights\n")
         f.write("features: a, b, c, 4a+9b+16c, #non-zero (ESyMReD.py:48-53); target: seconds per 50 steps; StandardScaler + MLPRegressor(32,32,16)\n")
         f.write(f"hold-out ({n_test} rows): mean relative error {err_te.mean():.4f}, max {err_te.max():.4f}; "
