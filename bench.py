@@ -42,9 +42,9 @@ KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<12
 
 
 KIND_SYMBOLS = {  # bench kernel label -> regex over the symbols in the rocprofv3 summaries (all instantiations of the kind)
-    "gemm_v2_kernel<160,false>": r"mx::gemm_v2_kernel<160, \d+, false>", "gemm_v2_kernel<160,true> (conv3x3)": r"mx::gemm_v2_kernel<160, \d+, true>",
-    "gemm_v2_kernel<128,false>": r"mx::gemm_v2_kernel<128, \d+, false>", "gemm_v2_kernel<128,true> (conv3x3)": r"mx::gemm_v2_kernel<128, \d+, true>",
-    "gemm_v4_kernel (256x256 ping-pong)": r"mx::gemm_v[34]_kernel<", "attn_fwd_kernel": r"mx::attn_fwd_kernel", "attn_cross_kernel (Lk<=96)": r"mx::attn_cross_kernel",
+    "gemm_v2_kernel<160,false>": r"mx::gemm_v2_kernel<160, \d+, false", "gemm_v2_kernel<160,true> (conv3x3)": r"mx::gemm_v2_kernel<160, \d+, true",
+    "gemm_v2_kernel<128,false>": r"mx::gemm_v2_kernel<128, \d+, false", "gemm_v2_kernel<128,true> (conv3x3)": r"mx::gemm_v2_kernel<128, \d+, true",
+    "gemm_v4_kernel (256x256 ping-pong)": r"mx::gemm_v[34]_kernel<", "attn_fwd_kernel": r"mx::attn_fwd", "attn_cross_kernel (Lk<=96)": r"mx::attn_cross_kernel",
 }
 
 
