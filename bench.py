@@ -320,7 +320,8 @@ def main():
             n, ms, fl, by = buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]
             if n > 0:
                 kinds.append({"kernel": name, "launches": int(n), "ms_total": ms, "avg_us": 1e3 * ms / n,
-                              "tflops": fl / (ms * 1e-3) / 1e12 if fl else None, "gbps": by / (ms * 1e-3) / 1e9})
+                              "tflops": fl / (ms * 1e-3) / 1e12 if fl else None, "gbps": by / (ms * 1e-3) / 1e9,
+                              "frac_of_mfma_peak": fl / (ms * 1e-3) / MFMA_PEAK_BF16 if fl else None})
         result["kernels"] = kinds
         mf = [k for k in kinds if k["tflops"]]
         if mf:
