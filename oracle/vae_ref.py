@@ -26,6 +26,8 @@ class VAEConfig:
     norm_num_groups: int = 32
     norm_eps: float = 1e-6
     scaling_factor: float = 0.13025          # SDXL vae config.json
+    shift_factor: float = 0.0                # SD3: latents / scaling_factor + shift_factor (pipeline_stable_diffusion_3_esymred.py:408)
+    use_post_quant_conv: bool = True         # SD3's AutoencoderKL has no quant convs
 
     @staticmethod
     def sdxl() -> "VAEConfig":
@@ -35,11 +37,17 @@ class VAEConfig:
     def tiny() -> "VAEConfig":
         return VAEConfig(block_out_channels=(64, 64, 128), layers_per_block=1)
 
+    @staticmethod
+    def tiny_sd3() -> "VAEConfig":
+        return VAEConfig(latent_channels=16, block_out_channels=(64, 64, 128), layers_per_block=1, scaling_factor=1.5305, shift_factor=0.0609,
+                         use_post_quant_conv=False)
+
 
 def param_shapes(cfg: VAEConfig) -> Dict[str, Tuple[int, ...]]:
     s: Dict[str, Tuple[int, ...]] = {}
     lc = cfg.latent_channels
-    s["post_quant_conv.weight"] = (lc, lc, 1, 1); s["post_quant_conv.bias"] = (lc,)
+    if cfg.use_post_quant_conv:
+        s["post_quant_conv.weight"] = (lc, lc, 1, 1); s["post_quant_conv.bias"] = (lc,)
     top = cfg.block_out_channels[-1]
     s["decoder.conv_in.weight"] = (top, lc, 3, 3); s["decoder.conv_in.bias"] = (top,)
 
@@ -113,8 +121,9 @@ def _attention(P, p, x, cfg: VAEConfig):
 def decode(P: Dict[str, torch.Tensor], cfg: VAEConfig, latents: torch.Tensor) -> torch.Tensor:
     """latents [B, 4, H, W] as the denoising loop leaves them (NOT yet divided by the scaling factor) -> images [B, 3, 8H, 8W]"""
     P = {k: v.to(torch.float32) for k, v in P.items()}
-    z = latents.to(torch.float32) / cfg.scaling_factor                     # :440
-    z = F.conv2d(z, P["post_quant_conv.weight"], P["post_quant_conv.bias"])
+    z = latents.to(torch.float32) / cfg.scaling_factor + cfg.shift_factor  # SDXL :440, SD3 :408
+    if cfg.use_post_quant_conv:
+        z = F.conv2d(z, P["post_quant_conv.weight"], P["post_quant_conv.bias"])
     x = F.conv2d(z, P["decoder.conv_in.weight"], P["decoder.conv_in.bias"], padding=1)
     x = _resnet(P, "decoder.mid_block.resnets.0", x, cfg)
     x = _attention(P, "decoder.mid_block.attentions.0", x, cfg)

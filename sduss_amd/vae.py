@@ -24,10 +24,18 @@ class VAEConfig:
     norm_num_groups: int = 32
     norm_eps: float = 1e-6
     scaling_factor: float = 0.13025
+    shift_factor: float = 0.0          # SD3: decode(latents / scaling_factor + shift_factor)
+    use_post_quant_conv: bool = True   # SD3's AutoencoderKL has none
 
     @staticmethod
     def sdxl() -> "VAEConfig":
         return VAEConfig()
+
+    @staticmethod
+    def sd3() -> "VAEConfig":
+        """the 16-channel VAE of SD3 / SD3.5 (vae/config.json: scaling 1.5305, shift 0.0609, no quant convs); same decoder graph
+        (pipeline_stable_diffusion_3_esymred.py:408-409)"""
+        return VAEConfig(latent_channels=16, scaling_factor=1.5305, shift_factor=0.0609, use_post_quant_conv=False)
 
     @staticmethod
     def tiny() -> "VAEConfig":
@@ -39,7 +47,8 @@ class VAEConfig:
         with open(path) as f:
             c = json.load(f)
         return VAEConfig(latent_channels=c["latent_channels"], out_channels=c["out_channels"], block_out_channels=tuple(c["block_out_channels"]),
-                         layers_per_block=c["layers_per_block"], norm_num_groups=c["norm_num_groups"], scaling_factor=c.get("scaling_factor", 0.18215))
+                         layers_per_block=c["layers_per_block"], norm_num_groups=c["norm_num_groups"], scaling_factor=c.get("scaling_factor", 0.18215),
+                         shift_factor=c.get("shift_factor") or 0.0, use_post_quant_conv=c.get("use_post_quant_conv", True))
 
 
 def pack_vae(cfg: VAEConfig, P: Dict[str, torch.Tensor]) -> List[Tuple[str, torch.Tensor]]:
@@ -47,10 +56,15 @@ def pack_vae(cfg: VAEConfig, P: Dict[str, torch.Tensor]) -> List[Tuple[str, torc
     bf, f32 = torch.bfloat16, torch.float32
     out: List[Tuple[str, torch.Tensor]] = []
     lc = cfg.latent_channels
-    # post_quant_conv as a padded [64, 64] linear with 1 / scaling_factor folded in (exact: both are linear)
+    # post_quant_conv as a padded [64, 64] linear with the latent rescaling folded in (exact: all of it is affine):
+    #   W (z / s + t) + b  =  (W / s) z + (b + W t 1);   without a post_quant_conv (SD3) W = I, b = 0
     w = torch.zeros(PAD, PAD, dtype=f32); b = torch.zeros(PAD, dtype=f32)
-    w[:lc, :lc] = P["post_quant_conv.weight"].reshape(lc, lc).to(f32) / cfg.scaling_factor
-    b[:lc] = P["post_quant_conv.bias"].to(f32)
+    if cfg.use_post_quant_conv:
+        w0 = P["post_quant_conv.weight"].reshape(lc, lc).to(f32); b0 = P["post_quant_conv.bias"].to(f32)
+    else:
+        w0 = torch.eye(lc, dtype=f32); b0 = torch.zeros(lc, dtype=f32)
+    w[:lc, :lc] = w0 / cfg.scaling_factor
+    b[:lc] = b0 + w0.sum(dim=1) * cfg.shift_factor
     out.append(("post_quant_conv.weight", w.to(bf))); out.append(("post_quant_conv.bias", b))
     for name, t in P.items():
         if not name.startswith("decoder."):
@@ -74,8 +88,8 @@ def pack_vae(cfg: VAEConfig, P: Dict[str, torch.Tensor]) -> List[Tuple[str, torc
 
 
 class MxVAEDecoder:
-    """``decode(latents) -> images`` with latents [B, 4, H, W] as the denoising loop leaves them (the division by
-    ``scaling_factor`` of post_inference :440 is folded into the packed weights) and images [B, 3, 8H, 8W] in [-1, 1]."""
+    """``decode(latents) -> images`` with latents [B, 4 | 16, H, W] as the denoising loop leaves them (``latents / scaling_factor
+    (+ shift_factor)`` of post_inference, SDXL :440 / SD3 :408, is folded into the packed weights) and images [B, 3, 8H, 8W] in [-1, 1]."""
 
     def __init__(self, cfg: VAEConfig, params: Dict[str, torch.Tensor], device="cuda:0", out_dtype=torch.float32):
         self.cfg = cfg

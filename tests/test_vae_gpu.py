@@ -33,6 +33,19 @@ def test_vae_decode_tiny(cuda_device, batch, hw):
     _check(got, want, f"vae decode tiny b{batch} {hw}x{hw}")
 
 
+def test_vae_decode_sd3_latents(cuda_device):
+    """the SD3 form: 16 latent channels, latents / scaling_factor + shift_factor, no post_quant_conv (pipeline_stable_diffusion_3_esymred.py:408)"""
+    from sduss_amd.vae import MxVAEDecoder, VAEConfig
+    from dataclasses import replace
+    ocfg = ref.VAEConfig.tiny_sd3()
+    P = ref.init_params(ocfg)
+    lat = (torch.randn(2, 16, 16, 16, generator=torch.Generator().manual_seed(8)) * 1.5).to(torch.bfloat16)
+    want = ref.decode(P, ocfg, lat.float())
+    cfg = replace(VAEConfig.sd3(), block_out_channels=(64, 64, 128), layers_per_block=1)
+    got = MxVAEDecoder(cfg, P, device="cuda:0").decode(lat.cuda())
+    _check(got, want, "vae decode tiny SD3 (16 ch, shift)")
+
+
 def test_vae_decode_sdxl_widths(cuda_device):
     """the real SDXL VAE widths (128 / 256 / 512 / 512, three resnets per up block, 512-wide single-head attention) on a 32 x 32 latent
     (256 px image): exercises the GEMM -> softmax -> GEMM attention at L = 1024 and every conv width"""
