@@ -129,6 +129,23 @@ def test_unet_full_width_sdxl(cuda_device):
     _check(got, want, "unet full width 32x32", max_rel=0.05, l2_rel=0.03)
 
 
+def test_unet_full_width_sdxl_batch8(cuda_device):
+    """the same widths at UNet batch 8 (M = 8192 tokens at the 640-wide level, 2048 at the 1280-wide one): both LayerNorm routes of the
+    step plan in one forward -- a normalisation pass in front of the 256 x 256 kernel where the batch makes it the tile of choice, row
+    statistics from the producing GEMM's epilogue elsewhere -- against the oracle on the weights as the device holds them"""
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.unet import MxUNet
+    from sduss_amd.weights import params_as_held
+    ocfg = ref.UNetConfig.sdxl_base()
+    P = ref.fast_params(ocfg)
+    s, t, e, te, ti = ref.make_inputs(ocfg, 8, 32)
+    with torch.inference_mode():
+        want = ref.unet_forward(params_as_held(UNetConfig.sdxl_base(), P), ocfg, s, t, e, te, ti)
+    net = MxUNet(UNetConfig.sdxl_base(), P, device="cuda:0")
+    got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
+    _check(got, want, "unet full width 32x32 batch 8", max_rel=0.05, l2_rel=0.03)
+
+
 def test_unet_graph_replay_follows_buffer_contents(tiny):
     """The forward is captured into a hipGraph keyed by its argument pointers (graph_cache.h) and replayed: a replay must read
     the CURRENT contents of the caller's buffers, and equal inputs must give bit-identical outputs on capture and replay."""
