@@ -135,7 +135,7 @@ __device__ __forceinline__ long gemm_out_row(const GemmArgs& p, int m, int bidx)
   return (long)bidx * p.c_batch_rows + p.c_row_off + (m - bidx * p.rows_per_batch);
 }
 
-// Register-layout epilogue of the generic 128-row kernel (gemm_bf16.hip); the 256-row kernels use gemm_epilogue_staged below.
+// Register-layout epilogue of the generic 128-row kernel (gemm_bf16.hip); the 256-row kernels use gemm_epilogue_regs below.
 template <int NI, int MI, int BN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0,
                                               const int wave_n0, const int fr, const int fq) {
@@ -303,224 +303,7 @@ __device__ __forceinline__ void gemm_tile_of_block(const int b, const int mt, co
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
-// LDS-staged epilogue of the 256-row kernels (gemm_bf16_v2.hip, gemm_bf16_v3.hip).
-//
-// The MFMA accumulator layout gives a lane 4 consecutive features of ONE token, so a direct store instruction touches 16
-// token rows x 32 bytes: 16 cache lines per kilobyte-half.  Measured (tools/exp_build.sh, MX_EXP=4): that epilogue cost
-// 16-28 us per 256-row tile -- 37-46 % of the launch for the K = 640..1536 shapes that make up the SDXL / SD3.5 step.
-// Here the tile is transposed through LDS in slabs (one 16-token block of every wave row at a time, fp32, so rounding
-// still happens once, after the residual add): lanes then read 8 consecutive features of a token and the wave's global
-// loads/stores cover whole rows of the tile (256-512 contiguous bytes) -- residual reads included.
-//   * wave grid WM x WN, wave tile 16*MI tokens x 16*NI features; slab = 16*WM tokens x BNO features of fp32
-//     (BNO = block features, halved by GEGLU), two slab buffers so one barrier per slab suffices;
-//   * slab swizzle: 16-byte chunk c of row r sits at c ^ (r & 7) (conflict-free ds_write_b128 from the accumulator layout);
-//   * order of operations as gemm_epilogue: bias -> GEGLU -> row bias -> gate (accumulator layout, before staging),
-//     residual -> SiLU / GELU-tanh -> convert -> store (row layout, after staging);
-//   * MX_EPI_QKV: q|k segments are staged; waves whose 64 features fall in a V segment write V^T directly as before.
-// The caller guarantees that `slab0` / `slab1` (16*WM * BNO floats of LDS each) are not being written by any DMA.
-// ----------------------------------------------------------------------------------------------------------------------
-// VEC: per-sample vectors (row bias, gate) supported; false compiles their registers out (32 VGPRs) for kernels that need the room
-template <int NI, int MI, int WM, int WN, bool GEGLU, bool VEC = true>
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4 (&acc)[NI][MI], float* slab0, float* slab1, const int m0,
-                                                     const int n0, const int wm, const int wn, const int fr, const int fq,
-                                                     const int tid) {
-  constexpr int BN = 16 * NI * WN;             // block features
-  constexpr int NIO = GEGLU ? NI / 2 : NI;     // staged 16-feature blocks per wave
-  constexpr int BNO = GEGLU ? BN / 2 : BN;     // staged features per slab row
-  constexpr int ROWS = 16 * WM;                // tokens per slab
-  constexpr int OCH = BNO / 8;                 // 8-feature output chunks per row
-  constexpr int TOTAL = ROWS * OCH;            // output chunks per slab
-  constexpr int KC = (TOTAL + 511) / 512;      // chunks per thread per slab
-  constexpr int DEPTH = 2;                     // residual loads run this many slabs ahead of their use
-  static_assert((BNO / 4) % 8 == 0, "slab swizzle needs a multiple of 8 fp32 chunks per row");
-  static_assert(MI % DEPTH == 0, "residual pipeline depth");
-  const int flags = p.flags;
-  const bool qkv = (flags & MX_EPI_QKV) != 0;
-  const int wave_n0 = n0 + wn * 16 * NI;       // first (packed) feature of this wave
-  // QKV: the wave's 64-feature range lies inside one segment (seg % 64 == 0)
-  int w_seg_idx = 0, w_seg_grp = 0;
-  bool w_to_vt = false;
-  if (qkv) {
-    w_seg_idx = wave_n0 / p.seg;
-    w_seg_grp = w_seg_idx / p.period;
-    w_to_vt = (w_seg_idx - w_seg_grp * p.period) == p.period - 1;
-  }
-  // MX_EPI_RMSNORM: heads are normalised in the read-out phase, where 8 consecutive lanes hold one 64-wide head of a token
-  const bool rms = qkv && (flags & MX_EPI_RMSNORM);
-  // output scale of this wave's features (QKV: the q segment only; with RMSNorm it is applied after the normalisation)
-  const float w_scale = (!rms && p.out_scale != 0.f && (!qkv || (w_seg_idx - w_seg_grp * p.period) == 0)) ? p.out_scale : 1.0f;
-  // read-out assignment of this thread (the same for every slab): chunk c = tid + 512 k -> slab row, feature chunk, C column
-  int ro_row[KC], ro_oc[KC], ro_col[KC];       // ro_col < 0: nothing to do (past the slab, or a V^T column)
-  int ro_rms[KC];                              // MX_EPI_RMSNORM: 0 = q chunk, 1 = k chunk
-#pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    const int c = tid + 512 * k;
-    const int r = c / OCH;
-    const int oc = c - r * OCH;
-    ro_row[k] = r; ro_oc[k] = oc;
-    int col = -1;
-    if (c < TOTAL) {
-      if (GEGLU) {
-        col = n0 / 2 + oc * 8;
-      } else if (qkv) {
-        const int n = n0 + oc * 8;
-        const int si = n / p.seg;
-        const int sg = si / p.period;
-        const int sp = si - sg * p.period;
-        if (sp != p.period - 1) col = sg * (p.period - 1) * p.seg + sp * p.seg + (n - si * p.seg);
-        ro_rms[k] = sp;
-      } else {
-        col = n0 + oc * 8;
-      }
-    }
-    if (!qkv || GEGLU) ro_rms[k] = 0;
-    ro_col[k] = col;
-  }
-  // token, output row and residual row of read-out chunk k in slab j
-  auto ro_token = [&](int k, int j) __attribute__((always_inline)) { return m0 + (ro_row[k] >> 4) * 16 * MI + j * 16 + (ro_row[k] & 15); };
-  const bool has_res = !GEGLU && p.residual != nullptr;
-  auto load_residual = [&](int k, int j) __attribute__((always_inline)) -> u32x4 {
-    const int m = ro_token(k, j);
-    if (!has_res || ro_col[k] < 0 || m >= p.M) return u32x4{0u, 0u, 0u, 0u};
-    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
-    const long rrow = (flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
-    return *reinterpret_cast<const u32x4*>(p.residual + rrow * p.ldr + ro_col[k]);
-  };
-  // per-wave vectors that do not depend on the token: loaded once, ahead of the slab loop (a load inside the loop cannot
-  // be hoisted by the compiler past the stores and would expose an L2 round trip per slab)
-  f32x4 bias_r[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    bias_r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && (GEGLU || i < NIO)) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + wave_n0 + i * 16 + fq * 4);
-  }
-  // per-batch vectors (row bias of the time embedding, AdaLN gate): one slab ahead
-  const bool has_rb = VEC && !GEGLU && p.rowbias != nullptr, has_gate = VEC && !GEGLU && p.gate != nullptr;
-  auto wave_bidx = [&](int j) __attribute__((always_inline)) {
-    const int m = m0 + wm * 16 * MI + j * 16 + fr;
-    const int mc = m < p.M ? m : p.M - 1;
-    return (p.rows_per_batch > 0) ? (mc / p.rows_per_batch) : 0;
-  };
-  f32x4 rb_r[VEC ? NIO : 1], gate_r[VEC ? NIO : 1];
-  auto load_batch_vectors = [&](int j) __attribute__((always_inline)) {
-    if constexpr (VEC) {
-      const int bidx = wave_bidx(j);
-#pragma unroll
-      for (int i = 0; i < NIO; ++i) {
-        const int n = wave_n0 + i * 16 + fq * 4;
-        if (has_rb) rb_r[i] = *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ldrb + n);
-        if (has_gate) gate_r[i] = *reinterpret_cast<const f32x4*>(p.gate + (long)bidx * p.ldg + n);
-      }
-    }
-  };
-  load_batch_vectors(0);
-  u32x4 res_r[DEPTH][KC];
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-    for (int k = 0; k < KC; ++k) res_r[d][k] = load_residual(k, d);
-
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    float* sb = (j & 1) ? slab1 : slab0;
-    // ---- phase A: accumulator layout -> slab (or V^T directly) ----
-    {
-      const int m = m0 + wm * 16 * MI + j * 16 + fr;
-      const int bidx = wave_bidx(j);
-      const int row = wm * 16 + fr;
-      f32x4 vv[NIO];
-#pragma unroll
-      for (int i = 0; i < NIO; ++i) {
-        f32x4 v = acc[i][j] + bias_r[i];
-        if constexpr (GEGLU) {
-          const f32x4 g = acc[i + NI / 2][j] + bias_r[i + NI / 2];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = v[q] * gelu_fast(g[q]);
-        } else {
-          v *= w_scale;
-          if constexpr (VEC) {
-            if (has_rb) v += rb_r[i];
-            if (has_gate) v *= gate_r[i];
-          }
-        }
-        vv[i] = v;
-      }
-        if (j + 1 < MI && (has_rb || has_gate)) load_batch_vectors(j + 1);
-      if (qkv && w_to_vt) {
-        if (m < p.M) {
-          const int key0 = (p.c_batch_rows > 0 ? p.c_row_off : 0) + m - bidx * p.rows_per_batch;
-          const int key = MX_VT_POS(key0);
-          const int nv = p.N / p.period;
-#pragma unroll
-          for (int i = 0; i < NIO; ++i) {
-            const int nin = wave_n0 + i * 16 + fq * 4 - w_seg_idx * p.seg;
-            bf16_t* dst = p.vt + ((long)bidx * nv + (long)w_seg_grp * p.seg + nin) * p.ldvt + key;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[(long)q * p.ldvt] = f32_to_bf16(vv[i][q]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NIO; ++i) {
-          const int ch = (wn * 16 * NIO + i * 16 + fq * 4) >> 2;             // fp32 chunk inside the slab row
-          *reinterpret_cast<f32x4*>(sb + row * BNO + ((ch ^ (row & 7)) << 2)) = vv[i];
-        }
-      }
-    }
-    __syncthreads();
-    // ---- phase B: slab rows -> global, 8 features (16 bytes of bf16) per lane, lanes along the row ----
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const u32x4 rr = res_r[j % DEPTH][k];
-      if (j + DEPTH < MI) res_r[j % DEPTH][k] = load_residual(k, j + DEPTH);
-      if (ro_col[k] < 0) continue;
-      const int r = ro_row[k];
-      const int m = ro_token(k, j);
-      if (m >= p.M) continue;
-      const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
-      const long orow = gemm_out_row(p, m, bidx);
-      const int pos = (2 * ro_oc[k]) ^ (r & 7);
-      const f32x4 a = *reinterpret_cast<const f32x4*>(sb + r * BNO + (pos << 2));
-      const f32x4 b = *reinterpret_cast<const f32x4*>(sb + r * BNO + ((pos ^ 1) << 2));
-      float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      if (rms) {   // the 8 lanes of a head all take this path together (OCH % 8 == 0: a head never straddles rows or masks)
-        float ss = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ss += v[q] * v[q];
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
-        const float mul = rsqrtf(ss * (1.0f / 64.0f) + p.rms_eps) * ((ro_rms[k] == 0 && p.out_scale != 0.f) ? p.out_scale : 1.0f);
-        const float* w = (ro_rms[k] == 0 ? p.rms_wq : p.rms_wk) + ((ro_oc[k] & 7) << 3);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w), w1 = *reinterpret_cast<const f32x4*>(w + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] *= mul * w0[q]; v[4 + q] *= mul * w1[q]; }
-      }
-      if (has_res) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[2 * q] += bf16lo_to_f32(rr[q]); v[2 * q + 1] += bf16hi_to_f32(rr[q]); }
-      }
-      if (flags & MX_EPI_SILU) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = silu_f(v[q]);
-      }
-      if (flags & MX_EPI_GELU_TANH) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = gelu_tanh_f(v[q]);
-      }
-      if (flags & MX_EPI_OUT_F32) {
-        float* dst = reinterpret_cast<float*>(p.c) + orow * p.ldc + ro_col[k];
-        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      } else {
-        const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + ro_col[k]) = o;
-      }
-    }
-  }
-}
-
-
-// ----------------------------------------------------------------------------------------------------------------------
-// Register-exchange epilogue of the 256-row kernels (round 2; replaces gemm_epilogue_staged in gemm_bf16_v2/v3.hip).
+// Register-exchange epilogue of the 256-row kernels (round 2; replaces the LDS-staged epilogue of round 1, see git history).
 //
 // The staged epilogue above costs ~15 us per 256 x 256 tile (8 slabs x {ds_write, barrier, ds_read, store}: 30 % of a
 // K = 1536 launch and > 40 % at the SDXL depths K = 640 / 1280, profiles/r01_e_gemm_component_removal.txt) with the

@@ -216,7 +216,7 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
     if (rows == 128 && small_disabled) continue;
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;
-    if ((d->flags & MX_EPI_RMSNORM) && bn == 160) continue;   // heads must not straddle read-out rows (gemm_epilogue_staged)
+    if ((d->flags & MX_EPI_RMSNORM) && bn == 160) continue;   // a 64-wide head must lie inside one wave panel (gemm_epilogue_regs)
     if (qkv && bn != 256 && d->seg % (bn / 2) != 0) continue;
     const long tiles = (long)cdiv(d->M, rows) * (d->N / bn);
     const double cost = (double)((tiles + 255) / 256) * (rows + bn) * (bn == 256 ? v3_discount : 1.0);

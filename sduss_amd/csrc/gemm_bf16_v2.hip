@@ -15,10 +15,9 @@
 //     loader (next K tile / next conv tap) runs after the MFMAs;
 //   * conv3x3: per-row source pointers are recomputed only when the tap changes (every Cin/64 K tiles) and otherwise
 //     just advance by one K tile; out-of-image taps and rows beyond M walk a zero page instead of branching;
-//   * epilogue: the ring is drained and reused as the transpose buffer of gemm_epilogue_staged (gemm_args.h), so global
-//     stores and residual loads move whole tile rows.  (An earlier persistent form that prefetched the next tile's K tiles
-//     under a register-layout epilogue was 8-11 % faster than one tile per workgroup; the staged epilogue is worth 20-40 %
-//     and needs the ring, so it replaced it.)
+//   * epilogue: gemm_epilogue_regs (gemm_args.h) transposes the accumulators in registers, so global stores and residual loads move whole
+//     128-byte lines per token without LDS or a barrier (round 1 staged the tile through the drained ring instead; that form bought 20-40 %
+//     over per-lane stores and was replaced in round 2).
 #include <cstdlib>
 
 #include "common.h"

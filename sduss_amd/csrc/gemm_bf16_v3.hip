@@ -22,7 +22,7 @@
 //   * launches of more tiles than CUs whose epilogue needs no per-sample vectors are PERSISTENT: one workgroup per CU walks
 //     its tiles (t, t + grid, ...) and their half-tiles form one DMA stream, so the first three half-tiles of the next tile
 //     land during the epilogue, which transposes through the two ring slots the last K iteration just released
-//     (gemm_args.h: gemm_epilogue_staged).  The variant with row-bias / gate support is at the 256-VGPR wall and keeps one
+//     (round 1; gemm_args.h: gemm_epilogue_regs since round 2).  The variant with row-bias / gate support is at the 256-VGPR wall and keeps one
 //     tile per workgroup.
 #include <cstdlib>
 
