@@ -86,7 +86,8 @@ enum {
   MX_EPI_RES_BCAST = 1 << 5, /* residual row = output row modulo rows_per_batch (positional table broadcast over the batch) */
   MX_EPI_RMSNORM  = 1 << 6,  /* with MX_EPI_QKV: RMS-normalise every 64-wide head of the q and k segments (see rms_wq below) */
   MX_EPI_GELU     = 1 << 7,  /* out = gelu(v), exact (erf) form: the OpenCLIP text encoder's MLP */
-  MX_EPI_QUICK_GELU = 1 << 8 /* out = v * sigmoid(1.702 v): the CLIP ViT-L text encoder's MLP */
+  MX_EPI_QUICK_GELU = 1 << 8, /* out = v * sigmoid(1.702 v): the CLIP ViT-L text encoder's MLP */
+  MX_EPI_GEGLU_TANH = 1 << 9 /* with MX_EPI_GEGLU: the gate takes the tanh form of GELU ("gelu_new": T5 v1.1 gated-gelu) */
 };
 
 typedef struct mx_gemm_desc {
@@ -186,6 +187,10 @@ int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, c
 #define MX_ATTN_QSCALE(scale) ((scale) * 1.4426950408889634f)
 int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk);
+/* softmax(q k^T + bias[h]) v: q and the fp32 bias [H][Lq][ldb] both already multiplied by log2(e) (T5: no 1/sqrt(d) scaling, bucketed relative
+ * position bias shared by all layers); ldb % 4 == 0, ldb >= Lk rounded up to 64 */
+int mx_attention_prescaled_bias(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, const float* bias, int ldb);
 /* the same with the causal mask (key j counts for query i only when j <= i), Lq == Lk == L: the CLIP text encoders */
 int mx_attention_prescaled_causal(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                                   int64_t vt_batch_stride, void* o, int ldo, int B, int H, int L);
@@ -194,6 +199,9 @@ int mx_attention_prescaled_causal(void* stream, const void* q, int ldq, const vo
  * input of a linear whose weights carry the affine (weights folded for mx_gemm_desc.ln_stats work unchanged on it, without ln_stats) */
 int mx_layernorm(void* stream, const void* x, void* y, const float* gamma, const float* beta,
                  int M, int C, float eps);
+
+/* y = x * rsqrt(mean(x^2) + eps) * w over the last dim C (T5LayerNorm: no mean subtraction, no bias); x,y bf16 [M, C], w fp32 [C] */
+int mx_rmsnorm(void* stream, const void* x, void* y, const float* w, int M, int C, float eps);
 
 /* AdaLN modulate: y = LayerNorm(x) * (1 + scale[b]) + shift[b] (no affine), optional second output y2 with
  * (scale2, shift2) sharing the normalisation; x,y bf16 [M, C]; scale/shift fp32 rows with stride ldmod, b = row / rows_per_batch */
@@ -385,6 +393,26 @@ size_t mx_clip_workspace_bytes(const mx_clip* c, int batch);
 int mx_clip_validate(const mx_clip* c, int batch);
 int mx_clip_encode(mx_clip* c, void* stream, const int32_t* ids, void* hidden_out, void* pooled_out, int batch, void* workspace,
                    size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * T5 v1.1 encoder (csrc/t5_text.cpp): SD3's text_encoder_3 (transformers T5EncoderModel, XXL: 24 blocks x 4096, 64 heads of 64, d_ff 10240,
+ * gated gelu_new), run by encode_prompt on 256 token ids per prompt without an attention mask; out = last_hidden_state bf16 [batch, L, d_model].
+ * Packed weights keep the transformers names except: q / k / v fused into "<block>.layer.0.SelfAttention.qkv.weight" [3 * 64 heads, d_model],
+ * wi_1 | wi_0 interleaved for the GEGLU epilogue into "<block>.layer.1.DenseReluDense.wi.weight" [2 d_ff, d_model], and the relative position
+ * bias of block 0 expanded for the sequence length into "encoder.position_bias.<L>" fp32 [heads, L, ceil64(L)], times log2(e)
+ * (sduss_amd/t5.py::pack_t5).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mx_t5_config {
+  int vocab_size, d_model, d_ff, num_layers, num_heads;    /* d_kv = 64 */
+  float layer_norm_epsilon;
+} mx_t5_config;
+typedef struct mx_t5 mx_t5;
+mx_t5* mx_t5_create(const mx_t5_config* cfg);
+void mx_t5_destroy(mx_t5* t);
+int mx_t5_set_weights(mx_t5* t, const void* blob, uint64_t blob_bytes, const mx_weight_entry* table, int n_entries);
+size_t mx_t5_workspace_bytes(const mx_t5* t, int batch, int L);
+int mx_t5_validate(const mx_t5* t, int batch, int L);
+int mx_t5_encode(mx_t5* t, void* stream, const int32_t* ids, void* out, int batch, int L, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * The element-wise steps either side of the model call.

@@ -51,6 +51,8 @@ struct AttnArgs {
   int key_chunk;     // 0: one contiguous key range per batch
   long k_bstride, k_cstride, vt_cstride;
   int causal;        // 1: key j counts for query i only when j <= i (text encoders; attn_fwd_kernel only)
+  const float* bias; // additive score bias [H][Lq][ldb], already in the kernel's log2 domain (T5 relative position bias; attn_fwd_kernel only)
+  int ldb;
 };
 
 constexpr int KT = 64;                 // keys per tile
@@ -231,6 +233,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
       for (int db = 0; db < 2; ++db) fr[sidx * 2 + db] = *reinterpret_cast<const bf16x8*>(smem + koff[sidx] + 8192 + db * 4096);
     __builtin_amdgcn_sched_barrier(0);
+    if (p.bias != nullptr) {            // additive bias, four consecutive keys per load; BEFORE the masks (the pad of a bias row may hold anything) (key = 32 kb + 8 g + 4 hh + {0..3})
+      int qi = q0 + r;
+      if (qi > p.Lq - 1) qi = p.Lq - 1;
+      const float* brow = p.bias + ((long)head * p.Lq + qi) * p.ldb + kt * KT + 4 * hh;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + kb * 32 + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[kb][4 * g + e] += b4[e];
+        }
+    }
     if (ragged && !has_next) {          // mask keys beyond Lk (tail tile only)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -1103,7 +1118,8 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnArgs p) {
 
 static int launch_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                             int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale, bool pre,
-                            int key_chunk = 0, int64_t k_bstride = 0, int64_t k_cstride = 0, int64_t vt_cstride = 0, bool causal = false) {
+                            int key_chunk = 0, int64_t k_bstride = 0, int64_t k_cstride = 0, int64_t vt_cstride = 0, bool causal = false,
+                            const float* bias = nullptr, int ldb = 0) {
   using namespace mx;
   MX_CHECK(q && k && vt && o, "attention: null operand");
   MX_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
@@ -1123,12 +1139,15 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
   a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale_log2 = scale * 1.4426950408889634f;
   a.causal = causal ? 1 : 0;
+  a.bias = bias; a.ldb = ldb;
+  if (bias) MX_CHECK(pre && key_chunk == 0 && ldb % 4 == 0 && ldb >= (Lk + KT - 1) / KT * KT && ((uintptr_t)bias & 15) == 0,
+                     "attention: bias form needs prescaled q, ldb a multiple of 4 covering whole 64-key tiles, 16-byte alignment");
   if (causal) MX_CHECK(Lq == Lk && key_chunk == 0 && Lk <= 4096, "attention: causal form is for Lq == Lk <= 4096, one key range");
   a.key_chunk = key_chunk; a.k_bstride = key_chunk > 0 ? (long)k_bstride : (long)Lk * ldk; a.k_cstride = (long)k_cstride; a.vt_cstride = (long)vt_cstride;
   static const int xcd_env = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
   a.xcd_map = (xcd_env && ((B * H) % 8 == 0)) ? 1 : 0;
   static const bool cross_off = [] { const char* e = getenv("MX_ATTN_CROSS"); return e && e[0] == '0'; }();
-  if (Lk <= 32 * XK_MAXBLK && Lq >= 2048 && !cross_off && key_chunk == 0 && !causal) {   // (at Lq 1024 the general kernel is 7 % faster: both are latency-bound)    // short key sequence: every wave keeps K / V^T in registers (attn_cross_kernel)
+  if (Lk <= 32 * XK_MAXBLK && Lq >= 2048 && !cross_off && key_chunk == 0 && !causal && !bias) {   // (at Lq 1024 the general kernel is 7 % faster: both are latency-bound)    // short key sequence: every wave keeps K / V^T in registers (attn_cross_kernel)
     MX_CHECK(ldo % 8 == 0, "attention: ldo must be a multiple of 8 elements");
     dim3 xgrid(cdiv(Lq, 4 * XK_QPW), H, B);
     prof_begin((hipStream_t)stream, PROF_ATTN_CROSS, 4.0 * B * H * (double)Lq * Lk * 64.0, 2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
@@ -1143,7 +1162,7 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
              2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
   static const bool dma_off = [] { const char* e = getenv("MX_ATTN_DMA"); return e && e[0] == '0'; }();
   static const int w64_min = [] { const char* e = getenv("MX_ATTN_W64_MIN_LQ"); return e ? atoi(e) : 2048; }();   // (a tie with the 32-row kernels at Lq 1024)
-  if (causal) {                                        // the masked form lives in the register-staged kernel
+  if (causal || bias) {                                // the masked / biased forms live in the register-staged kernel
     if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
   } else if (pre && Lk > 2 * KT && !dma_off && Lq >= w64_min && ldo % 8 == 0) {   // 64 query rows per wave
@@ -1173,6 +1192,14 @@ extern "C" int mx_attention_prescaled(void* stream, const void* q, int ldq, cons
 extern "C" int mx_attention_prescaled_causal(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                                              int64_t vt_batch_stride, void* o, int ldo, int B, int H, int L) {
   return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, L, L, 1.0f, true, 0, 0, 0, 0, true);
+}
+
+/* additive score bias (T5 relative position bias): softmax(q k^T + bias[h]) v with q AND bias already in the log2 domain (both multiplied by
+ * log2(e) by their producers); bias fp32 [H][Lq][ldb], ldb >= Lk rounded up to 64 */
+extern "C" int mx_attention_prescaled_bias(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                           int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, const float* bias, int ldb) {
+  MX_CHECK(bias != nullptr, "attention: null bias");
+  return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, 1.0f, true, 0, 0, 0, 0, false, bias, ldb);
 }
 
 /* patch-parallel form (mx_unet_forward_pp): K rows and V^T columns of the `world` ranks arrive rank-major from the all-gather.

@@ -402,7 +402,7 @@ int launch_softmax_rows(hipStream_t s, void* scores, long rows, int L, long ld) 
 // CLIP text encoder glue (clip_text.cpp): token + position embedding lookup, and the pooled row of each prompt
 // ----------------------------------------------------------------------------------------------------------------------
 namespace mx {
-// out[b, t, :] = tok[ids[b, t], :] + pos[t, :]   (bf16 tables, fp32 add, one rounding); ids outside the vocabulary are an error upstream
+// out[b, t, :] = tok[ids[b, t], :] + pos[t, :]   (bf16 tables, fp32 add, one rounding; pos == nullptr: token embedding only, T5); ids are clamped to the vocabulary
 __global__ void clip_embed_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ tok, const bf16_t* __restrict__ pos,
                                   bf16_t* __restrict__ out, int rows, int L, int H, int vocab) {
   const int row = blockIdx.x;
@@ -413,7 +413,7 @@ __global__ void clip_embed_kernel(const int* __restrict__ ids, const bf16_t* __r
   const bf16_t* pr = pos + (long)(row % L) * H;
   bf16_t* orow = out + (long)row * H;
   for (int c = threadIdx.x * 8; c < H; c += blockDim.x * 8) {
-    const u32x4 a = *reinterpret_cast<const u32x4*>(tr + c), b = *reinterpret_cast<const u32x4*>(pr + c);
+    const u32x4 a = *reinterpret_cast<const u32x4*>(tr + c), b = pos ? *reinterpret_cast<const u32x4*>(pr + c) : u32x4{0u, 0u, 0u, 0u};
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16lo_to_f32(a[e]) + bf16lo_to_f32(b[e]), bf16hi_to_f32(a[e]) + bf16hi_to_f32(b[e]));

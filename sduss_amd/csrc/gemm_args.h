@@ -220,7 +220,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
           for (int q = 0; q < 4; ++q) g[q] += b4[q];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] * gelu_fast(g[q]);
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * ((flags & MX_EPI_GEGLU_TANH) ? gelu_tanh_f(g[q]) : gelu_fast(g[q]));
         const int nout = wave_n0 / 2 + i * 16 + fq * 4;
         u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + nout) = o;
@@ -475,7 +475,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       if constexpr (GEGLU) {
         const f32x4 g = STATS ? acc[i + NI / 2][j] * ln_rstd + bias_r[i + NI / 2] : acc[i + NI / 2][j] + bias_r[i + NI / 2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = t[q] * gelu_fast(g[q]);
+        for (int q = 0; q < 4; ++q) t[q] = t[q] * ((flags & MX_EPI_GEGLU_TANH) ? gelu_tanh_f(g[q]) : gelu_fast(g[q]));
       } else {
         if (rms) {
 #pragma unroll

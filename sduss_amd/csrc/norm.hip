@@ -408,6 +408,43 @@ extern "C" int mx_layernorm(void* stream, const void* x, void* y, const float* g
 // ------------------------------------------------------------------------------------------
 namespace mx {
 
+// T5LayerNorm: y = x * rsqrt(mean(x^2) + eps) * w; one wave per row, the row stays in registers between the two passes
+template <int VPL>
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ w, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C / 8;
+  const bf16_t* xr = x + (long)row * C;
+  float v[VPL][8];
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const u32x4 u = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][2 * e] = bf16lo_to_f32(u[e]); v[i][2 * e + 1] = bf16hi_to_f32(u[e]);
+        sq += v[i][2 * e] * v[i][2 * e] + v[i][2 * e + 1] * v[i][2 * e + 1];
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  bf16_t* yr = y + (long)row * C;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(w + ch * 8), g1 = *reinterpret_cast<const f32x4*>(w + ch * 8 + 4);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = v[i][e] * rstd * g0[e]; o[e + 4] = v[i][e + 4] * rstd * g1[e]; }
+      *reinterpret_cast<u32x4*>(yr + ch * 8) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    }
+  }
+}
+
 // (sum, sum of squares) of every row: the one-slab statistics of the LayerNorm folded into its consumer GEMM (mx_gemm_desc.ln_stats)
 __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, int ldx, float* __restrict__ stats, int M, int C) {
   const int lane = threadIdx.x & 63;
@@ -579,6 +616,22 @@ extern "C" int mx_row_stats(void* stream, const void* x, int ldx, float* stats, 
   MX_CHECK(x && stats && M > 0, "row_stats: null operand");
   MX_CHECK(C % 8 == 0 && ldx >= C && ldx % 8 == 0 && (((uintptr_t)x & 15) | ((uintptr_t)stats & 7)) == 0, "row_stats: C and ldx must be multiples of 8, pointers aligned");
   hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, stats, M, C);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mx_rmsnorm(void* stream, const void* x, void* y, const float* w, int M, int C, float eps) {
+  using namespace mx;
+  MX_CHECK(x && y && w && M > 0, "rmsnorm: null operand");
+  MX_CHECK(C % 8 == 0 && C <= 64 * 8 * 8 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15) == 0), "rmsnorm: C must be a multiple of 8 and <= 4096, pointers 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(M, 4)), block(256);
+  const int vpl = cdiv(C / 8, 64);
+  const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y;
+  if (vpl <= 1) hipLaunchKernelGGL((rmsnorm_rows_kernel<1>), grid, block, 0, s, xp, yp, w, M, C, eps);
+  else if (vpl <= 2) hipLaunchKernelGGL((rmsnorm_rows_kernel<2>), grid, block, 0, s, xp, yp, w, M, C, eps);
+  else if (vpl <= 4) hipLaunchKernelGGL((rmsnorm_rows_kernel<4>), grid, block, 0, s, xp, yp, w, M, C, eps);
+  else hipLaunchKernelGGL((rmsnorm_rows_kernel<8>), grid, block, 0, s, xp, yp, w, M, C, eps);
   MX_LAUNCH_CHECK();
   return 0;
 }

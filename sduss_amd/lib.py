@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmxdenoise.so")
 
 MX_F32, MX_F16, MX_BF16 = 0, 1, 2
-EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV, EPI_GELU_TANH, EPI_RES_BCAST, EPI_RMSNORM, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16, 32, 64, 128, 256
+EPI_SILU, EPI_GEGLU, EPI_OUT_F32, EPI_QKV, EPI_GELU_TANH, EPI_RES_BCAST, EPI_RMSNORM, EPI_GELU, EPI_QUICK_GELU, EPI_GEGLU_TANH = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
 class MxError(RuntimeError):
@@ -66,6 +66,11 @@ class CLIPConfigC(C.Structure):
     _fields_ = [("vocab_size", C.c_int), ("hidden_size", C.c_int), ("intermediate_size", C.c_int), ("num_hidden_layers", C.c_int),
                 ("num_attention_heads", C.c_int), ("max_position_embeddings", C.c_int), ("hidden_act", C.c_int), ("projection_dim", C.c_int),
                 ("eos_token_id", C.c_int), ("hidden_layer", C.c_int), ("layer_norm_eps", C.c_float)]
+
+
+class T5ConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int), ("d_model", C.c_int), ("d_ff", C.c_int), ("num_layers", C.c_int), ("num_heads", C.c_int),
+                ("layer_norm_epsilon", C.c_float)]
 
 
 class VAEConfigC(C.Structure):
@@ -133,6 +138,14 @@ SYMBOLS = {
     "mx_clip_validate": (_i, [_vp, _i]),
     "mx_clip_encode": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "mx_attention_prescaled_causal": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i]),
+    "mx_attention_prescaled_bias": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _vp, _i]),
+    "mx_rmsnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f]),
+    "mx_t5_create": (_vp, [C.POINTER(T5ConfigC)]),
+    "mx_t5_destroy": (None, [_vp]),
+    "mx_t5_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),
+    "mx_t5_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "mx_t5_validate": (_i, [_vp, _i, _i]),
+    "mx_t5_encode": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
     "mx_cfg_flow_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),
     "mx_euler_scale_input": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i]),
     "mx_cfg_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _i]),

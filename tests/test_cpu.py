@@ -419,3 +419,39 @@ def test_clip_plan_resolves_packed_weights_on_host():
         l.mx_clip_destroy(hnd)
     cc.num_attention_heads = 3                                   # heads of 64 only
     assert not l.mx_clip_create(C.byref(cc)) and b"bad config" in l.mx_last_error()
+
+
+def test_t5_plan_resolves_packed_weights_on_host():
+    """mx_t5_validate walks the T5 encoder plan on the host against what pack_t5 produces from a transformers-named state dict; the position
+    bias table follows the published bucket rule (checked against transformers' own function)"""
+    from sduss_amd import lib, weights
+    from sduss_amd.t5 import T5Config, pack_t5, position_bias, relative_position_bucket
+    cfg = T5Config.tiny()
+    d, f, inner = cfg.d_model, cfg.d_ff, cfg.num_heads * 64
+    P = {"shared.weight": torch.zeros(cfg.vocab_size, d), "encoder.final_layer_norm.weight": torch.ones(d),
+         "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight": torch.arange(32 * cfg.num_heads, dtype=torch.float32).reshape(32, cfg.num_heads)}
+    for k in range(cfg.num_layers):
+        a = f"encoder.block.{k}.layer.0"
+        for n in ("q", "k", "v"):
+            P[f"{a}.SelfAttention.{n}.weight"] = torch.zeros(inner, d)
+        P[f"{a}.SelfAttention.o.weight"] = torch.zeros(d, inner); P[f"{a}.layer_norm.weight"] = torch.ones(d)
+        m = f"encoder.block.{k}.layer.1"
+        P[f"{m}.DenseReluDense.wi_0.weight"] = torch.zeros(f, d); P[f"{m}.DenseReluDense.wi_1.weight"] = torch.zeros(f, d)
+        P[f"{m}.DenseReluDense.wo.weight"] = torch.zeros(d, f); P[f"{m}.layer_norm.weight"] = torch.ones(d)
+    pw = weights.PackedWeights(pack_t5(cfg, P, (256, 64)), "cpu")
+    l = lib.load()
+    cc = lib.T5ConfigC()
+    cc.vocab_size, cc.d_model, cc.d_ff, cc.num_layers, cc.num_heads, cc.layer_norm_epsilon = cfg.vocab_size, d, f, cfg.num_layers, cfg.num_heads, 1e-6
+    h = l.mx_t5_create(C.byref(cc))
+    assert h and l.mx_t5_set_weights(h, pw.blob.data_ptr(), pw.blob.numel(), pw.table, len(pw.names)) == 0
+    assert l.mx_t5_validate(h, 2, 256) == 0, l.mx_last_error()
+    assert l.mx_t5_validate(h, 1, 64) == 0, l.mx_last_error()
+    assert l.mx_t5_validate(h, 1, 128) != 0 and b"position_bias.128" in l.mx_last_error()       # a length that was not prepared
+    assert l.mx_t5_workspace_bytes(h, 2, 256) > 0
+    l.mx_t5_destroy(h)
+    from transformers.models.t5 import modeling_t5
+    pos = torch.arange(300); rel = pos[None, :] - pos[:, None]
+    assert torch.equal(relative_position_bucket(rel, 32, 128), modeling_t5.T5Attention._relative_position_bucket(rel, bidirectional=True, num_buckets=32, max_distance=128))
+    pb = position_bias(cfg, P["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], 100)
+    assert pb.shape == (cfg.num_heads, 100, 128) and float(pb[:, :, 100:].abs().max()) == 0.0
+    assert abs(float(pb[1, 10, 10]) - 1.4426950408889634 * 1.0) < 1e-5          # bucket 0 (offset 0), head 1 -> weight[0, 1] = 1
