@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--mix-rates", type=str, default="1.0,2.0")
     ap.add_argument("--mix-max-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="skip the informative timing of the stages either side of the loop (text encoders, VAE decode)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -196,6 +197,59 @@ def probe_diffusers():
         if r and os.path.isdir(r) and glob.glob(os.path.join(r, "**", "unet", "diffusion_pytorch_model*.safetensors"), recursive=True):
             return True, f"diffusers {diffusers.__version__} and a UNet snapshot under {r}"
     return False, f"diffusers {diffusers.__version__} importable but no model snapshot on disk (no network)"
+
+
+def time_side_stages(device, batch, step_s):
+    """prepare_inference's text encoders and post_inference's VAE decode for one step's worth of requests (random-init weights of the real SDXL
+    architectures: CLIP ViT-L, OpenCLIP bigG, the 1024^2 VAE decoder), as a share of a request's 50 steps"""
+    from sduss_amd.clip import CLIPTextConfig, MxCLIPTextEncoder, encode_prompt_sdxl
+    from sduss_amd.vae import MxVAEDecoder, VAEConfig
+    g = torch.Generator().manual_seed(10086)
+
+    def rand_clip(c):
+        h, i = c.hidden_size, c.intermediate_size
+        P = {"text_model.embeddings.token_embedding.weight": torch.randn(c.vocab_size, h, generator=g) * 0.02,
+             "text_model.embeddings.position_embedding.weight": torch.randn(77, h, generator=g) * 0.02,
+             "text_model.final_layer_norm.weight": torch.ones(h), "text_model.final_layer_norm.bias": torch.zeros(h)}
+        for k in range(c.num_hidden_layers):
+            p = f"text_model.encoder.layers.{k}"
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                P[f"{p}.self_attn.{n}.weight"] = torch.randn(h, h, generator=g) * h ** -0.5; P[f"{p}.self_attn.{n}.bias"] = torch.zeros(h)
+            for n in ("layer_norm1", "layer_norm2"):
+                P[f"{p}.{n}.weight"] = torch.ones(h); P[f"{p}.{n}.bias"] = torch.zeros(h)
+            P[f"{p}.mlp.fc1.weight"] = torch.randn(i, h, generator=g) * h ** -0.5; P[f"{p}.mlp.fc1.bias"] = torch.zeros(i)
+            P[f"{p}.mlp.fc2.weight"] = torch.randn(h, i, generator=g) * i ** -0.5; P[f"{p}.mlp.fc2.bias"] = torch.zeros(h)
+        if c.projection_dim:
+            P["text_projection.weight"] = torch.randn(c.projection_dim, h, generator=g) * h ** -0.5
+        return P
+
+    def timed(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    c1, c2 = CLIPTextConfig.sdxl_text_encoder(), CLIPTextConfig.sdxl_text_encoder_2()
+    e1, e2 = MxCLIPTextEncoder(c1, rand_clip(c1), device), MxCLIPTextEncoder(c2, rand_clip(c2), device)
+    ids = torch.randint(0, 49000, (2 * batch, 77), generator=g)          # prompt + negative prompt per request
+    t_text = timed(lambda: encode_prompt_sdxl(e1, e2, ids, ids))
+    del e1, e2
+    vcfg = VAEConfig.sdxl()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from vae_bench import shapes as vae_shapes
+    VP = {k: (torch.randn(s_, generator=g) * (float(np.prod(s_[1:])) ** -0.5) if len(s_) > 1 else torch.ones(s_) if k.endswith("weight") else torch.zeros(s_))
+          for k, s_ in vae_shapes(vcfg).items()}
+    vae = MxVAEDecoder(vcfg, VP, device, out_dtype=torch.bfloat16)
+    lat = torch.randn(batch, 4, 128, 128, device=device, dtype=torch.bfloat16)
+    t_vae = timed(lambda: vae.decode(lat), n=3)
+    loop_s = STEPS_PER_IMAGE * step_s                                     # one step batch's requests share their 50 steps
+    return {"text_encoders_ms_per_request": 1e3 * t_text / batch, "vae_decode_ms_per_image": 1e3 * t_vae / batch,
+            "denoising_loop_ms_per_request": 1e3 * loop_s / batch,
+            "share_of_request_time": (t_text + t_vae) / (t_text + t_vae + loop_s),
+            "note": "CLIP ViT-L + OpenCLIP bigG on prompt and negative prompt (77 tokens each), SDXL VAE decoder at 1024^2; tokenizers / PIL conversion stay "
+                    "on the host; NOT included in `value`"}
 
 
 def cpu_baseline(res, model):
@@ -379,6 +433,13 @@ def main():
             result["mixed_stream"] = {"legs": legs, "trace": "synthetic, shape of exp/<model>/qps_*.csv: resolutions uniform over 512/768/1024, steps 30-50 by the "
                                                               "traces' histogram, exponential arrivals seed 10086", "deadlines_s": REF_DEADLINES_S[args.model],
                                       "max_batch": args.mix_max_batch, "policy": "FCFS mixed batching; resolutions of a step run as concurrent launch sequences"}
+
+    # ---- informative: the stages either side of the denoising loop (not part of `value`, which is the loop as BASELINE.json defines it) ----
+    if rank == 0 and not args.no_stages and not args.no_roofline and args.model == "sdxl" and args.res == 1024:
+        try:
+            result["stages_either_side"] = time_side_stages(device, args.batch, step_s)
+        except Exception as e:                                  # never fatal for the headline line
+            result["stages_either_side"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- CPU baseline leg ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
