@@ -8,6 +8,17 @@
 namespace mx {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+int cu_count() {
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    }
+    return (n & ~7) > 0 ? (n & ~7) : 256;         // whole XCD groups, so tile % 8 stays the workgroup's XCD (gemm_tile_of_block)
+  }();
+  return ncu;
+}
 
 struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; int m, n, k; float ms; };
 static std::vector<ProfRec> g_last;

@@ -66,6 +66,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- host side ----
 void set_error(const std::string& msg);
+int cu_count();   // compute units of the current device, whole XCD groups (multiple of 8); 256 when no device is visible (host-side planning)
 #define MX_CHECK(cond, msg)                   \
   do {                                        \
     if (!(cond)) {                            \

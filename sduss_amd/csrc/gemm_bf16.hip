@@ -219,7 +219,8 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
     if ((d->flags & MX_EPI_RMSNORM) && bn == 160) continue;   // a 64-wide head must lie inside one wave panel (gemm_epilogue_regs)
     if (qkv && bn != 256 && d->seg % (bn / 2) != 0) continue;
     const long tiles = (long)cdiv(d->M, rows) * (d->N / bn);
-    const double cost = (double)((tiles + 255) / 256) * (rows + bn) * (bn == 256 ? v3_discount : 1.0);
+    const int ncu = cu_count();
+    const double cost = (double)((tiles + ncu - 1) / ncu) * (rows + bn) * (bn == 256 ? v3_discount : 1.0);
     if (best.rows == 0 || cost < best_cost) { best = cands[c]; best_cost = cost; }
   }
   return best;

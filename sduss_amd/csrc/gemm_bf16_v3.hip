@@ -296,14 +296,7 @@ extern "C" int mx_debug_v3_stamps(unsigned long long* out) {
 #endif
 
 int launch_v3(hipStream_t s, const GemmArgs& a) {
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-    }
-    return n & ~7;                              // whole XCD groups, so tile % 8 stays the workgroup's XCD (gemm_tile_of_block)
-  }();
+  const int ncu = cu_count();
   static const bool persist = [] { const char* e = getenv("MX_V3_PERSIST"); return !(e && e[0] == '0'); }();
   const int tiles = cdiv(a.M, BM3) * (a.N / BN3);
   dim3 block(512);

@@ -328,14 +328,7 @@ static void v4_unused_marker() {}
 
 
 int launch_v4(hipStream_t s, const GemmArgs& a) {
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-    }
-    return n & ~7;                              // whole XCD groups, so tile % 8 stays the workgroup's XCD (gemm_tile_of_block)
-  }();
+  const int ncu = cu_count();
   const int tiles = cdiv(a.M, BM4) * (a.N / BN4);
   const dim3 grid(tiles > ncu && ncu > 0 ? ncu : tiles), block(512);
   if (a.rowbias || a.gate) hipLaunchKernelGGL(gemm_v4_kernel<true>, grid, block, 0, s, a);
