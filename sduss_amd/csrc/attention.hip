@@ -420,27 +420,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
   // ---- staging by LDS-DMA into a three-buffer ring, two tiles ahead: 512 16-byte chunks per tile per operand, 2 per thread.
   //      Chunk c = i * 256 + tid lands at byte 16 c of the image (an LDS-DMA writes base + 16 * lane); it is row c >> 3, slot c & 7,
   //      and holds logical chunk slot ^ ((row >> 1) & 7) of that row: the swizzle is applied on the SOURCE address. ----
-  const bf16_t* kbase = p.k + (long)b * p.k_bstride + head * 64;
-  const bf16_t* vbase = p.vt + (long)b * p.vt_bstride + ((long)head * 64) * p.ldvt;
-  auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
-    int key0 = kt * KT;
-    const bf16_t* kb_ = kbase;
-    const bf16_t* vb_ = vbase;
-    if (p.key_chunk > 0) {                     // tiles never straddle a chunk (key_chunk % 64 == 0)
-      const int ch = key0 / p.key_chunk;
-      key0 -= ch * p.key_chunk;
-      kb_ += ch * p.k_cstride;
-      vb_ += ch * p.vt_cstride;
-    }
-    char* img = smem + buf * kBufBytes;
+  // Addresses: a wave-uniform base that moves with the tile plus a per-lane 32-bit offset fixed for the whole kernel (as in attn_fwd64_kernel:
+  // the per-tile 64-bit address arithmetic cost 6 % of the launch there).
+  const char* kbase = (const char*)(p.k + (long)b * p.k_bstride + head * 64);
+  const char* vbase = (const char*)(p.vt + (long)b * p.vt_bstride + ((long)head * 64) * p.ldvt);
+  unsigned voffk[2], voffv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 3, ch = (c & 7) ^ ((row >> 1) & 7);
+    voffk[i] = (unsigned)(row * p.ldk * 2 + ch * 16);
+    voffv[i] = (unsigned)(row * p.ldvt * 2 + ch * 16);
+  }
+  const char* knext = kbase;
+  const char* vnext = vbase;
+  int chunk_left = p.key_chunk > 0 ? p.key_chunk : 0x7fffffff;
+  int chunk_id = 0;
+  const unsigned wave_img = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+  auto issue_tile = [&](int /*kt: tiles are issued in order*/, int buf) __attribute__((always_inline)) {
+    char* img = smem + buf * kBufBytes + wave_img;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = i * 256 + tid;
-      const int row = c >> 3, ch = (c & 7) ^ ((row >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb_ + (long)(key0 + row) * p.ldk + ch * 8),
-                                       (__attribute__((address_space(3))) void*)(img + (i * 256 + wave * 64) * 16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb_ + (long)row * p.ldvt + key0 + ch * 8),
-                                       (__attribute__((address_space(3))) void*)(img + 8192 + (i * 256 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(knext + voffk[i]),
+                                       (__attribute__((address_space(3))) void*)(img + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vnext + voffv[i]),
+                                       (__attribute__((address_space(3))) void*)(img + 8192 + i * 4096), 16, 0, 0);
+    }
+    knext += (long)KT * p.ldk * 2;
+    vnext += KT * 2;
+    chunk_left -= KT;
+    if (chunk_left == 0) {                     // tiles never straddle a chunk (key_chunk % 64 == 0)
+      ++chunk_id;
+      chunk_left = p.key_chunk;
+      knext = kbase + (long)chunk_id * p.k_cstride * 2;
+      vnext = vbase + (long)chunk_id * p.vt_cstride * 2;
     }
   };
 
