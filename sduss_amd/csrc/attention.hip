@@ -547,17 +547,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
         }
     }
     // ---- online softmax (log2 domain) ----
-    float mx_ = s[0][0];
+    auto col_max = [&]() __attribute__((always_inline)) {
+      float mx_ = s[0][0];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mx_ = fmaxf(mx_, s[kb][e]);
-    mx_ = max_across_halves(mx_);
+        for (int e = 0; e < 16; ++e) mx_ = fmaxf(mx_, s[kb][e]);
+      return max_across_halves(mx_);
+    };
     float psum = 0.f;
     if constexpr (PRE) {
-      // s already holds s*c - m_ref.  Move the reference only on the first tile or when a row ran more than 8 above it.
-      const bool first = kt == 0;
-      if (first || __any(mx_ > 8.0f)) {
+      // s already holds s*c - m_ref, m_ref a lazy reference: set from tile 0, raised only when a row runs more than 8 above it.  After
+      // tile 0 the exponentials run SPECULATIVELY and the sums are watched (as in attn_fwd64_kernel): a score > 8 above the reference
+      // makes its p, hence the lane's sum, exceed 256; then (rarely) the tile is redone exactly.  The row maximum leaves the hot path.
+      auto exps = [&]() __attribute__((always_inline)) {
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+#if (MX_AEXP & 1)
+            const float pe = s[kb][e];
+#else
+            const float pe = __builtin_amdgcn_exp2f(s[kb][e]);
+#endif
+            s[kb][e] = pe;
+            ps += pe;
+          }
+        return ps;
+      };
+      auto move_reference = [&](bool first) __attribute__((always_inline)) {       // on exact scores in s
+        const float mx_ = col_max();
         float delta = 0.f;
         if (first || mx_ > 8.0f) {
           const float nr = bf16lo_to_f32(pack2(m_ref + mx_, 0.f));        // new reference, bf16-representable
@@ -577,21 +597,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
         }
-      }
+      };
+      if (kt == 0) {
+        move_reference(true);
+        psum = exps();
+      } else {
+        psum = exps();
+        if (__any(psum > 256.0f)) {            // redo: scores again from the K fragments (the V^T fragments took their registers)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+          for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-#if (MX_AEXP & 1)
-          const float pe = s[kb][e];
-#else
-          const float pe = __builtin_amdgcn_exp2f(s[kb][e]);
-#endif
-          s[kb][e] = pe;
-          psum += pe;
+            for (int ks = 0; ks < 4; ++ks) fr[kb * 4 + ks] = *reinterpret_cast<const bf16x8*>(smem + bofs + koff[ks] + kb * 4096);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+              s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm), s[kb], 0, 0, 0);
+          move_reference(false);
+          psum = exps();
+#pragma unroll
+          for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) fr[sidx * 2 + db] = *reinterpret_cast<const bf16x8*>(smem + bofs + koff[sidx] + 8192 + db * 4096);
         }
+      }
       l_run += psum;
     } else {
+      const float mx_ = col_max();
       const float m_new = fmaxf(m_run, mx_ * c);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
