@@ -13,6 +13,8 @@
 // Pass 1  gn_stats_kernel : per (image, spatial tile, channel) sum / sum-of-squares partials (fp32)
 // Pass 2  gn_fold_kernel  : fp64 fold of the partials -> per (image, channel) scale/shift
 // Pass 3  gn_apply_kernel : y = silu?(x*scale + shift)
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/mxdenoise.h"
 
@@ -204,11 +206,15 @@ static int gn_geom(GnGeom& g, int B, int H, int W, int C, int patch) {
   g.tpr = C / 8;
   g.L = 1024 / g.tpr;
   if (g.L > 32) g.L = 32;
-  // spatial tile: full rows of the image (or of the patch), about 256 pixels
+  // spatial tile: full rows of the image (or of the patch), about 256 pixels -- fewer at the small levels, where 256-pixel tiles leave
+  // most CUs without a statistics block (8 images of 32 x 32: 32 blocks); halved until the launch has two blocks per CU
+  static const int tile_pix = [] { const char* e = getenv("MX_GN_TILE_PIX"); return e ? atoi(e) : 256; }();
   int tw = (patch > 0) ? patch : W;
-  int th = 256 / tw; if (th < 1) th = 1;
+  int th = tile_pix / tw; if (th < 1) th = 1;
   const int hlim = (patch > 0) ? patch : H;
   while (hlim % th != 0) --th;
+  static const bool spread = [] { const char* e = getenv("MX_GN_SPREAD"); return !(e && e[0] == '0'); }();     // 0: the round-1 geometry (A/B)
+  while (spread && th > 1 && th * tw >= 64 && (long)B * (H / th) * (W / tw) < 2L * cu_count()) { th /= 2; while (hlim % th != 0) --th; }   // >= 32 pixels per tile
   g.th = th; g.tw = tw;
   if (patch > 0) MX_CHECK(H % patch == 0 && W % patch == 0, "groupnorm: H, W must be multiples of patch");
   g.tiles_y = H / th; g.tiles_x = W / tw;
