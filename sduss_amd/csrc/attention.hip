@@ -72,7 +72,9 @@ __device__ __forceinline__ float max_across_halves(float x) {
   return fmaxf(a, b);
 }
 
-template <bool PRE>
+// EXTRA: the additive-bias and causal-mask forms of the text encoders, a separate instantiation (as run-time branches they cost the
+// 60 cross-attention launches of a UNet step 3.4 us each: profiles r02_f vs r02_g)
+template <bool PRE, bool EXTRA = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes];
 
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
       for (int db = 0; db < 2; ++db) fr[sidx * 2 + db] = *reinterpret_cast<const bf16x8*>(smem + koff[sidx] + 8192 + db * 4096);
     __builtin_amdgcn_sched_barrier(0);
-    if (p.bias != nullptr) {            // additive bias, four consecutive keys per load; BEFORE the masks (the pad of a bias row may hold anything) (key = 32 kb + 8 g + 4 hh + {0..3})
+    if constexpr (EXTRA) if (p.bias != nullptr) {   // additive bias, four consecutive keys per load; BEFORE the masks (the pad of a bias row may hold anything) (key = 32 kb + 8 g + 4 hh + {0..3})
       int qi = q0 + r;
       if (qi > p.Lq - 1) qi = p.Lq - 1;
       const float* brow = p.bias + ((long)head * p.Lq + qi) * p.ldb + kt * KT + 4 * hh;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
           if (key >= p.Lk) s[kb][e] = -INFINITY;
         }
     }
-    if (p.causal) {                     // keys after the query never count (every tile: short sequences only)
+    if constexpr (EXTRA) if (p.causal) {            // keys after the query never count (every tile: short sequences only)
       const int qi = q0 + r;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -1211,8 +1213,8 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
   static const bool dma_off = [] { const char* e = getenv("MX_ATTN_DMA"); return e && e[0] == '0'; }();
   static const int w64_min = [] { const char* e = getenv("MX_ATTN_W64_MIN_LQ"); return e ? atoi(e) : 2048; }();   // (a tie with the 32-row kernels at Lq 1024)
   if (causal || bias) {                                // the masked / biased forms live in the register-staged kernel
-    if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (pre) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   } else if (pre && Lk > 2 * KT && !dma_off && Lq >= w64_min && ldo % 8 == 0) {   // 64 query rows per wave
     dim3 grid64(cdiv(Lq, 256), H, B);
     hipLaunchKernelGGL(attn_fwd64_kernel, grid64, dim3(256), 0, (hipStream_t)stream, a);
