@@ -262,7 +262,10 @@ def test_sdxl_base_forward_1024(cuda_device):
         want = ref.unet_forward(params_as_held(UNetConfig.sdxl_base(), P), ocfg, s, t, e, te, ti)
     net = MxUNet(UNetConfig.sdxl_base(), P, device="cuda:0")
     got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
-    _check_forward(got, want, "SDXL-base 1024^2 forward, batch 2")
+    # error budget of tests/test_unet_gpu.py::test_unet_per_stage_error_budget (0.35 % * sqrt(n) + 0.2 % after n bf16-stored stages) at this
+    # model's depth -- 17 resnets + 70 transformer layers + 9 convs, n ~ 96 -> 3.6 %; measured 1.9-2.0 % over the round's kernel changes, so the
+    # bound is set at 2.5 %, not at the first measurement (a 2.0 % bound flipped on a change of summation order in the GroupNorm statistics)
+    _check_forward(got, want, "SDXL-base 1024^2 forward, batch 2", l2_rel=0.025)
 
 
 def test_sd35_medium_forward_1024(cuda_device):
