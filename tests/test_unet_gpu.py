@@ -146,6 +146,24 @@ def test_unet_full_width_sdxl_batch8(cuda_device):
     _check(got, want, "unet full width 32x32 batch 8", max_rel=0.05, l2_rel=0.03)
 
 
+@pytest.mark.parametrize("batch,hw", [(3, 24), (5, 40), (1, 48)])
+def test_unet_full_width_sdxl_ragged(cuda_device, batch, hw):
+    """the real widths on token counts that are not multiples of the GEMM tiles (batch 3 x 24 x 24 latents: M = 1728 / 432 tokens; 5 x 40 x 40:
+    8000 / 2000; 1 x 48 x 48: 2304 / 576): the last row tile of every GEMM is partial, so the producers' row statistics and the consumers'
+    folded LayerNorm run on tiles that end inside a tile; odd image sizes for the convs and the GroupNorm tiles"""
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.unet import MxUNet
+    from sduss_amd.weights import params_as_held
+    ocfg = ref.UNetConfig.sdxl_base()
+    P = ref.fast_params(ocfg)
+    s, t, e, te, ti = ref.make_inputs(ocfg, batch, hw)
+    with torch.inference_mode():
+        want = ref.unet_forward(params_as_held(UNetConfig.sdxl_base(), P), ocfg, s, t, e, te, ti)
+    net = MxUNet(UNetConfig.sdxl_base(), P, device="cuda:0")
+    got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
+    _check(got, want, f"unet full width {hw}x{hw} batch {batch}", max_rel=0.05, l2_rel=0.03)
+
+
 def test_unet_graph_replay_follows_buffer_contents(tiny):
     """The forward is captured into a hipGraph keyed by its argument pointers (graph_cache.h) and replayed: a replay must read
     the CURRENT contents of the caller's buffers, and equal inputs must give bit-identical outputs on capture and replay."""
