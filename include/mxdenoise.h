@@ -415,6 +415,39 @@ int mx_t5_validate(const mx_t5* t, int batch, int L);
 int mx_t5_encode(mx_t5* t, void* stream, const int32_t* ids, void* out, int batch, int L, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * Block-skip cache ("Mix-Cache"): the reference's CacheManager with ESYMRED_USE_CACHE=TRUE (modules/cache_manager.py:101-191, called at the
+ * top of each of the UNet's seven blocks -- three down, mid, three up: unet_2d_blocks.py:40,102,180,250,345).  Before a block runs, every
+ * sample's block input (for the up blocks also each skip tensor it consumes) is compared with the input that block saw at its last run: the
+ * mean squared difference.  The host predictor sees the reference's feature rows [block index, timestep, mse (, mse of each skip)] and answers
+ * run / reuse per sample; a reused block's outputs (hidden state and, for the down blocks, the skip tensors) come from the cache.
+ * Approximate by design and OFF on the exact path (mx_unet_forward never consults it).
+ * Granularity here: the step batch -- a block is reused only when NO sample of the batch asks to run it (the reference compacts the batch per
+ * block; exact for single-request steps, conservative otherwise).  The cached state belongs to one batch composition: a different
+ * batch_key, batch size or latent size invalidates it (every block runs once and refills it).  Not combined with patch parallelism.
+ *   predict(ctx, block, is_up, n_samples, n_feat, timesteps[n], mse[n * n_feat], run_out[n]): mse = MX_MSE_UNCACHED when the block has no
+ *   cached input; return non-zero to abort the forward.  The reference's predictors are cuML random forests that are not loadable here:
+ *   sduss_amd/block_cache.py ships a threshold rule with the reference's forced recompute after four reuses (cache_manager.py:134,154) and
+ *   takes any object with .predict(features).
+ * ------------------------------------------------------------------------------------------ */
+#define MX_MSE_UNCACHED 9.2233720368547758e18f      /* float(sys.maxsize), cache_manager.py:19 */
+typedef int (*mx_skip_predict_fn)(void* ctx, int block, int is_up, int n_samples, int n_feat, const float* timesteps, const float* mse,
+                                  unsigned char* run_out);
+typedef struct mx_block_cache {
+  mx_skip_predict_fn predict;
+  void* ctx;
+  void* state;                /* device memory, mx_unet_block_cache_bytes(...) bytes, kept by the caller across steps */
+  size_t state_bytes;
+  uint64_t batch_key;         /* in: identifies the batch composition (e.g. a hash of the request ids in row order) */
+  uint64_t cached_key;        /* library-owned from here on: zero-initialise the struct once */
+  int cached_valid, cached_batch, cached_h, cached_w;
+  unsigned blocks_run;        /* out: bit i set = block i ran in the last forward */
+} mx_block_cache;
+size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, int W);
+int mx_unet_forward_cached(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
+                           const void* encoder_hidden_states, const void* text_embeds, const float* time_ids, void* out,
+                           int batch, int H, int W, int ctx_len, int gn_patch, void* workspace, size_t workspace_bytes, mx_block_cache* cache);
+
+/* ------------------------------------------------------------------------------------------
  * The element-wise steps either side of the model call.
  * ------------------------------------------------------------------------------------------ */
 /* out[b] = x[b mod n_lat] / sqrt(sigma[b mod n_lat]^2 + 1) for b in [0, n_rows)   (batch_scale_model_input, CFG

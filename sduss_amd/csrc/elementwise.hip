@@ -455,3 +455,41 @@ int launch_clip_pool(hipStream_t s, const int* ids, const bf16_t* x, bf16_t* out
   return 0;
 }
 }  // namespace mx
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Block-skip cache (unet_sdxl.cpp, mx_unet_forward_cached): per-sample squared difference of a block input against the input the block saw
+// when it last ran -- the feature of the reference's CacheManager.get_mask (modules/cache_manager.py:105-159: mse_loss(...).mean(dim=(-1,-2,-3)))
+// ----------------------------------------------------------------------------------------------------------------------
+namespace mx {
+constexpr int kMseChunks = 64;
+// partial[b][chunk] = sum over the chunk of (a - b)^2 (fp32 in-thread, fp64 across the block); the host adds the 64 partials of a sample: the
+// result does not depend on launch order
+__global__ __launch_bounds__(256) void sq_diff_partial_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long elems, double* __restrict__ partial) {
+  const int smp = blockIdx.y, chunk = blockIdx.x;
+  const long per = (elems / 8 + kMseChunks - 1) / kMseChunks;           // 16-byte vectors per chunk
+  const long v0 = (long)chunk * per, v1 = min(v0 + per, elems / 8);
+  const bf16_t* pa = a + (long)smp * elems; const bf16_t* pb = b + (long)smp * elems;
+  float acc = 0.f;
+  for (long v = v0 + threadIdx.x; v < v1; v += 256) {
+    const u32x4 x = *reinterpret_cast<const u32x4*>(pa + v * 8), y = *reinterpret_cast<const u32x4*>(pb + v * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d0 = bf16lo_to_f32(x[e]) - bf16lo_to_f32(y[e]), d1 = bf16hi_to_f32(x[e]) - bf16hi_to_f32(y[e]);
+      acc += d0 * d0 + d1 * d1;
+    }
+  }
+  __shared__ double red[4];
+  double d = (double)acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long)smp * kMseChunks + chunk] = red[0] + red[1] + red[2] + red[3];
+}
+int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial) {
+  MX_CHECK(elems_per_sample % 8 == 0, "sq_diff: elements per sample must be a multiple of 8");
+  hipLaunchKernelGGL(sq_diff_partial_kernel, dim3(kMseChunks, B), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, elems_per_sample, partial);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mx

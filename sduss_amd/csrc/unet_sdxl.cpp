@@ -17,7 +17,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <algorithm>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -33,6 +35,7 @@ int launch_time_embed(hipStream_t s, const float* timesteps, const void* text_em
                       void* tsin, void* addin, int B, int d0, int text_dim, int da);
 int launch_concat(hipStream_t s, const void* a, const void* b, void* out, long M, int C1, int C2);
 size_t gn_workspace_exact(int B, int H, int W, int C, int patch);
+int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial);
 int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, int B, int H, int W, int C, int groups, void* workspace, double* sums);
 int launch_gn_pp_finish(hipStream_t s, const void* x, int C1, const void* x2, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
                         int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace);
@@ -74,6 +77,12 @@ struct Plan {
   Arena ar;
   int B, H, W, ctx_len, gn_patch;
   bool dry;                 // size-only pass: no launches
+  bool mute = false;        // block-skip cache: walk a block's plan (allocations, weight / K-V / time-embedding cursors) without launching it
+  bool quiet() const { return dry || mute; }
+  mx_block_cache* bc = nullptr;   // mx_unet_forward_cached
+  char* bc_top = nullptr;         // bump pointer into bc->state: same order and sizes every step
+  unsigned blocks_run = 0;
+  std::vector<float> h_timesteps; // host copy of the timesteps for the predictor
   bool lookup = false;      // dry pass that still resolves every weight (mx_unet_validate)
   const char* stage = nullptr; void* stage_out = nullptr; size_t stage_bytes = 0; bool stage_hit = false;
   std::string err;
@@ -177,7 +186,7 @@ struct Plan {
   // ---- op wrappers -------------------------------------------------------------------------
   bool gemm(mx_gemm_desc& d, bool conv) {
     if (!ok()) return false;
-    if (dry) return true;
+    if (quiet()) return true;
     const int rc = conv ? mx_conv3x3(stream, &d) : mx_gemm(stream, &d);
     if (rc) return fail(std::string("gemm/conv: ") + mx_last_error());
     return true;
@@ -191,7 +200,7 @@ struct Plan {
     if (slabs > 0) { d.stats_out = st.buf; st.slabs = slabs; return gemm(d, false); }
     st.slabs = 1;
     if (!gemm(d, false)) return false;
-    if (!dry && mx_row_stats(stream, d.c, d.ldc, st.buf, d.M, d.N)) return fail(std::string("row_stats: ") + mx_last_error());
+    if (!quiet() && mx_row_stats(stream, d.c, d.ldc, st.buf, d.M, d.N)) return fail(std::string("row_stats: ") + mx_last_error());
     return true;
   }
   void use_ln(mx_gemm_desc& d, const RowStats& st, const std::string& csname) {
@@ -233,7 +242,7 @@ struct Plan {
     void* ws = ar.alloc(need);
     if (!ws) return fail("workspace too small");
     const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
-    if (ok() && !dry) {
+    if (ok() && !quiet()) {
       if (mx_groupnorm_nhwc_cat(stream, x, x2 ? C1 : C, x2, y, g, b, B, h, wd, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, patch, ws))
         fail(std::string("groupnorm: ") + mx_last_error());
     }
@@ -243,14 +252,14 @@ struct Plan {
   bool attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int ldvt, long vt_bstride, bf16_t* o,
                  int ldo, int heads, int Lq, int Lk) {
     if (!ok()) return false;
-    if (dry) return true;
+    if (quiet()) return true;
     // q carries MX_ATTN_QSCALE(1/8) from the producing GEMM's epilogue (out_scale)
     if (mx_attention_prescaled(stream, q, ldq, k, ldk, vt, ldvt, vt_bstride, o, ldo, B, heads, Lq, Lk))
       return fail(std::string("attention: ") + mx_last_error());
     return true;
   }
   void dump(const std::string& name, const bf16_t* t, size_t elems) {
-    if (!stage || dry || !ok() || stage_hit) return;
+    if (!stage || quiet() || !ok() || stage_hit) return;
     if (name != stage) return;
     if (elems * 2 > stage_bytes) { fail("stage buffer too small for '" + name + "'"); return; }
     if (hipMemcpyAsync(stage_out, t, elems * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess) fail("stage copy failed");
@@ -362,7 +371,7 @@ struct Plan {
       pass1 = mx_gemm_ln_prefers_pass(&d1) != 0; pass2 = mx_gemm_ln_prefers_pass(&d2) != 0; pass3 = mx_gemm_ln_prefers_pass(&d3) != 0;
     }
     auto normalise = [&]() {      // ln = (y - mean) * rstd, no affine (it lives in the folded weights)
-      if (ok() && !dry && mx_layernorm(stream, y, ln, nullptr, nullptr, M, C, u->cfg.layer_norm_eps)) fail(std::string("layernorm: ") + mx_last_error());
+      if (ok() && !quiet() && mx_layernorm(stream, y, ln, nullptr, nullptr, M, C, u->cfg.layer_norm_eps)) fail(std::string("layernorm: ") + mx_last_error());
     };
     linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, pass1 ? nullptr : &st);
     // patch-parallel: every rank gathers the other ranks' K rows and V^T columns (modules/pp/attn.py:137: all_gather(kv))
@@ -493,12 +502,12 @@ struct Plan {
     conv(x0, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0);  // patches are cut from the true latent: no corner rule (unet.py:123-158)
     dump("conv_in", x, (size_t)B * h * wd * C0);
 
-    struct Skip { bf16_t* t; int C; };
+    struct Skip { bf16_t* t; int C; int h, wd; };
     std::vector<Skip> skips;
-    skips.push_back({x, C0});
+    skips.push_back({x, C0, h, wd});
     int Ccur = C0;
-    // ---- down (unet.py:371-405) ----
-    for (int i = 0; i < nlev && ok(); ++i) {
+    // The seven blocks the reference wraps with a CacheManager (unet_2d_blocks.py): each body advances x / h / wd / Ccur / skips.
+    auto down_block = [&](int i) {                              // unet.py:371-405
       const int Cout = c.block_out_channels[i];
       for (int j = 0; j < c.layers_per_block && ok(); ++j) {
         const std::string rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
@@ -508,7 +517,7 @@ struct Plan {
           const std::string ap = "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j);
           x = transformer(ap, x, h, wd, Cout, c.num_heads[i], c.transformer_layers[i], i);
         }
-        skips.push_back({x, Cout});
+        skips.push_back({x, Cout, h, wd});
       }
       if (i != nlev - 1) {
         const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0";
@@ -526,18 +535,16 @@ struct Plan {
         h /= 2; wd /= 2;
         x = d;
         dump(dp, x, (size_t)B * h * wd * Cout);
-        skips.push_back({x, Cout});
+        skips.push_back({x, Cout, h, wd});
       }
-    }
-    // ---- mid (unet.py:419-445) ----
-    {
+    };
+    auto mid_block = [&]() {                                    // unet.py:419-445
       const int Cm = c.block_out_channels[nlev - 1];
       x = resnet("mid_block.resnets.0", x, h, wd, Cm, Cm, nlev - 1);
       x = transformer("mid_block.attentions.0", x, h, wd, Cm, c.num_heads[nlev - 1], c.transformer_layers[nlev - 1], nlev - 1);
       x = resnet("mid_block.resnets.1", x, h, wd, Cm, Cm, nlev - 1);
-    }
-    // ---- up (unet.py:458-503) ----
-    for (int i = 0; i < nlev && ok(); ++i) {
+    };
+    auto up_block = [&](int i) {                                // unet.py:458-503
       const int level = nlev - 1 - i;
       const int Cout = c.block_out_channels[level];
       for (int j = 0; j < c.layers_per_block + 1 && ok(); ++j) {
@@ -566,7 +573,80 @@ struct Plan {
         x = d;
         dump(upn, x, (size_t)B * h * wd * Cout);
       }
-    }
+    };
+
+    // Block-skip cache (mx_unet_forward_cached; include/mxdenoise.h): inputs = the tensors the predictor's features come from, body = the
+    // block.  A reused block still walks its plan (mute) so that the arena, the K / V cursors and the time-embedding offset advance as if it
+    // had run; its outputs are then filled from the cache.
+    struct Ten { bf16_t* p; size_t per_sample; };
+    auto run_block = [&](int idx, bool is_up, const std::vector<Ten>& ins, const std::function<void()>& body) {
+      if (!bc) { body(); return; }
+      const int nf = (int)ins.size();
+      if (dry) {                                                 // mx_unet_block_cache_bytes: the same bump pointer, no launches
+        for (int f = 0; f < nf; ++f) bc_top += (ins[f].per_sample * B * 2 + 255) & ~(size_t)255;
+        const size_t n0 = skips.size();
+        body();
+        size_t n_out = 0;
+        bool x_listed = false;
+        if (!is_up) for (size_t k = std::min(n0, skips.size()); k < skips.size(); ++k) {
+          bc_top += ((size_t)skips[k].h * skips[k].wd * skips[k].C * B * 2 + 255) & ~(size_t)255; ++n_out; x_listed = skips[k].t == x;
+        }
+        if (!n_out || !x_listed) bc_top += ((size_t)h * wd * Ccur * B * 2 + 255) & ~(size_t)255;
+        return;
+      }
+      std::vector<float> mse((size_t)B * nf, MX_MSE_UNCACHED);
+      std::vector<char*> in_cache(nf);
+      for (int f = 0; f < nf; ++f) { in_cache[f] = bc_top; bc_top += (ins[f].per_sample * B * 2 + 255) & ~(size_t)255; }
+      if ((size_t)(bc_top - (char*)bc->state) > bc->state_bytes) { fail("block cache: state buffer too small (mx_unet_block_cache_bytes)"); return; }
+      if (bc->cached_valid && ok()) {
+        double* part = (double*)bc->state;                       // the first bc_scratch() bytes of the state
+        for (int f = 0; f < nf && ok(); ++f)
+          if (mx::launch_sq_diff_partial(stream, ins[f].p, in_cache[f], (long)ins[f].per_sample, B, part + (size_t)f * B * 64)) fail(mx_last_error());
+        std::vector<double> hp((size_t)nf * B * 64);
+        if (ok() && (hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                     hipStreamSynchronize(stream) != hipSuccess)) fail("block cache: reading the input differences failed");
+        for (int f = 0; f < nf; ++f)
+          for (int b = 0; b < B; ++b) {
+            double t = 0.0;
+            for (int k = 0; k < 64; ++k) t += hp[((size_t)f * B + b) * 64 + k];
+            mse[(size_t)b * nf + f] = (float)(t / (double)ins[f].per_sample);
+          }
+      }
+      if (!ok()) return;
+      std::vector<unsigned char> run(B, 1);
+      if (bc->predict(bc->ctx, idx, is_up ? 1 : 0, B, nf, h_timesteps.data(), mse.data(), run.data())) { fail("block cache: the predictor failed"); return; }
+      bool any = !bc->cached_valid;
+      for (int b = 0; b < B; ++b) any = any || run[b] != 0;
+      for (int f = 0; f < nf && ok(); ++f)                       // the cached input is always the latest one (cache_manager.py:133,153)
+        if (hipMemcpyAsync(in_cache[f], ins[f].p, ins[f].per_sample * B * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess) fail("block cache: input copy failed");
+      const size_t n_skips0 = skips.size();
+      mute = !any;
+      body();
+      mute = false;
+      // outputs: the hidden state and, for the down blocks, the skip tensors the block pushed
+      std::vector<Ten> outs;
+      if (!is_up) for (size_t k = std::min(n_skips0, skips.size()); k < skips.size(); ++k) outs.push_back({skips[k].t, (size_t)skips[k].h * skips[k].wd * skips[k].C});
+      if (outs.empty() || outs.back().p != x) outs.push_back({x, (size_t)h * wd * Ccur});
+      for (auto& o : outs) {
+        char* oc = bc_top; bc_top += (o.per_sample * B * 2 + 255) & ~(size_t)255;
+        if ((size_t)(bc_top - (char*)bc->state) > bc->state_bytes) { fail("block cache: state buffer too small (mx_unet_block_cache_bytes)"); return; }
+        if (!ok()) return;
+        const hipError_t e = any ? hipMemcpyAsync(oc, o.p, o.per_sample * B * 2, hipMemcpyDeviceToDevice, stream)
+                                 : hipMemcpyAsync(o.p, oc, o.per_sample * B * 2, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) { fail("block cache: output copy failed"); return; }
+      }
+      if (any) blocks_run |= 1u << idx;
+    };
+    auto up_inputs = [&](int n) {
+      std::vector<Ten> v{{x, (size_t)h * wd * Ccur}};
+      for (int k = 0; k < n && k < (int)skips.size(); ++k) { const Skip& sk = skips[skips.size() - 1 - k]; v.push_back({sk.t, (size_t)sk.h * sk.wd * sk.C}); }
+      return v;
+    };
+    int block = 0;
+    if (bc) bc_top = (dry ? (char*)nullptr : (char*)bc->state) + (((size_t)(c.layers_per_block + 2) * B * 64 * sizeof(double) + 255) & ~(size_t)255);
+    for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, false, {{x, (size_t)h * wd * Ccur}}, [&] { down_block(i); });
+    if (ok()) { run_block(block, false, {{x, (size_t)h * wd * Ccur}}, [&] { mid_block(); }); ++block; }
+    for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, true, up_inputs(c.layers_per_block + 1), [&] { up_block(i); });
     // ---- out (unet.py:508-517) ----
     {
       const size_t M = (size_t)B * h * wd;
@@ -716,6 +796,60 @@ extern "C" int mx_unet_forward(mx_unet* u, void* stream, const void* latents, in
                                int W, int ctx_len, int gn_patch, void* workspace, size_t workspace_bytes) {
   return forward_impl(u, stream, latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out, batch, H, W, ctx_len, gn_patch,
                       workspace, workspace_bytes, nullptr, nullptr, 0, false, nullptr);
+}
+
+/* ---- block-skip cache (include/mxdenoise.h; the reference's CacheManager, modules/cache_manager.py:101-161) ---- */
+extern "C" size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, int W) {
+  if (!u || batch <= 0 || H <= 0 || W <= 0) return 0;
+  const int div = 1 << (u->cfg.n_levels - 1);
+  if (H % div || W % div) return 0;
+  Plan p;
+  mx_block_cache sizing{};
+  p.u = const_cast<mx_unet*>(u); p.stream = nullptr; p.B = batch; p.H = H; p.W = W; p.ctx_len = 64; p.gn_patch = 0;
+  p.dry = true; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
+  p.bc = &sizing;
+  if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
+  return (size_t)(p.bc_top - (char*)nullptr) + 256;
+}
+
+extern "C" int mx_unet_forward_cached(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
+                                      const void* text_embeds, const float* time_ids, void* out, int batch, int H, int W, int ctx_len,
+                                      int gn_patch, void* workspace, size_t workspace_bytes, mx_block_cache* cache) {
+  MX_CHECK(u != nullptr, "unet: null handle");
+  MX_CHECK(cache && cache->predict && cache->state, "unet_forward_cached: cache, cache->predict and cache->state are required");
+  MX_CHECK(batch > 0 && H > 0 && W > 0 && ctx_len > 0, "unet: bad shape");
+  const int div = 1 << (u->cfg.n_levels - 1);
+  MX_CHECK(H % div == 0 && W % div == 0, "unet: H, W must be divisible by 2^(levels-1)");
+  MX_CHECK(gn_patch >= 0, "unet: gn_patch must be >= 0");
+  if (gn_patch > 0) {
+    MX_CHECK(H % gn_patch == 0 && W % gn_patch == 0, "unet: H, W must be multiples of gn_patch");
+    MX_CHECK((gn_patch >> (u->cfg.n_levels - 1)) >= 2 || gn_patch >= H, "unet: gn_patch too small for the deepest level (needs >= 2 pixels there)");
+  }
+  MX_CHECK(latents && timesteps && ehs && text_embeds && time_ids && out && workspace, "unet: null operand");
+  MX_CHECK(u->blob != nullptr, "unet: weights not set");
+  MX_CHECK(io_dtype == MX_F32 || io_dtype == MX_F16 || io_dtype == MX_BF16, "unet: bad io dtype");
+  MX_CHECK(((uintptr_t)cache->state & 255) == 0, "unet_forward_cached: cache->state must be 256-byte aligned");
+  cache->cached_valid = cache->cached_valid && cache->cached_key == cache->batch_key && cache->cached_batch == batch && cache->cached_h == H &&
+                        cache->cached_w == W;
+  Plan p;
+  p.u = u; p.stream = (hipStream_t)stream; p.B = batch; p.H = H; p.W = W; p.ctx_len = ctx_len;
+  p.gn_patch = (gn_patch >= H && gn_patch >= W) ? 0 : gn_patch;
+  p.dry = false;
+  p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = false;
+  p.bc = cache;
+  p.h_timesteps.resize(batch);
+  // the predictor's timestep feature: the per-sample timesteps live in device memory like the rest of the step's operands
+  if (hipMemcpyAsync(p.h_timesteps.data(), timesteps, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, p.stream) != hipSuccess ||
+      hipStreamSynchronize(p.stream) != hipSuccess) {
+    cache->cached_valid = 0;
+    mx::set_error("unet_forward_cached: reading the timesteps failed");
+    return 1;
+  }
+  const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
+  cache->blocks_run = p.blocks_run;
+  if (!okr) { cache->cached_valid = 0; mx::set_error(p.err); return 1; }
+  cache->cached_valid = 1; cache->cached_key = cache->batch_key; cache->cached_batch = batch; cache->cached_h = H; cache->cached_w = W;
+  return 0;
 }
 
 extern "C" int mx_unet_forward_trace(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,

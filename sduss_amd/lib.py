@@ -62,6 +62,17 @@ class PPComm(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("all_gather", ALLGATHER_FN), ("ctx", C.c_void_p)]
 
 
+SKIP_PREDICT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                              C.POINTER(C.c_ubyte))
+MSE_UNCACHED = 9.2233720368547758e18
+
+
+class BlockCacheC(C.Structure):
+    _fields_ = [("predict", SKIP_PREDICT_FN), ("ctx", C.c_void_p), ("state", C.c_void_p), ("state_bytes", C.c_size_t),
+                ("batch_key", C.c_uint64), ("cached_key", C.c_uint64), ("cached_valid", C.c_int), ("cached_batch", C.c_int),
+                ("cached_h", C.c_int), ("cached_w", C.c_int), ("blocks_run", C.c_uint)]
+
+
 class CLIPConfigC(C.Structure):
     _fields_ = [("vocab_size", C.c_int), ("hidden_size", C.c_int), ("intermediate_size", C.c_int), ("num_hidden_layers", C.c_int),
                 ("num_attention_heads", C.c_int), ("max_position_embeddings", C.c_int), ("hidden_act", C.c_int), ("projection_dim", C.c_int),
@@ -110,6 +121,8 @@ SYMBOLS = {
     "mx_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_unet_validate": (_i, [_vp, _i, _i, _i, _i]),
     "mx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
+    "mx_unet_block_cache_bytes": (_sz, [_vp, _i, _i, _i]),
+    "mx_unet_forward_cached": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mx_unet_forward_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz,
                                    C.c_char_p, _vp, _sz]),
     "mx_unet_workspace_bytes_pp": (_sz, [_vp, _i, _i, _i, _i, _i]),

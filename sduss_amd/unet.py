@@ -120,6 +120,35 @@ class MxUNet:
                                                    st.numel() * 2), "mx_unet_forward_trace")
         return st
 
+    def forward_one_cached(self, cache, sample: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                           text_embeds: torch.Tensor, time_ids: torch.Tensor, batch_key: int, gn_patch: int = 0) -> torch.Tensor:
+        """forward_one through the block-skip cache (sduss_amd/block_cache.py BlockSkipCache; the reference's ESYMRED_USE_CACHE=TRUE
+        path, cache_manager.py:101-161).  Approximate by design; forward_one never consults it."""
+        assert sample.is_cuda and sample.ndim == 4
+        sample = sample.contiguous()
+        b, _c, h, w = sample.shape
+        ctx_len = encoder_hidden_states.shape[1]
+        ts = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+        if ts.numel() == 1:
+            ts = ts.expand(b)
+        ts = ts.contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        te = text_embeds.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        ti = time_ids.to(device=self.device, dtype=torch.float32).contiguous()
+        assert ts.shape[0] == b and ehs.shape[0] == b and te.shape[0] == b and ti.shape == (b, 6)
+        out = torch.empty((b, self.cfg.out_channels, h, w), dtype=sample.dtype, device=self.device)
+        stream = _lib.current_stream()
+        ws = self._workspace(b, h, w, ctx_len, int(stream or 0))
+        desc = cache.bind(self, b, h, w, batch_key)
+        rc = self._lib.mx_unet_forward_cached(self._handle, stream, sample.data_ptr(), _lib.torch_dtype_code(sample.dtype),
+                                              ts.data_ptr(), ehs.data_ptr(), te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, h, w,
+                                              ctx_len, gn_patch, ws.data_ptr(), ws.numel(), desc)
+        if rc and cache.error is not None:
+            raise cache.error                 # the predictor's own exception, not the library's "predictor failed"
+        _lib.check(rc, "mx_unet_forward_cached")
+        cache.after_forward()
+        return out
+
     def forward(self, sample: Dict[str, torch.Tensor], timestep, encoder_hidden_states: torch.Tensor,
                 class_labels=None, timestep_cond=None, attention_mask=None, cross_attention_kwargs=None,
                 added_cond_kwargs: Optional[dict] = None, down_block_additional_residuals=None,

@@ -1,0 +1,205 @@
+"""Block-skip cache (mx_unet_forward_cached; the reference's CacheManager, modules/cache_manager.py:101-161) on the GPU.
+
+The cache is approximate by design, so parity is stated through what must hold exactly:
+  * a predictor that always answers "run" gives mx_unet_forward's output bit for bit (the block bodies are the same launches);
+  * a block that is reused returns exactly the tensors it produced at its last run -- with every block reused, the step's output
+    equals the previous step's output bit for bit even though the latents differ;
+  * the forced run after four reuses, the per-block decisions and the invalidation by batch key follow cache_manager.py:128-136;
+  * the input differences the predictor sees equal torch's MSELoss on the same tensors (first block: the conv_in output is not
+    observable, so the check uses the property mse(x, x) == 0 and the uncached marker)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sdxl_unet_ref as ref  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def tiny(cuda_device):
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.unet import MxUNet
+    ocfg = ref.UNetConfig.tiny()
+    P = ref.init_params(ocfg)
+    return ocfg, MxUNet(UNetConfig.tiny(), P, device="cuda:0")
+
+
+class Always:
+    def __init__(self, v):
+        self.v, self.rows = v, []
+
+    def predict(self, f):
+        self.rows.append(np.array(f))
+        return np.full(len(f), self.v)
+
+
+def _inputs(ocfg, batch, hw, seed=0):
+    s, t, e, te, ti = ref.make_inputs(ocfg, batch, hw)
+    g = torch.Generator().manual_seed(100 + seed)
+    s = s + 0.05 * seed * torch.randn(s.shape, generator=g)
+    return s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda()
+
+
+@pytest.mark.parametrize("batch,hw,gn_patch", [(2, 32, 0), (3, 24, 0), (2, 32, 16)])
+def test_always_run_is_the_exact_forward(tiny, batch, hw, gn_patch):
+    from sduss_amd.block_cache import BlockSkipCache, MSE_UNCACHED
+    ocfg, net = tiny
+    pred = Always(1)
+    bc = BlockSkipCache(pred)
+    for step in range(3):
+        s, t, e, te, ti = _inputs(ocfg, batch, hw, step)
+        want = net.forward_one(s, t, e, te, ti, gn_patch=gn_patch)
+        got = net.forward_one_cached(bc, s, t, e, te, ti, batch_key=7, gn_patch=gn_patch)
+        assert torch.equal(got, want), f"step {step}: cached path with every block run differs from mx_unet_forward"
+        assert bc.history[-1] == 0x7f
+    # seven feature matrices per step; first step uncached, later steps carry finite differences; up blocks have 1 + 3 differences
+    assert len(pred.rows) == 21
+    assert all((r[:, 2:] >= MSE_UNCACHED * 0.5).all() for r in pred.rows[:7])
+    assert all(np.isfinite(r).all() and (r[:, 2:] < 1e6).all() for r in pred.rows[7:])
+    assert [r.shape[1] for r in pred.rows[:7]] == [3, 3, 3, 3, 6, 6, 6]
+    assert [int(r[0, 0]) for r in pred.rows[:7]] == list(range(7))
+    assert np.allclose(pred.rows[0][:, 1], t.float().cpu().numpy())
+
+
+def test_first_block_difference_is_the_mse_of_its_input(tiny):
+    """down block 0 sees conv_in(latents): identical latents give exactly 0, and scaling the change scales the mse by its square."""
+    from sduss_amd.block_cache import BlockSkipCache
+    ocfg, net = tiny
+    pred = Always(1)
+    bc = BlockSkipCache(pred)
+    s, t, e, te, ti = _inputs(ocfg, 2, 32)
+    d = torch.randn_like(s.float())
+    d[1] = 0                                              # the second sample does not change
+    net.forward_one_cached(bc, s.float(), t, e, te, ti, batch_key=1)
+    net.forward_one_cached(bc, s.float() + 0.25 * d, t, e, te, ti, batch_key=1)
+    m1 = pred.rows[7][:, 2].copy()
+    net.forward_one_cached(bc, s.float(), t, e, te, ti, batch_key=1)      # back: the same distance again
+    m2 = pred.rows[14][:, 2].copy()
+    net.forward_one_cached(bc, s.float(), t, e, te, ti, batch_key=1)      # unchanged input
+    m3 = pred.rows[21][:, 2].copy()
+    assert m1[0] > 0 and m1[1] == 0.0 and m3.tolist() == [0.0, 0.0]
+    assert abs(m2[0] - m1[0]) <= 1e-3 * m1[0]
+    # conv_in is linear and the bias cancels in the difference: mse == mean(conv(0.25 d)^2), bf16 rounding of the two stored inputs aside
+    import torch.nn.functional as F
+    P = ref.init_params(ocfg)
+    y = F.conv2d(0.25 * d[:1].cpu(), P["conv_in.weight"].float(), None, padding=1)
+    want = float((y ** 2).mean())
+    assert abs(m1[0] - want) <= 0.05 * want, (m1[0], want)
+
+
+def test_all_blocks_reused_returns_the_previous_output(tiny):
+    from sduss_amd.block_cache import BlockSkipCache
+    ocfg, net = tiny
+    pred = Always(1)
+    bc = BlockSkipCache(pred)
+    s0, t, e, te, ti = _inputs(ocfg, 2, 32, 0)
+    out0 = net.forward_one_cached(bc, s0, t, e, te, ti, batch_key=3)
+    pred.v = 0
+    outs = []
+    for step in range(1, 7):
+        s, *_ = _inputs(ocfg, 2, 32, step)
+        outs.append(net.forward_one_cached(bc, s, t, e, te, ti, batch_key=3))
+    # four reuses, the forced run at the fifth call (cache_manager.py:134), then reuse again
+    assert [h for h in bc.history] == [0x7f, 0, 0, 0, 0, 0x7f, 0]
+    for k in range(4):
+        assert torch.equal(outs[k], out0)
+    s5, *_ = _inputs(ocfg, 2, 32, 5)
+    assert torch.equal(outs[4], net.forward_one(s5, t, e, te, ti))
+    assert torch.equal(outs[5], outs[4])
+
+
+def test_partial_reuse_recomputes_only_what_was_asked(tiny):
+    """up blocks reused, down and mid run: the output is the up path's cached output, and a later full run is exact again; a block runs
+    when ANY sample of the batch asks (batch-level granularity)."""
+    from sduss_amd.block_cache import BlockSkipCache
+    ocfg, net = tiny
+
+    class Split:
+        def __init__(self):
+            self.run_up = 1
+            self.one_sample = False
+
+        def predict(self, f):
+            f = np.asarray(f)
+            if f.shape[1] == 3:
+                return np.ones(len(f))
+            if self.one_sample:
+                m = np.zeros(len(f)); m[-1] = 1
+                return m
+            return np.full(len(f), self.run_up)
+    pred = Split()
+    bc = BlockSkipCache(pred)
+    s0, t, e, te, ti = _inputs(ocfg, 2, 32, 0)
+    out0 = net.forward_one_cached(bc, s0, t, e, te, ti, batch_key=9)
+    pred.run_up = 0
+    s1, *_ = _inputs(ocfg, 2, 32, 1)
+    out1 = net.forward_one_cached(bc, s1, t, e, te, ti, batch_key=9)
+    assert bc.history[-1] == 0x0f and torch.equal(out1, out0)
+    pred.one_sample = True
+    out2 = net.forward_one_cached(bc, s1, t, e, te, ti, batch_key=9)
+    assert bc.history[-1] == 0x7f and torch.equal(out2, net.forward_one(s1, t, e, te, ti))
+    # only the last up block reused: its cached output is the hidden state conv_out sees -> the output of the step before
+    class LastUp(Split):
+        def predict(self, f):
+            f = np.asarray(f)
+            return np.zeros(len(f)) if int(f[0, 0]) == 6 else np.ones(len(f))
+    bc2 = BlockSkipCache(LastUp())
+    a = net.forward_one_cached(bc2, s0, t, e, te, ti, batch_key=9)
+    b = net.forward_one_cached(bc2, s1, t, e, te, ti, batch_key=9)
+    assert bc2.history == [0x7f, 0x3f] and torch.equal(a, b)
+    # only the mid block reused: everything downstream is recomputed from the cached mid output and the fresh skips -> neither step's output
+    class Mid(Split):
+        def predict(self, f):
+            f = np.asarray(f)
+            return np.zeros(len(f)) if int(f[0, 0]) == 3 else np.ones(len(f))
+    bc3 = BlockSkipCache(Mid())
+    a = net.forward_one_cached(bc3, s0, t, e, te, ti, batch_key=9)
+    b = net.forward_one_cached(bc3, s1, t, e, te, ti, batch_key=9)
+    exact = net.forward_one(s1, t, e, te, ti)
+    assert bc3.history == [0x7f, 0x77] and not torch.equal(b, a) and not torch.equal(b, exact)
+    rel = ((b.float() - exact.float()).norm() / exact.float().norm()).item()
+    assert rel < 0.5, rel                        # an approximation of the exact step, not garbage
+
+
+def test_batch_key_and_shape_invalidate(tiny):
+    from sduss_amd.block_cache import BlockSkipCache
+    ocfg, net = tiny
+    pred = Always(0)
+    bc = BlockSkipCache(pred)
+    s0, t, e, te, ti = _inputs(ocfg, 2, 32, 0)
+    net.forward_one_cached(bc, s0, t, e, te, ti, batch_key=1)
+    s1, *_ = _inputs(ocfg, 2, 32, 1)
+    net.forward_one_cached(bc, s1, t, e, te, ti, batch_key=1)
+    got = net.forward_one_cached(bc, s1, t, e, te, ti, batch_key=2)           # another batch composition: nothing may be reused
+    assert bc.history == [0x7f, 0, 0x7f] and torch.equal(got, net.forward_one(s1, t, e, te, ti))
+    s3, t3, e3, te3, ti3 = _inputs(ocfg, 3, 24, 0)
+    got = net.forward_one_cached(bc, s3, t3, e3, te3, ti3, batch_key=2)       # another shape
+    assert bc.history[-1] == 0x7f and torch.equal(got, net.forward_one(s3, t3, e3, te3, ti3))
+
+
+def test_predictor_failure_and_bad_arguments_are_reported(tiny):
+    from sduss_amd import lib
+    from sduss_amd.block_cache import BlockSkipCache
+    ocfg, net = tiny
+
+    class Broken:
+        def predict(self, f):
+            raise ValueError("predictor file missing")
+    s0, t, e, te, ti = _inputs(ocfg, 2, 32, 0)
+    with pytest.raises(ValueError, match="predictor file missing"):
+        net.forward_one_cached(BlockSkipCache(Broken()), s0, t, e, te, ti, batch_key=1)
+    bc = BlockSkipCache(Always(1))
+    net.forward_one_cached(bc, s0, t, e, te, ti, batch_key=1)
+    bc.desc.state_bytes = 4096
+    l = lib.load()
+    ws = net._workspace(2, 32, 32, e.shape[1], int(lib.current_stream() or 0))
+    out = torch.empty_like(s0)
+    ts = t.float().reshape(-1).expand(2).contiguous() if t.numel() == 1 else t.float().contiguous()
+    import ctypes as C
+    rc = l.mx_unet_forward_cached(net._handle, lib.current_stream(), s0.data_ptr(), lib.torch_dtype_code(s0.dtype), ts.data_ptr(),
+                                  e.to(torch.bfloat16).contiguous().data_ptr(), te.to(torch.bfloat16).contiguous().data_ptr(),
+                                  ti.float().contiguous().data_ptr(), out.data_ptr(), 2, 32, 32, e.shape[1], 0, ws.data_ptr(), ws.numel(),
+                                  C.byref(bc.desc))
+    assert rc != 0 and b"state buffer too small" in l.mx_last_error() and bc.desc.cached_valid == 0
+    torch.cuda.synchronize()

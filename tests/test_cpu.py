@@ -5,6 +5,7 @@ import os
 import re
 
 import pytest
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -455,3 +456,77 @@ def test_t5_plan_resolves_packed_weights_on_host():
     pb = position_bias(cfg, P["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], 100)
     assert pb.shape == (cfg.num_heads, 100, 128) and float(pb[:, :, 100:].abs().max()) == 0.0
     assert abs(float(pb[1, 10, 10]) - 1.4426950408889634 * 1.0) < 1e-5          # bucket 0 (offset 0), head 1 -> weight[0, 1] = 1
+
+
+def test_block_skip_decisions_follow_the_reference_counters():
+    """cache_manager.py:134-136: a sample that reused a block four times in a row runs it; the counter resets on a run."""
+    from sduss_amd.block_cache import BlockSkipCache, ThresholdPredictor, decide, MSE_UNCACHED
+    run, prev = decide(np.array([0, 0, 1, 0]), np.array([4, 3, 2, 0]))
+    assert run.tolist() == [True, False, True, False] and prev.tolist() == [0, 4, 0, 1]
+    # five steps of "never run": reuse x4 then the forced run
+    prev = np.zeros(1, dtype=np.int64)
+    seen = []
+    for _ in range(11):
+        run, prev = decide(np.array([0]), prev)
+        seen.append(bool(run[0]))
+    assert seen == [False] * 4 + [True] + [False] * 4 + [True, False]
+    # the callback builds the reference's feature rows and treats an uncached sample as a fresh counter
+    rows = []
+
+    class Spy:
+        def predict(self, f):
+            rows.append(np.array(f)); return np.zeros(len(f))
+    bc = BlockSkipCache(Spy())
+    fp = C.POINTER(C.c_float)                      # what the library hands to the callback
+    ts = C.cast((C.c_float * 2)(981.0, 961.0), fp)
+    mse = C.cast((C.c_float * 8)(*([0.5, 0.1, 0.2, 0.3] + [MSE_UNCACHED] * 4)), fp)
+    out = (C.c_ubyte * 2)(9, 9)
+    assert bc._predict(None, 5, 1, 2, 4, ts, mse, out) == 0
+    assert rows[0].shape == (2, 6) and rows[0][0].tolist()[:3] == [5.0, 981.0, 0.5] and list(out) == [0, 0]
+    assert ThresholdPredictor(0.25).predict(rows[0]).tolist() == [1, 1]
+    assert ThresholdPredictor(0.6).predict(rows[0][:1]).tolist() == [0]
+
+    class Broken:
+        def predict(self, f):
+            raise RuntimeError("no model")
+    bc = BlockSkipCache(Broken())
+    assert bc._predict(None, 0, 0, 2, 1, ts, mse, out) == 1 and isinstance(bc.error, RuntimeError)
+
+
+def test_block_cache_state_size_is_the_sum_of_block_inputs_and_outputs(tiny):
+    """mx_unet_block_cache_bytes walks the plan without launches: it must equal the inputs and outputs of the seven blocks."""
+    from sduss_amd import config, lib
+    l = lib.load()
+    pcfg = config.UNetConfig.tiny()
+    cc = lib.UNetConfigC()
+    cc.in_channels, cc.out_channels, cc.n_levels, cc.layers_per_block = 4, 4, 3, 2
+    for i, v in enumerate(pcfg.block_out_channels):
+        cc.block_out_channels[i] = v; cc.down_has_attn[i] = int(pcfg.down_has_attn[i])
+        cc.transformer_layers[i] = pcfg.transformer_layers_per_block[i]; cc.num_heads[i] = pcfg.num_heads[i]
+    cc.cross_attention_dim, cc.addition_time_embed_dim = pcfg.cross_attention_dim, pcfg.addition_time_embed_dim
+    cc.projection_class_embeddings_input_dim, cc.norm_num_groups = pcfg.projection_class_embeddings_input_dim, 32
+    h = l.mx_unet_create(C.byref(cc))
+    B, H = 3, 24
+    r256 = lambda n: (n + 255) // 256 * 256
+    ten = lambda hw, ch: r256(B * hw * hw * ch * 2)
+    ch = list(pcfg.block_out_channels)
+    want = r256(4 * B * 64 * 8)
+    hw, cin, skips = H, ch[0], [(H, ch[0])]
+    for i in range(3):
+        want += ten(hw, cin)
+        for _ in range(2):
+            want += ten(hw, ch[i]); skips.append((hw, ch[i]))
+        if i != 2:
+            hw //= 2; want += ten(hw, ch[i]); skips.append((hw, ch[i]))
+        cin = ch[i]
+    want += 2 * ten(hw, cin)
+    for i in range(3):
+        want += ten(hw, cin) + sum(ten(*skips[-1 - k]) for k in range(3))
+        del skips[-3:]
+        cin = ch[2 - i]
+        if i != 2:
+            hw *= 2
+        want += ten(hw, cin)
+    assert l.mx_unet_block_cache_bytes(h, B, H, H) == want + 256
+    assert l.mx_unet_block_cache_bytes(h, B, 25, 24) == 0
+    l.mx_unet_destroy(h)
