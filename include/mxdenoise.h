@@ -421,8 +421,10 @@ int mx_t5_encode(mx_t5* t, void* stream, const int32_t* ids, void* out, int batc
  * mean squared difference.  The host predictor sees the reference's feature rows [block index, timestep, mse (, mse of each skip)] and answers
  * run / reuse per sample; a reused block's outputs (hidden state and, for the down blocks, the skip tensors) come from the cache.
  * Approximate by design and OFF on the exact path (mx_unet_forward never consults it).
- * Granularity here: the step batch -- a block is reused only when NO sample of the batch asks to run it (the reference compacts the batch per
- * block; exact for single-request steps, conservative otherwise).  The cached state belongs to one batch composition: a different
+ * Granularity: the step batch, as the reference's block-level caches -- a block's outputs come from the cache only when NO sample asks to run
+ * it (save_and_get_block_states: mask.sum() == 0, cache_manager.py:60-67).  When a block runs here it runs for every sample; the reference
+ * additionally drops the not-asking samples inside the block's attention layers (attention.py:104,224,415), a further approximation that is
+ * not reproduced.  The cached state belongs to one batch composition: a different
  * batch_key, batch size or latent size invalidates it (every block runs once and refills it).  Not combined with patch parallelism.
  *   predict(ctx, block, is_up, n_samples, n_feat, timesteps[n], mse[n * n_feat], run_out[n]): mse = MX_MSE_UNCACHED when the block has no
  *   cached input; return non-zero to abort the forward.  The reference's predictors are cuML random forests that are not loadable here:
@@ -441,11 +443,19 @@ typedef struct mx_block_cache {
   uint64_t cached_key;        /* library-owned from here on: zero-initialise the struct once */
   int cached_valid, cached_batch, cached_h, cached_w;
   unsigned blocks_run;        /* out: bit i set = block i ran in the last forward */
+  unsigned blocks_run_hi;     /* out: blocks 32..63 (MMDiT) */
 } mx_block_cache;
 size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, int W);
 int mx_unet_forward_cached(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
                            const void* encoder_hidden_states, const void* text_embeds, const float* time_ids, void* out,
                            int batch, int H, int W, int ctx_len, int gn_patch, void* workspace, size_t workspace_bytes, mx_block_cache* cache);
+/* The same for the SD3 / SD3.5 transformer: one cache point per joint block (SD3Transformer.py:54-57, 151, 172, 219-228 with
+ * cache_manager.py:163-191): the feature row is [block index, timestep, mse of the image stream]; a reused block restores both the image and
+ * the context stream it produced.  The reference forces a run after TWO reuses here (cache_manager.py:184). */
+size_t mx_mmdit_block_cache_bytes(const mx_mmdit* u, int batch, int H, int W, int ctx_len);
+int mx_mmdit_forward_cached(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
+                            const void* encoder_hidden_states, const void* pooled_projections, void* out, int batch, int H, int W,
+                            int ctx_len, void* workspace, size_t workspace_bytes, mx_block_cache* cache);
 
 /* ------------------------------------------------------------------------------------------
  * The element-wise steps either side of the model call.

@@ -21,7 +21,8 @@ import torch
 from . import lib as _lib
 
 MSE_UNCACHED = float(np.float32(_lib.MSE_UNCACHED))
-FORCED_RUN_AFTER = 4          # cache_manager.py:134,154 (SDXL; the SD3 manager uses 2, cache_manager.py:184)
+FORCED_RUN_AFTER = 4          # cache_manager.py:134,154 (SDXL)
+FORCED_RUN_AFTER_SD3 = 2      # cache_manager.py:184-186
 
 
 class ThresholdPredictor:
@@ -50,8 +51,6 @@ def decide(mask: np.ndarray, previous: np.ndarray, forced_after: int = FORCED_RU
 class BlockSkipCache:
     """State for one stream of steps over one batch composition.  ``down`` decides the down and mid blocks, ``up`` the up blocks
     (downsample_predictor / upsample_predictor of the reference)."""
-
-    N_BLOCKS = 7
 
     def __init__(self, down, up=None, forced_after: int = FORCED_RUN_AFTER):
         self.down, self.up = down, (up if up is not None else down)
@@ -84,10 +83,15 @@ class BlockSkipCache:
             self.error = e
             return 1
 
-    def bind(self, unet, batch: int, h: int, w: int, batch_key: int):
-        need = unet._lib.mx_unet_block_cache_bytes(unet._handle, batch, h, w)
+    def bind(self, model, batch: int, h: int, w: int, batch_key: int, ctx_len: Optional[int] = None):
+        """size / (re)allocate the device state for `model` (MxUNet, or MxMMDiT when ctx_len is given) and return the descriptor"""
+        unet = model
+        if ctx_len is None:
+            need = model._lib.mx_unet_block_cache_bytes(model._handle, batch, h, w)
+        else:
+            need = model._lib.mx_mmdit_block_cache_bytes(model._handle, batch, h, w, ctx_len)
         if need == 0:
-            raise _lib.MxError("mx_unet_block_cache_bytes: " + unet._lib.mx_last_error().decode())
+            raise _lib.MxError("block_cache_bytes: " + model._lib.mx_last_error().decode())
         if self.state is None or self.state.numel() < need:
             self.state = torch.empty(need, dtype=torch.uint8, device=unet.device)
             self.desc.cached_valid = 0
@@ -101,7 +105,7 @@ class BlockSkipCache:
         return C.byref(self.desc)
 
     def after_forward(self):
-        self.history.append(int(self.desc.blocks_run))
+        self.history.append(int(self.desc.blocks_run) | int(self.desc.blocks_run_hi) << 32)
 
     def invalidate(self):
         self.desc.cached_valid = 0
@@ -109,4 +113,4 @@ class BlockSkipCache:
 
     @staticmethod
     def blocks_of(mask: int) -> Sequence[int]:
-        return [i for i in range(BlockSkipCache.N_BLOCKS) if mask >> i & 1]
+        return [i for i in range(64) if mask >> i & 1]

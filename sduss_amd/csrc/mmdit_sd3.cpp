@@ -30,6 +30,7 @@ int launch_patchify(hipStream_t s, const void* in, int dtype, void* out, int B, 
 int launch_unpatchify(hipStream_t s, const void* in, void* out, int dtype, int B, int C, int H, int W, int ps, int ld);
 int launch_crop_pos(hipStream_t s, const void* table, void* out, int m, int h, int w, int d);
 int launch_sinus_embed(hipStream_t s, const float* t, void* out, int B, int dim);
+int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial);
 }  // namespace mx
 
 using mx::bf16_t;
@@ -61,6 +62,12 @@ struct Plan {
   Arena ar;
   int B, H, W, Lt;
   bool dry, lookup = false;
+  bool mute = false;               // block-skip cache: the block is reused, nothing of it is launched
+  bool quiet() const { return dry || mute; }
+  mx_block_cache* bc = nullptr;    // mx_mmdit_forward_cached
+  size_t bc_bytes = 0;             // state bytes the plan needs (also the dry answer of mx_mmdit_block_cache_bytes)
+  unsigned long long blocks_run = 0;
+  std::vector<float> h_timesteps;
   const char* stage = nullptr; void* stage_out = nullptr; size_t stage_bytes = 0; bool stage_hit = false;
   std::string err;
 
@@ -85,7 +92,7 @@ struct Plan {
   }
   bool gemm(mx_gemm_desc& d) {
     if (!ok()) return false;
-    if (dry) return true;
+    if (quiet()) return true;
     if (mx_gemm(stream, &d)) return fail(std::string("gemm: ") + mx_last_error());
     return true;
   }
@@ -113,21 +120,21 @@ struct Plan {
   bool lnmod(const bf16_t* x, bf16_t* y, bf16_t* y2, const float* scale, const float* shift, const float* scale2,
              const float* shift2, int ldmod, int M, int C, int rows_per_batch) {
     if (!ok()) return false;
-    if (dry) return true;
+    if (quiet()) return true;
     if (mx_layernorm_mod(stream, x, y, y2, scale, shift, scale2, shift2, ldmod, M, C, rows_per_batch, u->cfg.norm_eps))
       return fail(std::string("layernorm_mod: ") + mx_last_error());
     return true;
   }
   bool attention(const bf16_t* qk, int d_model, const bf16_t* vt, int ldvt, bf16_t* o, int heads, int L) {
     if (!ok()) return false;
-    if (dry) return true;
+    if (quiet()) return true;
     // q carries MX_ATTN_QSCALE(1/8) from the QKV epilogue (RMSNorm + out_scale)
     if (mx_attention_prescaled(stream, qk, 2 * d_model, qk + d_model, 2 * d_model, vt, ldvt, (int64_t)d_model * ldvt, o, d_model, B, heads, L, L))
       return fail(std::string("attention: ") + mx_last_error());
     return true;
   }
   void dump(const std::string& name, const bf16_t* t, size_t elems) {
-    if (!stage || dry || !ok() || stage_hit) return;
+    if (!stage || quiet() || !ok() || stage_hit) return;
     if (name != stage) return;
     if (elems * 2 > stage_bytes) { fail("stage buffer too small for '" + name + "'"); return; }
     if (hipMemcpyAsync(stage_out, t, elems * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess) fail("stage copy failed");
@@ -200,9 +207,56 @@ struct Plan {
     bf16_t* ff = alloc<bf16_t>((size_t)MI * 4 * d);
     bf16_t* ffc = alloc<bf16_t>((size_t)MT * 4 * d);
 
+    // Block-skip cache (mx_mmdit_forward_cached; the reference's per-block CacheManagers, SD3Transformer.py:54-57,151,172,219-228): a block
+    // runs when any sample asks (state_mask.sum() > 0), otherwise the image and context streams take the values the block produced last
+    // time.  State per block: [input x | output x | output context], each 256-byte aligned, after the comparison scratch.
+    const size_t bc_x = ((size_t)MI * d * 2 + 255) & ~(size_t)255, bc_c = ((size_t)MT * d * 2 + 255) & ~(size_t)255;
+    const size_t bc_scratch = ((size_t)B * 64 * sizeof(double) + 255) & ~(size_t)255;
+    if (bc) {
+      bc_bytes = bc_scratch + (size_t)c.num_layers * (2 * bc_x + bc_c);
+      if (!dry && bc_bytes > bc->state_bytes) fail("block cache: state buffer too small (mx_mmdit_block_cache_bytes)");
+    }
+    // decides block i; false = reuse.  Leaves the latest input in the cache (cache_manager.py:183)
+    auto decide = [&](int i) -> bool {
+      char* st = (char*)bc->state + bc_scratch + (size_t)i * (2 * bc_x + bc_c);
+      std::vector<float> mse(B, MX_MSE_UNCACHED);
+      if (bc->cached_valid) {
+        double* part = (double*)bc->state;
+        std::vector<double> hp((size_t)B * 64);
+        if (mx::launch_sq_diff_partial(stream, x, st, (long)L * d, B, part)) { fail(mx_last_error()); return true; }
+        if (hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) { fail("block cache: reading the input differences failed"); return true; }
+        for (int s = 0; s < B; ++s) {
+          double t = 0.0;
+          for (int k = 0; k < 64; ++k) t += hp[(size_t)s * 64 + k];
+          mse[s] = (float)(t / ((double)L * d));
+        }
+      }
+      std::vector<unsigned char> run(B, 1);
+      if (bc->predict(bc->ctx, i, 0, B, 1, h_timesteps.data(), mse.data(), run.data())) { fail("block cache: the predictor failed"); return true; }
+      bool any = !bc->cached_valid;
+      for (int s = 0; s < B; ++s) any = any || run[s] != 0;
+      if (hipMemcpyAsync(st, x, (size_t)MI * d * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess) fail("block cache: input copy failed");
+      return any;
+    };
+    auto after = [&](int i, bool ran, bool last) {
+      char* st = (char*)bc->state + bc_scratch + (size_t)i * (2 * bc_x + bc_c);
+      hipError_t e = ran ? hipMemcpyAsync(st + bc_x, x, (size_t)MI * d * 2, hipMemcpyDeviceToDevice, stream)
+                         : hipMemcpyAsync(x, st + bc_x, (size_t)MI * d * 2, hipMemcpyDeviceToDevice, stream);
+      if (e == hipSuccess && !last)
+        e = ran ? hipMemcpyAsync(st + 2 * bc_x, ctx, (size_t)MT * d * 2, hipMemcpyDeviceToDevice, stream)
+                : hipMemcpyAsync(ctx, st + 2 * bc_x, (size_t)MT * d * 2, hipMemcpyDeviceToDevice, stream);
+      if (e != hipSuccess) fail("block cache: output copy failed");
+      if (ran) blocks_run |= 1ull << i;
+    };
+
     for (int i = 0; i < c.num_layers && ok(); ++i) {
       const std::string b = "transformer_blocks." + std::to_string(i);
       const bool dual = c.dual_attention[i] != 0, last = i == c.num_layers - 1;
+      const bool cached = bc != nullptr && !dry;
+      const bool ran = cached ? decide(i) : true;
+      if (!ok()) break;
+      mute = !ran;
       const float* mi = mod + off_img[i];   // chunks: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp[, shift2, scale2, gate2]
       const float* mc = mod + off_ctx[i];
       // AdaLN-Zero(-X) on the image stream, AdaLN-Zero / -continuous on the context stream (transformer.py:316-328)
@@ -232,6 +286,8 @@ struct Plan {
         dump(b + ".context", ctx, (size_t)MT * d);
       }
       dump(b, x, (size_t)MI * d);
+      mute = false;
+      if (cached && ok()) after(i, ran, last);
     }
     // ---- norm_out (AdaLN-continuous) + proj_out + unpatchify (SD3Transformer.py:238-259) ----
     lnmod(x, xin, nullptr, mod + off_out, mod + off_out + d, nullptr, nullptr, ntot, MI, d, L);
@@ -340,6 +396,53 @@ extern "C" int mx_mmdit_forward(mx_mmdit* u, void* stream, const void* latents, 
                                 void* workspace, size_t workspace_bytes) {
   return forward_impl(u, stream, latents, io_dtype, timesteps, ehs, pooled, out, batch, H, W, ctx_len, workspace, workspace_bytes,
                       nullptr, nullptr, 0, false, nullptr);
+}
+
+/* ---- block-skip cache (include/mxdenoise.h; SD3Transformer.py:151-228 with cache_manager.py:163-191) ---- */
+extern "C" size_t mx_mmdit_block_cache_bytes(const mx_mmdit* u, int batch, int H, int W, int ctx_len) {
+  if (!u || batch <= 0 || H <= 0 || W <= 0 || ctx_len <= 0 || H % u->cfg.patch_size || W % u->cfg.patch_size) return 0;
+  Plan p;
+  mx_block_cache sizing{};
+  p.u = const_cast<mx_mmdit*>(u); p.stream = nullptr; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
+  p.dry = true; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
+  p.bc = &sizing;
+  if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
+  return p.bc_bytes;
+}
+
+extern "C" int mx_mmdit_forward_cached(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
+                                       const void* pooled, void* out, int batch, int H, int W, int ctx_len, void* workspace,
+                                       size_t workspace_bytes, mx_block_cache* cache) {
+  MX_CHECK(u != nullptr, "mmdit: null handle");
+  MX_CHECK(cache && cache->predict && cache->state, "mmdit_forward_cached: cache, cache->predict and cache->state are required");
+  MX_CHECK(u->cfg.num_layers <= 64, "mmdit_forward_cached: at most 64 blocks");
+  MX_CHECK(batch > 0 && H > 0 && W > 0 && ctx_len > 0, "mmdit: bad shape");
+  MX_CHECK(H % u->cfg.patch_size == 0 && W % u->cfg.patch_size == 0, "mmdit: H, W must be multiples of patch_size");
+  MX_CHECK(H / u->cfg.patch_size <= u->cfg.pos_embed_max_size && W / u->cfg.patch_size <= u->cfg.pos_embed_max_size, "mmdit: latent larger than the positional table");
+  MX_CHECK(latents && timesteps && ehs && pooled && out && workspace, "mmdit: null operand");
+  MX_CHECK(u->blob != nullptr, "mmdit: weights not set");
+  MX_CHECK(io_dtype == MX_F32 || io_dtype == MX_F16 || io_dtype == MX_BF16, "mmdit: bad io dtype");
+  MX_CHECK(((uintptr_t)cache->state & 255) == 0, "mmdit_forward_cached: cache->state must be 256-byte aligned");
+  cache->cached_valid = cache->cached_valid && cache->cached_key == cache->batch_key && cache->cached_batch == batch && cache->cached_h == H &&
+                        cache->cached_w == W;
+  Plan p;
+  p.u = u; p.stream = (hipStream_t)stream; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
+  p.dry = false;
+  p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = false;
+  p.bc = cache;
+  p.h_timesteps.resize(batch);
+  if (hipMemcpyAsync(p.h_timesteps.data(), timesteps, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, p.stream) != hipSuccess ||
+      hipStreamSynchronize(p.stream) != hipSuccess) {
+    cache->cached_valid = 0;
+    mx::set_error("mmdit_forward_cached: reading the timesteps failed");
+    return 1;
+  }
+  const bool okr = p.run(latents, io_dtype, timesteps, ehs, pooled, out);
+  cache->blocks_run = (unsigned)p.blocks_run;
+  cache->blocks_run_hi = (unsigned)(p.blocks_run >> 32);
+  if (!okr) { cache->cached_valid = 0; mx::set_error(p.err); return 1; }
+  cache->cached_valid = 1; cache->cached_key = cache->batch_key; cache->cached_batch = batch; cache->cached_h = H; cache->cached_w = W;
+  return 0;
 }
 
 extern "C" int mx_mmdit_forward_trace(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps,

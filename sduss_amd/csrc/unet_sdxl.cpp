@@ -846,7 +846,7 @@ extern "C" int mx_unet_forward_cached(mx_unet* u, void* stream, const void* late
     return 1;
   }
   const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
-  cache->blocks_run = p.blocks_run;
+  cache->blocks_run = p.blocks_run; cache->blocks_run_hi = 0;
   if (!okr) { cache->cached_valid = 0; mx::set_error(p.err); return 1; }
   cache->cached_valid = 1; cache->cached_key = cache->batch_key; cache->cached_batch = batch; cache->cached_h = H; cache->cached_w = W;
   return 0;

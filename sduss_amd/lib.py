@@ -70,7 +70,7 @@ MSE_UNCACHED = 9.2233720368547758e18
 class BlockCacheC(C.Structure):
     _fields_ = [("predict", SKIP_PREDICT_FN), ("ctx", C.c_void_p), ("state", C.c_void_p), ("state_bytes", C.c_size_t),
                 ("batch_key", C.c_uint64), ("cached_key", C.c_uint64), ("cached_valid", C.c_int), ("cached_batch", C.c_int),
-                ("cached_h", C.c_int), ("cached_w", C.c_int), ("blocks_run", C.c_uint)]
+                ("cached_h", C.c_int), ("cached_w", C.c_int), ("blocks_run", C.c_uint), ("blocks_run_hi", C.c_uint)]
 
 
 class CLIPConfigC(C.Structure):
@@ -123,6 +123,8 @@ SYMBOLS = {
     "mx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
     "mx_unet_block_cache_bytes": (_sz, [_vp, _i, _i, _i]),
     "mx_unet_forward_cached": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mx_mmdit_block_cache_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "mx_mmdit_forward_cached": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mx_unet_forward_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz,
                                    C.c_char_p, _vp, _sz]),
     "mx_unet_workspace_bytes_pp": (_sz, [_vp, _i, _i, _i, _i, _i]),

@@ -15,6 +15,18 @@ from .unet import _Config
 from .weights import PackedWeights, pack_mmdit
 
 
+def mmdit_config_c(cfg: MMDiTConfig) -> "_lib.MMDiTConfigC":
+    cc = _lib.MMDiTConfigC()
+    cc.patch_size, cc.in_channels, cc.out_channels = cfg.patch_size, cfg.in_channels, cfg.out_channels
+    cc.num_layers, cc.num_attention_heads = cfg.num_layers, cfg.num_attention_heads
+    cc.joint_attention_dim, cc.pooled_projection_dim = cfg.joint_attention_dim, cfg.pooled_projection_dim
+    cc.pos_embed_max_size, cc.norm_eps = cfg.pos_embed_max_size, cfg.norm_eps
+    assert cfg.attention_head_dim == 64, "the attention kernel is built for head_dim 64"
+    for i in range(cfg.num_layers):
+        cc.dual_attention[i] = int(i in cfg.dual_attention_layers)
+    return cc
+
+
 class MxSD3Transformer:
     """``forward(hidden_states: {str(res): [n,16,h,w]}, encoder_hidden_states [N,333,4096], pooled_projections [N,2048],
     timestep [N], ..., return_dict=False, is_sliced, patch_size, input_indices) -> (dict,)``.  Unlike the reference it does
@@ -25,14 +37,7 @@ class MxSD3Transformer:
         self.device = torch.device(device)
         self.dtype = torch.bfloat16
         self._lib = _lib.load()
-        cc = _lib.MMDiTConfigC()
-        cc.patch_size, cc.in_channels, cc.out_channels = cfg.patch_size, cfg.in_channels, cfg.out_channels
-        cc.num_layers, cc.num_attention_heads = cfg.num_layers, cfg.num_attention_heads
-        cc.joint_attention_dim, cc.pooled_projection_dim = cfg.joint_attention_dim, cfg.pooled_projection_dim
-        cc.pos_embed_max_size, cc.norm_eps = cfg.pos_embed_max_size, cfg.norm_eps
-        assert cfg.attention_head_dim == 64, "the attention kernel is built for head_dim 64"
-        for i in range(cfg.num_layers):
-            cc.dual_attention[i] = int(i in cfg.dual_attention_layers)
+        cc = mmdit_config_c(cfg)
         self._handle = self._lib.mx_mmdit_create(C.byref(cc))
         if not self._handle:
             raise _lib.MxError("mx_mmdit_create: " + self._lib.mx_last_error().decode())
@@ -54,7 +59,9 @@ class MxSD3Transformer:
         return self
 
     def forward_one(self, latents: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
-                    pooled: torch.Tensor, stage: Optional[str] = None, stage_shape=None) -> torch.Tensor:
+                    pooled: torch.Tensor, stage: Optional[str] = None, stage_shape=None, cache=None, batch_key: int = 0) -> torch.Tensor:
+        """`cache` (sduss_amd/block_cache.py BlockSkipCache, forced_after=2) routes the step through mx_mmdit_forward_cached: the
+        reference's ESYMRED_USE_CACHE=TRUE path (SD3Transformer.py:151-228).  Approximate by design; off by default."""
         assert latents.is_cuda and latents.ndim == 4
         latents = latents.contiguous()
         b, _c, h, w = latents.shape
@@ -81,6 +88,16 @@ class MxSD3Transformer:
             self._ws_by_stream[skey] = None
             ws = self._ws_by_stream[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
         out = torch.empty((b, self.cfg.out_channels, h, w), dtype=latents.dtype, device=self.device)
+        if cache is not None:
+            assert stage is None
+            desc = cache.bind(self, b, h, w, batch_key, ctx_len=lt)
+            rc = self._lib.mx_mmdit_forward_cached(self._handle, stream, latents.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
+                                                   pp.data_ptr(), out.data_ptr(), b, h, w, lt, ws.data_ptr(), ws.numel(), desc)
+            if rc and cache.error is not None:
+                raise cache.error
+            _lib.check(rc, "mx_mmdit_forward_cached")
+            cache.after_forward()
+            return out
         if stage is None:
             _lib.check(self._lib.mx_mmdit_forward(self._handle, stream, latents.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
                                                   pp.data_ptr(), out.data_ptr(), b, h, w, lt, ws.data_ptr(),

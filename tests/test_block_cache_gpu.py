@@ -203,3 +203,83 @@ def test_predictor_failure_and_bad_arguments_are_reported(tiny):
                                   C.byref(bc.desc))
     assert rc != 0 and b"state buffer too small" in l.mx_last_error() and bc.desc.cached_valid == 0
     torch.cuda.synchronize()
+
+
+# ---- SD3 / SD3.5 transformer: one cache point per joint block (SD3Transformer.py:151-228, cache_manager.py:163-191) ----
+from oracle import sd3_mmdit_ref as mmdit_ref  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def tiny_sd3(cuda_device):
+    from sduss_amd.config import MMDiTConfig
+    from sduss_amd.transformer_sd3 import MxSD3Transformer
+    ocfg = mmdit_ref.MMDiTConfig.tiny()
+    return ocfg, MxSD3Transformer(MMDiTConfig.tiny(), mmdit_ref.init_params(ocfg), device="cuda:0")
+
+
+def _sd3_inputs(ocfg, batch, hw, lt, seed=0):
+    lat, t, e, p = mmdit_ref.make_inputs(ocfg, batch, hw, ctx_len=lt)
+    g = torch.Generator().manual_seed(200 + seed)
+    lat = lat + 0.05 * seed * torch.randn(lat.shape, generator=g)
+    return lat.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), p.cuda()
+
+
+@pytest.mark.parametrize("batch,hw,lt", [(2, 16, 37), (3, 24, 77)])
+def test_sd3_always_run_is_the_exact_forward(tiny_sd3, batch, hw, lt):
+    from sduss_amd.block_cache import BlockSkipCache, FORCED_RUN_AFTER_SD3, MSE_UNCACHED
+    ocfg, net = tiny_sd3
+    n = ocfg.num_layers
+    pred = Always(1)
+    bc = BlockSkipCache(pred, forced_after=FORCED_RUN_AFTER_SD3)
+    for step in range(3):
+        lat, t, e, p = _sd3_inputs(ocfg, batch, hw, lt, step)
+        want = net.forward_one(lat, t, e, p)
+        got = net.forward_one(lat, t, e, p, cache=bc, batch_key=5)
+        assert torch.equal(got, want), f"step {step}"
+        assert bc.history[-1] == (1 << n) - 1
+    assert len(pred.rows) == 3 * n and all(r.shape == (batch, 3) for r in pred.rows)
+    assert all((r[:, 2] >= MSE_UNCACHED * 0.5).all() for r in pred.rows[:n])
+    assert all((r[:, 2] < 1e6).all() and (r[:, 2] > 0).all() for r in pred.rows[n:])
+    assert [int(r[0, 0]) for r in pred.rows[:n]] == list(range(n))
+
+
+def test_sd3_reuse_forced_run_after_two_and_invalidation(tiny_sd3):
+    from sduss_amd.block_cache import BlockSkipCache, FORCED_RUN_AFTER_SD3
+    ocfg, net = tiny_sd3
+    n = ocfg.num_layers
+    full = (1 << n) - 1
+    pred = Always(1)
+    bc = BlockSkipCache(pred, forced_after=FORCED_RUN_AFTER_SD3)
+    lat0, t, e, p = _sd3_inputs(ocfg, 2, 16, 37, 0)
+    out0 = net.forward_one(lat0, t, e, p, cache=bc, batch_key=1)
+    pred.v = 0
+    outs = []
+    for step in range(1, 5):
+        lat, *_ = _sd3_inputs(ocfg, 2, 16, 37, step)
+        outs.append(net.forward_one(lat, t, e, p, cache=bc, batch_key=1))
+    assert bc.history == [full, 0, 0, full, 0]                    # cache_manager.py:184-186: the third call runs
+    assert torch.equal(outs[0], out0) and torch.equal(outs[1], out0)
+    lat3, *_ = _sd3_inputs(ocfg, 2, 16, 37, 3)
+    assert torch.equal(outs[2], net.forward_one(lat3, t, e, p)) and torch.equal(outs[3], outs[2])
+    # the last block alone reused: norm_out / proj_out see the cached image stream -> the previous output
+    class Last:
+        def predict(self, f):
+            f = np.asarray(f)
+            return np.zeros(len(f)) if int(f[0, 0]) == n - 1 else np.ones(len(f))
+    bc2 = BlockSkipCache(Last(), forced_after=FORCED_RUN_AFTER_SD3)
+    a = net.forward_one(lat0, t, e, p, cache=bc2, batch_key=1)
+    b = net.forward_one(lat3, t, e, p, cache=bc2, batch_key=1)
+    assert bc2.history == [full, full >> 1] and torch.equal(a, b)
+    # a middle block reused: both streams continue from its cached outputs -> an approximation of the exact step
+    class Mid:
+        def predict(self, f):
+            f = np.asarray(f)
+            return np.zeros(len(f)) if int(f[0, 0]) == 1 else np.ones(len(f))
+    bc3 = BlockSkipCache(Mid(), forced_after=FORCED_RUN_AFTER_SD3)
+    net.forward_one(lat0, t, e, p, cache=bc3, batch_key=1)
+    b = net.forward_one(lat3, t, e, p, cache=bc3, batch_key=1)
+    exact = net.forward_one(lat3, t, e, p)
+    assert bc3.history[-1] == full & ~2 and not torch.equal(b, exact)
+    assert ((b.float() - exact.float()).norm() / exact.float().norm()).item() < 0.5
+    got = net.forward_one(lat3, t, e, p, cache=bc3, batch_key=2)   # another batch composition
+    assert bc3.history[-1] == full and torch.equal(got, exact)

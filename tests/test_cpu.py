@@ -530,3 +530,19 @@ def test_block_cache_state_size_is_the_sum_of_block_inputs_and_outputs(tiny):
     assert l.mx_unet_block_cache_bytes(h, B, H, H) == want + 256
     assert l.mx_unet_block_cache_bytes(h, B, 25, 24) == 0
     l.mx_unet_destroy(h)
+
+
+def test_mmdit_block_cache_state_size():
+    from sduss_amd import config, lib
+    from sduss_amd.transformer_sd3 import mmdit_config_c
+    l = lib.load()
+    pcfg = config.MMDiTConfig.tiny()
+    h = l.mx_mmdit_create(C.byref(mmdit_config_c(pcfg)))
+    assert h
+    B, H, Lt = 3, 24, 77
+    d, L = pcfg.num_attention_heads * 64, (H // pcfg.patch_size) ** 2
+    r256 = lambda n: (n + 255) // 256 * 256
+    want = r256(B * 64 * 8) + pcfg.num_layers * (2 * r256(B * L * d * 2) + r256(B * Lt * d * 2))
+    assert l.mx_mmdit_block_cache_bytes(h, B, H, H, Lt) == want
+    assert l.mx_mmdit_block_cache_bytes(h, B, H + 1, H, Lt) == 0
+    l.mx_mmdit_destroy(h)
