@@ -305,6 +305,26 @@ size_t mx_unet_workspace_bytes_pp(const mx_unet* u, int batch, int H_local, int 
 int mx_unet_forward_pp(mx_unet* u, void* stream, const void* latents_local, int io_dtype, const float* timesteps, const void* ehs,
                        const void* text_embeds, const float* time_ids, void* out_local, int batch, int H_local, int W, int ctx_len,
                        const mx_pp_comm* comm, void* workspace, size_t workspace_bytes);
+/* Stale-asynchronous steps: distrifuser's default mode after `warmup_steps` (= 4) synchronous steps (utils.py:30-32, 180-214;
+ * modules/pp/conv2d.py:97-117, attn.py:136-146, groupnorm.py:46-66).  Every exchange k of a forward owns region k of a state buffer the caller
+ * keeps across steps.  A WARMUP step is a synchronous step that also leaves what it gathered in the state.  A STALE step reads, for every
+ * exchange, the OTHER ranks' slots as they were sent one step earlier and its own slot fresh, and hands its fresh slot to
+ * all_gather_async(ctx, stream, region, bytes_per_rank): an in-place all-gather over the `world` slots of `region` (this rank's slot is already
+ * filled) that must start after the work queued on `stream` so far and may complete at any time before the NEXT forward's first launch -- the
+ * caller orders that (sduss_amd/patch_parallel.py: a side stream and an event per step).  Approximate by construction: with unchanged inputs a
+ * stale step reproduces the synchronous result bit for bit; otherwise it lags one step in what it sees of the other ranks' rows.
+ * corrected_gn: 0 = "stale_gn" (fresh own sums beside stale remote ones), 1 = "corrected_async_gn", distrifuser's default (stale whole-image
+ * moments + this rank's change, local variance where that turns negative).  distrifuser's unbiased-variance factor is not applied in either
+ * mode: the synchronous arithmetic here is nn.GroupNorm's. */
+#define MX_PP_SYNC 0
+#define MX_PP_WARMUP 1
+#define MX_PP_STALE 2
+typedef int (*mx_allgather_inplace_fn)(void* ctx, void* stream, void* region, size_t bytes_per_rank);
+typedef struct mx_pp_stale { void* state; size_t state_bytes; int mode; int corrected_gn; mx_allgather_inplace_fn all_gather_async; } mx_pp_stale;
+size_t mx_unet_pp_state_bytes(const mx_unet* u, int batch, int H_local, int W, int ctx_len, int world);
+int mx_unet_forward_pp_stale(mx_unet* u, void* stream, const void* latents_local, int io_dtype, const float* timesteps, const void* ehs,
+                             const void* text_embeds, const float* time_ids, void* out_local, int batch, int H_local, int W, int ctx_len,
+                             const mx_pp_comm* comm, const mx_pp_stale* stale, void* workspace, size_t workspace_bytes);
 /* Host-only walk of the patch-parallel plan (no launches, no GPU): calls comm->all_gather once per exchange of a forward, in
  * order, with send / recv = (void*)(0x1000 + byte offset of the region inside the workspace). */
 int mx_unet_pp_comm_plan(const mx_unet* u, int batch, int H_local, int W, int ctx_len, const mx_pp_comm* comm);

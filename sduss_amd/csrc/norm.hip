@@ -180,7 +180,8 @@ __global__ __launch_bounds__(64) void gn_pp_sums_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(64) void gn_pp_coef_kernel(const double* __restrict__ all_sums, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ coef, int B, int C,
-                                                        int groups, int world, double cnt, float eps) {
+                                                        int groups, int world, double cnt, float eps,
+                                                        const double* __restrict__ fresh_own, int own_rank) {
   const int grp = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const int cpg = C / groups;
   double s = 0.0, q = 0.0;
@@ -188,9 +189,20 @@ __global__ __launch_bounds__(64) void gn_pp_coef_kernel(const double* __restrict
     s += all_sums[(((long)r * B + b) * groups + grp) * 2];
     q += all_sums[(((long)r * B + b) * groups + grp) * 2 + 1];
   }
+  double var_fallback = 0.0;
+  if (fresh_own) {
+    // distrifuser "corrected_async_gn" (modules/pp/groupnorm.py:52-66): full = mean over ranks of the STALE slice moments + (fresh - stale) of
+    // this rank's slice, the correction NOT divided by the number of ranks; in sums: sum_r stale_r + world * (fresh_own - stale_own)
+    const long o = (((long)own_rank * B + b) * groups + grp) * 2, f = ((long)b * groups + grp) * 2;
+    s += (double)world * (fresh_own[f] - all_sums[o]);
+    q += (double)world * (fresh_own[f + 1] - all_sums[o + 1]);
+    const double lc = cnt / world, lm = fresh_own[f] / lc;
+    var_fallback = fresh_own[f + 1] / lc - lm * lm;       // "var = torch.where(var < 0, slice_var, var)"
+    if (var_fallback < 0.0) var_fallback = 0.0;
+  }
   const double mean = s / cnt;
   double var = q / cnt - mean * mean;
-  if (var < 0.0) var = 0.0;
+  if (var < 0.0) var = var_fallback;
   const double rstd = 1.0 / sqrt(var + (double)eps);
   for (int c = lane; c < cpg; c += 64) {
     const int ch = grp * cpg + c;
@@ -300,13 +312,14 @@ int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, i
 }
 // all_sums: double [world][B][groups][2]; y rows of image b start at y + b * y_img_elems; H = LOCAL rows, H_total = rows of the whole image
 int launch_gn_pp_finish(hipStream_t s, const void* x, int C1, const void* x2, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
-                        int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace) {
+                        int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace,
+                        const double* fresh_own, int own_rank) {
   GnGeom g;
   if (gn_geom(g, B, H, W, C, 0)) return 1;
   if (x2) { g.x2 = (const bf16_t*)x2; g.C1 = C1; }
   float* coef = (float*)workspace + (size_t)B * g.tiles_y * g.tiles_x * C * 2;
   const double cnt = (double)H_total * W * (C / groups);
-  hipLaunchKernelGGL(gn_pp_coef_kernel, dim3(groups, B), dim3(64), 0, s, all_sums, gamma, beta, coef, B, C, groups, world, cnt, eps);
+  hipLaunchKernelGGL(gn_pp_coef_kernel, dim3(groups, B), dim3(64), 0, s, all_sums, gamma, beta, coef, B, C, groups, world, cnt, eps, fresh_own, own_rank);
   const int threads = ((g.tpr * g.L + 63) / 64) * 64;
   const int hw = H * W;
   int ppb = g.L * 8;

@@ -38,7 +38,8 @@ size_t gn_workspace_exact(int B, int H, int W, int C, int patch);
 int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial);
 int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, int B, int H, int W, int C, int groups, void* workspace, double* sums);
 int launch_gn_pp_finish(hipStream_t s, const void* x, int C1, const void* x2, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
-                        int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace);
+                        int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace,
+                        const double* fresh_own = nullptr, int own_rank = 0);
 }  // namespace mx
 extern "C" int mx_attention_prescaled_chunked(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                                               int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, int key_chunk,
@@ -79,6 +80,11 @@ struct Plan {
   bool dry;                 // size-only pass: no launches
   bool mute = false;        // block-skip cache: walk a block's plan (allocations, weight / K-V / time-embedding cursors) without launching it
   bool quiet() const { return dry || mute; }
+  // stale-asynchronous patch parallelism (mx_unet_forward_pp_stale): every exchange owns a region of the persistent state
+  int pp_mode = 0;                // MX_PP_SYNC / MX_PP_WARMUP / MX_PP_STALE
+  bool pp_corrected_gn = false;
+  char* pp_state = nullptr; size_t pp_state_bytes = 0, pp_state_top = 0;
+  mx_allgather_inplace_fn pp_ag_async = nullptr;
   mx_block_cache* bc = nullptr;   // mx_unet_forward_cached
   char* bc_top = nullptr;         // bump pointer into bc->state: same order and sizes every step
   unsigned blocks_run = 0;
@@ -119,11 +125,33 @@ struct Plan {
   bool ok() const { return err.empty(); }
 
   // ---- patch-parallel helpers --------------------------------------------------------------
-  bool all_gather(const void* send, void* recv, size_t bytes_per_rank) {
+  // keep_stale_own (stale mode only): recv keeps the stale copy of this rank's slot too (the corrected GroupNorm needs it)
+  bool all_gather(const void* send, void* recv, size_t bytes_per_rank, bool keep_stale_own = false) {
     if (!ok()) return false;
+    char* region = nullptr;
+    if (pp_mode != MX_PP_SYNC) {             // the exchanges of a forward come in a fixed order: exchange k owns region k of the state
+      region = pp_state + pp_state_top;
+      pp_state_top += ((size_t)pp_world * bytes_per_rank + 255) & ~(size_t)255;
+      if (!dry && pp_state_top > pp_state_bytes) return fail("patch-parallel: state buffer too small (mx_unet_pp_state_bytes)");
+    }
     if (dry && !pp_ag) return true;          // sizing pass
-    // dry with a callback (mx_unet_pp_comm_plan): the callback sees the arena's placeholder addresses (0x1000 + offset)
-    if (pp_ag(pp_ctx, stream, send, recv, bytes_per_rank)) return fail("patch-parallel all_gather failed");
+    if (dry || pp_mode != MX_PP_STALE) {
+      // dry with a callback (mx_unet_pp_comm_plan): the callback sees the arena's placeholder addresses (0x1000 + offset)
+      if (pp_ag(pp_ctx, stream, send, recv, bytes_per_rank)) return fail("patch-parallel all_gather failed");
+      // a warm-up step leaves what it gathered behind for the first stale step (distrifuser: the buffers registered during warm-up)
+      if (!dry && pp_mode == MX_PP_WARMUP &&
+          hipMemcpyAsync(region, recv, (size_t)pp_world * bytes_per_rank, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+        return fail("patch-parallel: state copy failed");
+      return true;
+    }
+    // stale step (utils.py:180-214, modules/pp/*.py `counter > warmup_steps`): the other ranks' slots are what they sent LAST step, this
+    // rank's slot is fresh; the fresh slot goes out through the asynchronous collective and is read by the others NEXT step
+    const size_t own = (size_t)pp_rank * bytes_per_rank;
+    bool e = hipMemcpyAsync(recv, region, (size_t)pp_world * bytes_per_rank, hipMemcpyDeviceToDevice, stream) != hipSuccess;
+    if (!keep_stale_own) e |= hipMemcpyAsync((char*)recv + own, send, bytes_per_rank, hipMemcpyDeviceToDevice, stream) != hipSuccess;
+    e |= hipMemcpyAsync(region + own, send, bytes_per_rank, hipMemcpyDeviceToDevice, stream) != hipSuccess;
+    if (e) return fail("patch-parallel: stale assembly failed");
+    if (pp_ag_async(pp_ctx, stream, region, bytes_per_rank)) return fail("patch-parallel asynchronous all_gather failed");
     return true;
   }
   // [B, h + 2, wd, C] image with one halo row above and below; returns the base (the top halo row of image 0)
@@ -175,8 +203,12 @@ struct Plan {
     if (ok() && dry) all_gather(sums, all, (size_t)B * G * 2 * sizeof(double));
     if (ok() && !dry) {
       if (mx::launch_gn_pp_partial(stream, x, C1, x2, B, h, wd, C, G, ws, sums)) return fail(std::string("groupnorm: ") + mx_last_error());
-      if (!all_gather(sums, all, (size_t)B * G * 2 * sizeof(double))) return false;
-      if (mx::launch_gn_pp_finish(stream, x, C1, x2, y, y_img, g, b, all, pp_world, B, h, wd, C, G, Htot >> level, eps, silu ? 1 : 0, ws))
+      // stale steps: "stale_gn" = fresh own sums beside the others' stale ones; "corrected_async_gn" (distrifuser's default,
+      // modules/pp/groupnorm.py:52-66) = the stale whole-image moments plus this rank's (fresh - stale) change, local variance if negative
+      const bool corrected = pp_mode == MX_PP_STALE && pp_corrected_gn;
+      if (!all_gather(sums, all, (size_t)B * G * 2 * sizeof(double), corrected)) return false;
+      if (mx::launch_gn_pp_finish(stream, x, C1, x2, y, y_img, g, b, all, pp_world, B, h, wd, C, G, Htot >> level, eps, silu ? 1 : 0, ws,
+                                  corrected ? sums : nullptr, pp_rank))
         return fail(std::string("groupnorm: ") + mx_last_error());
     }
     ar.release(m);
@@ -691,7 +723,8 @@ int check_cfg(const mx_unet_config* c) {
 int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
                  const void* text_embeds, const float* time_ids, void* out, int batch, int H, int W, int ctx_len, int gn_patch,
                  void* workspace, size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_bytes, bool dry,
-                 size_t* peak, bool lookup = false, const mx_pp_comm* comm = nullptr) {
+                 size_t* peak, bool lookup = false, const mx_pp_comm* comm = nullptr, const mx_pp_stale* stale = nullptr,
+                 size_t* state_need = nullptr) {
   MX_CHECK(u != nullptr, "unet: null handle");
   const bool pp = comm != nullptr && comm->world > 1;
   if (pp) {
@@ -721,8 +754,13 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
     p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
     p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
     if (pp) { p.pp_rank = comm->rank; p.pp_world = comm->world; p.pp_ag = comm->all_gather; p.pp_ctx = comm->ctx; p.Htot = H * comm->world; }
+    if (pp && stale) {
+      p.pp_mode = stale->mode; p.pp_corrected_gn = stale->corrected_gn != 0; p.pp_state = (char*)stale->state;
+      p.pp_state_bytes = stale->state_bytes; p.pp_ag_async = stale->all_gather_async;
+    }
     const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
     plan_peak = p.ar.peak;
+    if (state_need) *state_need = p.pp_state_top;
     if (!okr) err = p.err;
     return okr;
   };
@@ -878,6 +916,30 @@ extern "C" int mx_unet_forward_pp(mx_unet* u, void* stream, const void* latents_
   MX_CHECK(comm != nullptr, "unet_forward_pp: null communicator");
   return forward_impl(u, stream, latents_local, io_dtype, timesteps, ehs, text_embeds, time_ids, out_local, batch, H_local, W, ctx_len, 0,
                       workspace, workspace_bytes, nullptr, nullptr, 0, false, nullptr, false, comm);
+}
+
+/* stale-asynchronous steps (distrifuser's default after its warm-up: utils.py:180-214 enqueue / handles; modules/pp/conv2d.py:97-117,
+ * attn.py:136-146, groupnorm.py:46-66) */
+extern "C" size_t mx_unet_pp_state_bytes(const mx_unet* u, int batch, int H_local, int W, int ctx_len, int world) {
+  if (!u) return 0;
+  size_t need = 0;
+  mx_pp_comm c; c.rank = 0; c.world = world; c.all_gather = nullptr; c.ctx = nullptr;
+  mx_pp_stale st{}; st.mode = MX_PP_WARMUP;
+  if (forward_impl(const_cast<mx_unet*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr, batch, H_local, W, ctx_len, 0,
+                   nullptr, 0, nullptr, nullptr, 0, true, nullptr, false, &c, &st, &need))
+    return 0;
+  return need + 256;
+}
+
+extern "C" int mx_unet_forward_pp_stale(mx_unet* u, void* stream, const void* latents_local, int io_dtype, const float* timesteps, const void* ehs,
+                                        const void* text_embeds, const float* time_ids, void* out_local, int batch, int H_local, int W,
+                                        int ctx_len, const mx_pp_comm* comm, const mx_pp_stale* stale, void* workspace, size_t workspace_bytes) {
+  MX_CHECK(comm != nullptr && stale != nullptr, "unet_forward_pp_stale: null communicator / state");
+  MX_CHECK(stale->mode == MX_PP_WARMUP || stale->mode == MX_PP_STALE, "unet_forward_pp_stale: mode must be MX_PP_WARMUP or MX_PP_STALE");
+  MX_CHECK(stale->state != nullptr && ((uintptr_t)stale->state & 255) == 0, "unet_forward_pp_stale: state must be 256-byte aligned device memory");
+  MX_CHECK(stale->mode != MX_PP_STALE || stale->all_gather_async != nullptr, "unet_forward_pp_stale: a stale step needs all_gather_async");
+  return forward_impl(u, stream, latents_local, io_dtype, timesteps, ehs, text_embeds, time_ids, out_local, batch, H_local, W, ctx_len, 0,
+                      workspace, workspace_bytes, nullptr, nullptr, 0, false, nullptr, false, comm, stale);
 }
 
 /* host-only walk of the patch-parallel plan that calls comm->all_gather for every exchange of one forward, in order, with

@@ -62,6 +62,15 @@ class PPComm(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("all_gather", ALLGATHER_FN), ("ctx", C.c_void_p)]
 
 
+ALLGATHER_INPLACE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+PP_SYNC, PP_WARMUP, PP_STALE = 0, 1, 2
+
+
+class PPStale(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("state_bytes", C.c_size_t), ("mode", C.c_int), ("corrected_gn", C.c_int),
+                ("all_gather_async", ALLGATHER_INPLACE_FN)]
+
+
 SKIP_PREDICT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                               C.POINTER(C.c_ubyte))
 MSE_UNCACHED = 9.2233720368547758e18
@@ -121,6 +130,8 @@ SYMBOLS = {
     "mx_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_unet_validate": (_i, [_vp, _i, _i, _i, _i]),
     "mx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
+    "mx_unet_pp_state_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
+    "mx_unet_forward_pp_stale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "mx_unet_block_cache_bytes": (_sz, [_vp, _i, _i, _i]),
     "mx_unet_forward_cached": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mx_mmdit_block_cache_bytes": (_sz, [_vp, _i, _i, _i, _i]),

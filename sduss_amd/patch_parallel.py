@@ -1,6 +1,6 @@
 """Patch parallelism for ONE request across the GPUs of a node (BASELINE.json configs[3]): the distrifuser baseline the
 reference bundles (distrifuser/distrifuser/distrifuser/models/distri_sdxl_unet_pp.py:15-216, utils.py:119-214), synchronous
-mode, behind the C ABI (``mx_unet_forward_pp``, include/mxdenoise.h).
+and stale-asynchronous modes, behind the C ABI (``mx_unet_forward_pp`` / ``mx_unet_forward_pp_stale``, include/mxdenoise.h).
 
 One process per GPU.  Every rank holds the whole UNet (weights are not sharded, as in distrifuser) and the latent ROWS
 [rank * H / world, (rank + 1) * H / world).  The step plan itself decides what is exchanged (conv boundary rows, GroupNorm
@@ -50,8 +50,18 @@ class PatchParallelUNet:
     rank (rows all-gathered).  ``group`` is the torch.distributed group of the ranks sharing the request (distrifuser's
     batch_group, utils.py:93-97)."""
 
-    def __init__(self, unet: MxUNet, group=None, log: Optional[CommLog] = None):
+    def __init__(self, unet: MxUNet, group=None, log: Optional[CommLog] = None, mode: str = "sync", warmup_steps: int = 4):
+        """mode: "sync" (every step exchanges fresh tensors; distrifuser "full_sync"), "stale_gn" or "corrected_async_gn" (distrifuser's
+        default, utils.py:30-32): `warmup_steps` synchronous steps, then stale-asynchronous ones (mx_unet_forward_pp_stale).  Call
+        ``reset()`` when a new request starts (distrifuser resets its counters per generation, models/base_model.py)."""
         import torch.distributed as dist
+        assert mode in ("sync", "stale_gn", "corrected_async_gn")
+        self.mode, self.warmup_steps = mode, warmup_steps
+        self.counter = 0
+        self._state: Optional[torch.Tensor] = None
+        self._pending = []                                   # collectives of the last stale step still in flight
+        self._comm_stream: Optional[torch.cuda.Stream] = None
+        self._cb_async = _lib.ALLGATHER_INPLACE_FN(self._all_gather_async)
         self.unet = unet
         self.dist = dist
         self.group = group
@@ -84,6 +94,48 @@ class PatchParallelUNet:
             self._err = e
             return 1
 
+    # stale steps: in-place all-gather over the slots of one state region; must start after what is queued on the compute stream and
+    # finish before the next forward (wait_pending)
+    def _all_gather_async(self, _ctx, _stream, region, nbytes) -> int:
+        try:
+            st = self._state
+            off = region - st.data_ptr()
+            assert 0 <= off and off + nbytes * self.world <= st.numel() and off % 256 == 0
+            if self.log is not None:
+                self.log.calls.append((-1, off, nbytes))
+            r = st[off:off + nbytes * self.world]
+            own = r[self.rank * nbytes:(self.rank + 1) * nbytes]
+            if self.backend == "gloo":               # tests: through host memory, completes at once (a legal schedule of the async contract)
+                host = own.cpu()
+                parts = [torch.empty_like(host) for _ in range(self.world)]
+                self.dist.all_gather(parts, host, group=self.group)
+                r.copy_(torch.cat(parts))
+            else:                                    # RCCL on a side stream: the compute stream runs on while the slots travel
+                cur = torch.cuda.current_stream()
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream(device=st.device)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self._comm_stream.wait_event(ev)
+                with torch.cuda.stream(self._comm_stream):
+                    self._pending.append(self.dist.all_gather_into_tensor(r, own, group=self.group, async_op=True))
+            return 0
+        except BaseException as e:  # noqa: BLE001
+            self._err = e
+            return 1
+
+    def wait_pending(self) -> None:
+        """the compute stream waits for the collectives the last stale step left in flight"""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def reset(self) -> None:
+        self.wait_pending()
+        self.counter = 0
+
     def forward_local(self, latents_local: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                       text_embeds: torch.Tensor, time_ids: torch.Tensor) -> torch.Tensor:
         u = self.unet
@@ -104,9 +156,26 @@ class PatchParallelUNet:
         out = torch.empty((b, u.cfg.out_channels, hl, w), dtype=x.dtype, device=dev)
         comm = _lib.PPComm(self.rank, self.world, self._cb, None)
         self._err = None
-        rc = u._lib.mx_unet_forward_pp(u._handle, _lib.current_stream(), x.data_ptr(), _lib.torch_dtype_code(x.dtype), ts.data_ptr(),
-                                       ehs.data_ptr(), te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, hl, w, ctx_len, C.byref(comm),
-                                       self._ws.data_ptr(), self._ws.numel())
+        if self.mode == "sync":
+            rc = u._lib.mx_unet_forward_pp(u._handle, _lib.current_stream(), x.data_ptr(), _lib.torch_dtype_code(x.dtype), ts.data_ptr(),
+                                           ehs.data_ptr(), te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, hl, w, ctx_len, C.byref(comm),
+                                           self._ws.data_ptr(), self._ws.numel())
+        else:
+            sneed = u._lib.mx_unet_pp_state_bytes(u._handle, b, hl, w, ctx_len, self.world)
+            if sneed == 0:
+                raise _lib.MxError("mx_unet_pp_state_bytes: " + u._lib.mx_last_error().decode())
+            if self._state is None or self._state.numel() < sneed:
+                self._state = torch.empty(sneed, dtype=torch.uint8, device=dev)
+                self.counter = 0                     # nothing to be stale about yet
+            self.wait_pending()
+            stale = _lib.PPStale(self._state.data_ptr(), self._state.numel(),
+                                 _lib.PP_WARMUP if self.counter < self.warmup_steps else _lib.PP_STALE,
+                                 int(self.mode == "corrected_async_gn"), self._cb_async)
+            self.last_step_mode = stale.mode
+            rc = u._lib.mx_unet_forward_pp_stale(u._handle, _lib.current_stream(), x.data_ptr(), _lib.torch_dtype_code(x.dtype), ts.data_ptr(),
+                                                 ehs.data_ptr(), te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, hl, w, ctx_len,
+                                                 C.byref(comm), C.byref(stale), self._ws.data_ptr(), self._ws.numel())
+            self.counter += 1
         if self._err is not None:
             raise self._err
         _lib.check(rc, "mx_unet_forward_pp")

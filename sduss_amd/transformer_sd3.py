@@ -11,7 +11,7 @@ import torch
 
 from . import lib as _lib
 from .config import MMDiTConfig
-from .unet import _Config
+from .unet import _Config, _stable_key
 from .weights import PackedWeights, pack_mmdit
 
 
@@ -125,8 +125,28 @@ class MxSD3Transformer:
             n = x.shape[0]
             sl = slice(row, row + n)
             ts = timestep if timestep.ndim == 0 else timestep[sl]
-            out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], pooled_projections[sl])
+            caches = getattr(self, "_block_caches", None)
+            if caches is not None:                     # ESYMRED_USE_CACHE=TRUE (enable_block_cache)
+                ids = (input_indices or {}).get(key)
+                assert ids is not None and len(ids) > 0 and n % len(ids) == 0, "the block-skip cache keys its state by input_indices[resolution] (cache_manager.py:166)"
+                bc = caches.get(key)
+                if bc is None:
+                    bc = caches[key] = self._new_block_cache()
+                out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], pooled_projections[sl], cache=bc, batch_key=_stable_key(ids))
+            else:
+                out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], pooled_projections[sl])
             row += n
         return (out,)
+
+    def enable_block_cache(self, predictor, forced_after: Optional[int] = None) -> None:
+        """Route forward() through the block-skip cache, one state per resolution key (SD3Transformer.py:151-228 with
+        ESYMRED_USE_CACHE=TRUE).  `predictor`: an object with .predict(features) (block_cache.py)."""
+        from .block_cache import BlockSkipCache, FORCED_RUN_AFTER_SD3
+        fa = FORCED_RUN_AFTER_SD3 if forced_after is None else forced_after
+        self._new_block_cache = lambda: BlockSkipCache(predictor, forced_after=fa)
+        self._block_caches = {}
+
+    def disable_block_cache(self) -> None:
+        self._block_caches = None
 
     __call__ = forward

@@ -22,6 +22,12 @@ class _Config(dict):
     __getattr__ = dict.__getitem__
 
 
+def _stable_key(ids) -> int:
+    """64-bit key of a batch composition (the request ids of a resolution in row order)"""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b("\x1f".join(str(i) for i in ids).encode(), digest_size=8).digest(), "little")
+
+
 class MxUNet:
     """Drop-in for ``PatchUNet``: ``forward(sample_dict, timestep, encoder_hidden_states, ..., added_cond_kwargs,
     return_dict=False, is_sliced, patch_size, input_indices) -> (dict,)``.
@@ -178,9 +184,30 @@ class MxUNet:
             ts = timestep if (not torch.is_tensor(timestep) or timestep.ndim == 0) else timestep[sl]
             if not torch.is_tensor(ts):
                 ts = torch.tensor([float(ts)], device=self.device)
-            out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl], gn_patch)
+            caches = getattr(self, "_block_caches", None)
+            if caches is not None:                     # ESYMRED_USE_CACHE=TRUE (enable_block_cache)
+                ids = (input_indices or {}).get(key)
+                assert ids is not None and len(ids) > 0 and n % len(ids) == 0, "the block-skip cache keys its state by input_indices[resolution] (cache_manager.py:105)"
+                bc = caches.get(key)
+                if bc is None:
+                    bc = caches[key] = self._new_block_cache()
+                out[key] = self.forward_one_cached(bc, x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl],
+                                                   batch_key=_stable_key(ids), gn_patch=gn_patch)
+            else:
+                out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl], gn_patch)
             row += n
         return (out,)
+
+    def enable_block_cache(self, down, up=None, forced_after: Optional[int] = None) -> None:
+        """Route forward() through the block-skip cache, one state per resolution key: what ESYMRED_USE_CACHE=TRUE does to the
+        reference's model (cache_manager.py:46-50).  `down` / `up`: objects with .predict(features) (block_cache.py)."""
+        from .block_cache import BlockSkipCache, FORCED_RUN_AFTER
+        fa = FORCED_RUN_AFTER if forced_after is None else forced_after
+        self._new_block_cache = lambda: BlockSkipCache(down, up, forced_after=fa)
+        self._block_caches = {}
+
+    def disable_block_cache(self) -> None:
+        self._block_caches = None
 
     __call__ = forward
 

@@ -283,3 +283,48 @@ def test_sd3_reuse_forced_run_after_two_and_invalidation(tiny_sd3):
     assert ((b.float() - exact.float()).norm() / exact.float().norm()).item() < 0.5
     got = net.forward_one(lat3, t, e, p, cache=bc3, batch_key=2)   # another batch composition
     assert bc3.history[-1] == full and torch.equal(got, exact)
+
+
+def test_model_slot_forward_with_the_cache_enabled(tiny):
+    """enable_block_cache: the same forward(sample_dict, ..., input_indices) call the pipeline makes, one cache state per resolution; the
+    whole denoising step (CFG rows, Euler update) runs through it."""
+    from sduss_amd.pipeline import SDXLDenoiser, synthetic_request
+    from sduss_amd.config import UNetConfig
+    ocfg, net = tiny
+    cfg = UNetConfig.tiny()
+    den = SDXLDenoiser(net)
+    shared = {}
+
+    def fresh():
+        return {"256": [synthetic_request(i, 256, 10, cfg, den, torch.device("cuda:0"), shared=shared) for i in range(2)],
+                "128": [synthetic_request(10 + i, 128, 10, cfg, den, torch.device("cuda:0"), shared=shared) for i in range(1)]}
+    exact = fresh()
+    for _ in range(3):
+        den.denoising_step(exact)
+    pred = Always(1)
+    net.enable_block_cache(pred)
+    try:
+        got = fresh()
+        for _ in range(3):
+            den.denoising_step(got)
+        for res in exact:
+            for a, b in zip(exact[res], got[res]):
+                assert torch.equal(a.latents, b.latents)
+        assert sorted(net._block_caches) == ["128", "256"] and all(c.history == [0x7f] * 3 for c in net._block_caches.values())
+        # reuse everything from here on: the noise prediction repeats, the latents still move by the Euler step
+        pred.v = 0
+        before = [r.latents.clone() for r in got["256"]]
+        den.denoising_step(got)
+        assert all(c.history[-1] == 0 for c in net._block_caches.values())
+        assert all(not torch.equal(a, r.latents) for a, r in zip(before, got["256"]))
+        # a request leaves the 256 px batch: that resolution's state is refilled, the other one keeps reusing
+        got["256"] = got["256"][:1]
+        den.denoising_step(got)
+        assert net._block_caches["256"].history[-1] == 0x7f and net._block_caches["128"].history[-1] == 0
+    finally:
+        net.disable_block_cache()
+    s, t, e, te, ti = _inputs(ocfg, 2, 32)
+    key = "256"
+    out = net.forward({key: s}, t, e, added_cond_kwargs={"text_embeds": te, "time_ids": ti}, return_dict=False, is_sliced=False,
+                      patch_size=256, input_indices={key: ["0", "1"]})[0][key]
+    assert torch.equal(out, net.forward_one(s, t, e, te, ti))

@@ -73,7 +73,10 @@ def _worker(rank, world, port, q):
         log.check(need, world)
         logs = [None] * world
         dist.all_gather_object(logs, log.calls)
-        q.put((rank, len(log.calls), bad, logs[0] == logs[1], sum(nb for _s, _r, nb in log.calls), need))
+        # stale-asynchronous mode: one 256-byte-aligned region of `world` slots per exchange, in the order of the plan
+        state_need = l.mx_unet_pp_state_bytes(h, batch, hl, w, ctx, world)
+        state_want = sum((world * nb + 255) // 256 * 256 for _s, _r, nb in log.calls) + 256
+        q.put((rank, len(log.calls), bad, logs[0] == logs[1], sum(nb for _s, _r, nb in log.calls), need, state_need == state_want))
         l.mx_unet_destroy(h)
     finally:
         dist.destroy_process_group()
@@ -92,7 +95,8 @@ def test_pp_exchange_bookkeeping_world2_gloo():
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    for rank, ncalls, bad, same, total, need in res:
+    for rank, ncalls, bad, same, total, need, state_ok in res:
+        assert state_ok, "mx_unet_pp_state_bytes must be the sum of the exchanges' receive sizes"
         # tiny config: 8 resnets x 2 (GroupNorm sums + conv halo) x 2 + transformer norms + K / V^T per layer + conv_in / down / up / out
         assert ncalls > 40, ncalls
         assert bad == [], f"rank {rank}: wrong bytes after exchanges {bad[:4]}"

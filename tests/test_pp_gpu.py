@@ -72,3 +72,67 @@ def test_two_ranks_equal_one_rank(cuda_device):
     assert dmax <= 0.03 * scale, f"2 ranks differ from 1 rank by {dmax} (range {scale})"
     assert oerr <= 0.04 * oscale
     assert ncalls > 40
+
+
+def _stale_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import sdxl_unet_ref as ref
+        from sduss_amd import lib
+        from sduss_amd.config import UNetConfig
+        from sduss_amd.patch_parallel import PatchParallelUNet
+        from sduss_amd.unet import MxUNet
+        ocfg = ref.UNetConfig.tiny()
+        net = MxUNet(UNetConfig.tiny(), ref.init_params(ocfg), device="cuda:0")
+        s, t, e, te, ti = ref.make_inputs(ocfg, 2, 64)
+        x0 = s.cuda().to(torch.bfloat16)
+        g = torch.Generator().manual_seed(5)
+        x1 = (s + 0.1 * torch.randn(s.shape, generator=g)).cuda().to(torch.bfloat16)     # the next step's latents: a small move
+        args = (t.cuda(), e.cuda(), te.cuda(), ti.cuda())
+        sync = PatchParallelUNet(net)
+        want0, want1 = sync.forward(x0, *args), sync.forward(x1, *args)
+        res = {}
+        for mode in ("stale_gn", "corrected_async_gn"):
+            pp = PatchParallelUNet(net, mode=mode, warmup_steps=1)
+            a = pp.forward(x0, *args)                    # warm-up: synchronous, fills the state
+            assert pp.last_step_mode == lib.PP_WARMUP
+            b = pp.forward(x0, *args)                    # stale step on unchanged inputs: what it reads stale equals what is fresh
+            assert pp.last_step_mode == lib.PP_STALE
+            c = pp.forward(x1, *args)                    # stale step on moved inputs: the other rank's rows lag one step
+            d = pp.forward(x1, *args)                    # the inputs stop moving: the lag is gone one step later
+            pp.reset()
+            torch.cuda.synchronize()
+            nrm = float(want1.float().norm())
+            l2 = lambda u, v: float((u.float() - v.float()).norm()) / nrm
+            res[mode] = (bool(torch.equal(a, want0)), bool(torch.equal(b, want0)), l2(c, want1), l2(c, want0), l2(d, want1), l2(want1, want0))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_stale_async_steps(cuda_device):
+    """mx_unet_forward_pp_stale: a warm-up step is the synchronous step; a stale step with unchanged inputs reproduces it bit for bit
+    (every stale slot equals the fresh one); with moved inputs it lands between: closer to the synchronous result of the new inputs than the
+    old output is, and one more step on the same inputs removes most of the lag (only second-order staleness inside the network is left)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stale_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        for mode, (warm_eq, same_eq, lag, old, settled, moved) in res[rank].items():
+            print(f"rank {rank} {mode}: relative L2 of the stale step to the synchronous result {lag:.4f} (to the old output {old:.4f}; the inputs "
+                  f"moved the synchronous output by {moved:.4f}); one more step on the same inputs {settled:.4f}")
+            assert warm_eq, f"{mode}: the warm-up step must equal the synchronous step"
+            assert same_eq, f"{mode}: a stale step on unchanged inputs must equal the synchronous step"
+            assert lag < 0.75 * moved, f"{mode}: stale step too far from the synchronous result (rel L2 {lag}; the inputs moved it {moved})"
+            assert lag < old, f"{mode}: the stale step must be nearer the new synchronous result than the old one"
+            assert settled < lag, f"{mode}: the lag must shrink once the inputs stop moving"
