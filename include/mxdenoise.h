@@ -363,6 +363,19 @@ int mx_mmdit_forward_trace(mx_mmdit* u, void* stream, const void* latents, int i
                            const void* pooled, void* out, int batch, int H, int W, int ctx_len, void* workspace,
                            size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes);
 
+/* Patch parallelism for the SD3 / SD3.5 transformer (distrifuser models/distri_sd3_transformer_pp.py:87-97: the positional embedding is taken
+ * for the whole grid, then the image tokens are sliced by rank; modules/pp/attn.py:202-277: the joint attention keeps its local queries -- this
+ * rank's image tokens and the text tokens -- and gathers the other ranks' image K / V; the text stream is computed by every rank).
+ * Rank r owns latent rows [r * H_local, (r + 1) * H_local); (H_local / patch_size) * (W / patch_size) must be a multiple of 16.
+ * Per joint block: one all-gather of the local q|k rows, one of the local V^T (attn2 of the dual blocks: two more).  stale = NULL: every step
+ * synchronous; otherwise as mx_unet_forward_pp_stale.  Equal to mx_mmdit_forward on the whole latent up to the GEMM tile selection. */
+size_t mx_mmdit_workspace_bytes_pp(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, int world);
+size_t mx_mmdit_pp_state_bytes(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, int world);
+int mx_mmdit_forward_pp(mx_mmdit* u, void* stream, const void* latents_local, int io_dtype, const float* timesteps, const void* encoder_hidden_states,
+                        const void* pooled_projections, void* out_local, int batch, int H_local, int W, int ctx_len, const mx_pp_comm* comm,
+                        const mx_pp_stale* stale, void* workspace, size_t workspace_bytes);
+int mx_mmdit_pp_comm_plan(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, const mx_pp_comm* comm);
+
 /* ------------------------------------------------------------------------------------------
  * The step after the loop: the SDXL VAE decoder (AutoencoderKL.decode as post_inference calls it,
  * pipelines/stable_diffusion_xl/pipeline_stable_diffusion_xl_esymred.py:406-463).  SURVEY.md section 8f rank 2.

@@ -24,6 +24,7 @@
 #include "../../include/mxdenoise.h"
 #include "common.h"
 #include "graph_cache.h"
+#include "pp_exchange.h"
 
 namespace mx {
 int launch_patchify(hipStream_t s, const void* in, int dtype, void* out, int B, int C, int H, int W, int ps);
@@ -64,6 +65,21 @@ struct Plan {
   bool dry, lookup = false;
   bool mute = false;               // block-skip cache: the block is reused, nothing of it is launched
   bool quiet() const { return dry || mute; }
+  // patch parallelism (mx_mmdit_forward_pp; distrifuser models/distri_sd3_transformer_pp.py:87-97, modules/pp/attn.py:202-277): this rank owns
+  // the image tokens of H (local) latent rows; the text stream is computed by every rank; K / V^T of the image tokens are all-gathered
+  mx::PPExchange px;
+  bool is_pp() const { return px.world > 1; }
+  bool all_gather(const void* send, void* recv, size_t bytes_per_rank) {
+    if (!ok()) return false;
+    if (const char* e = px.all_gather(stream, dry, send, recv, bytes_per_rank)) return fail(e);
+    return true;
+  }
+  bool copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    if (!ok()) return false;
+    if (quiet()) return true;
+    if (hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("patch-parallel: K / V assembly copy failed");
+    return true;
+  }
   mx_block_cache* bc = nullptr;    // mx_mmdit_forward_cached
   size_t bc_bytes = 0;             // state bytes the plan needs (also the dry answer of mx_mmdit_block_cache_bytes)
   unsigned long long blocks_run = 0;
@@ -133,6 +149,14 @@ struct Plan {
       return fail(std::string("attention: ") + mx_last_error());
     return true;
   }
+  // queries and keys from different buffers / of different counts (patch-parallel: local queries, gathered keys)
+  bool attention_qk(const bf16_t* q, const bf16_t* k, int d_model, const bf16_t* vt, int ldvt, bf16_t* o, int heads, int Lq, int Lk) {
+    if (!ok()) return false;
+    if (quiet()) return true;
+    if (mx_attention_prescaled(stream, q, 2 * d_model, k, 2 * d_model, vt, ldvt, (int64_t)d_model * ldvt, o, d_model, B, heads, Lq, Lk))
+      return fail(std::string("attention: ") + mx_last_error());
+    return true;
+  }
   void dump(const std::string& name, const bf16_t* t, size_t elems) {
     if (!stage || quiet() || !ok() || stage_hit) return;
     if (name != stage) return;
@@ -155,6 +179,12 @@ struct Plan {
     const int ldvt_i = (MX_VT_LD(L) + 63) / 64 * 64;
     const int Kp = ps * ps * c.in_channels;
     const int MI = B * L, MT = B * Lt;
+    // patch-parallel: L counts this rank's image tokens; the keys of the joint attention are all ranks' image tokens, then the text tokens
+    const int world = px.world;
+    const int Ltot = L * world, Ljt = Ltot + Lt;
+    const int ldvt_jt = (MX_VT_LD(Ljt) + 63) / 64 * 64, ldvt_it = (MX_VT_LD(Ltot) + 63) / 64 * 64;
+    if (is_pp() && L % 16 != 0) return fail("mmdit pp: local image tokens must be a multiple of 16 (V^T key order, MX_VT_POS)");
+    if (is_pp() && bc) return fail("mmdit pp: not combined with the block-skip cache");
 
     // ---- AdaLN column layout of the one projection GEMM ----
     std::vector<int> off_img(c.num_layers), off_ctx(c.num_layers);
@@ -182,10 +212,13 @@ struct Plan {
     // ---- PatchEmbed + positional table (:82-83), context_embedder (:115) ----
     bf16_t* patches = alloc<bf16_t>((size_t)MI * Kp);
     if (ok() && !dry && mx::launch_patchify(stream, latents, io_dtype, patches, B, c.in_channels, H, W, ps)) fail(mx_last_error());
-    bf16_t* pos = alloc<bf16_t>((size_t)L * d);
+    bf16_t* pos = alloc<bf16_t>((size_t)Ltot * d);
     {
+      // the centre crop is taken for the WHOLE grid (distri_sd3_transformer_pp.py:87 embeds before it slices); this rank reads its rows
       const bf16_t* table = wb("pos_embed.table", (size_t)c.pos_embed_max_size * c.pos_embed_max_size * d);
-      if (ok() && !dry && mx::launch_crop_pos(stream, table, pos, c.pos_embed_max_size, h, wd, d)) fail(mx_last_error());
+      if (h * world > c.pos_embed_max_size) return fail("mmdit: latent larger than the positional table");
+      if (ok() && !dry && mx::launch_crop_pos(stream, table, pos, c.pos_embed_max_size, h * world, wd, d)) fail(mx_last_error());
+      if (pos) pos += (size_t)px.rank * L * d;
     }
     bf16_t* x = alloc<bf16_t>((size_t)MI * d);
     linear(patches, Kp, "pos_embed.proj", x, d, MI, d, Kp, MX_EPI_RES_BCAST, pos, d, nullptr, 0, L);
@@ -206,6 +239,32 @@ struct Plan {
     bf16_t* o_i = alloc<bf16_t>((size_t)MI * d);
     bf16_t* ff = alloc<bf16_t>((size_t)MI * 4 * d);
     bf16_t* ffc = alloc<bf16_t>((size_t)MT * 4 * d);
+    // patch-parallel: receive buffers of the two all-gathers (rank-major copies of the local q|k rows and V^T) and the assembled operands
+    bf16_t *qk_g = nullptr, *vt_g = nullptr, *kq_all = nullptr, *vt_all = nullptr;
+    if (is_pp()) {
+      qk_g = alloc<bf16_t>((size_t)world * B * Lj * 2 * d);
+      vt_g = alloc<bf16_t>((size_t)world * B * d * ldvt_j);
+      kq_all = alloc<bf16_t>((size_t)B * Ljt * 2 * d);
+      vt_all = alloc<bf16_t>((size_t)B * d * ldvt_jt);
+    }
+    // K rows and V^T columns of every rank's `L` image tokens, then the `tail` local-only (text) tokens, per sample:
+    // kq_all [B][world * L + tail][2d] (whole q|k rows are moved, k is the second half), vt_all [B][d][ld_all]
+    auto gather_kv = [&](bf16_t* qk_loc, bf16_t* vt_loc, int ld_loc, int tail, int ld_all) {
+      const int rows_loc = L + tail, rows_all = Ltot + tail;
+      const size_t qrow = (size_t)2 * d * 2;
+      all_gather(qk_loc, qk_g, (size_t)B * rows_loc * qrow);
+      all_gather(vt_loc, vt_g, (size_t)B * d * ld_loc * 2);
+      for (int r = 0; r < world && ok(); ++r) {
+        copy2d((char*)kq_all + (size_t)r * L * qrow, rows_all * qrow, (char*)qk_g + (size_t)r * B * rows_loc * qrow, rows_loc * qrow, L * qrow, B);
+        copy2d((char*)vt_all + (size_t)r * L * 2, (size_t)ld_all * 2, (char*)vt_g + (size_t)r * B * d * ld_loc * 2, (size_t)ld_loc * 2, (size_t)L * 2,
+               (size_t)B * d);
+      }
+      if (tail) {
+        copy2d((char*)kq_all + (size_t)Ltot * qrow, rows_all * qrow, (char*)qk_loc + (size_t)L * qrow, rows_loc * qrow, tail * qrow, B);
+        copy2d((char*)vt_all + (size_t)Ltot * 2, (size_t)ld_all * 2, (char*)vt_loc + (size_t)L * 2, (size_t)ld_loc * 2, (size_t)MX_VT_LD(tail) * 2,
+               (size_t)B * d);
+      }
+    };
 
     // Block-skip cache (mx_mmdit_forward_cached; the reference's per-block CacheManagers, SD3Transformer.py:54-57,151,172,219-228): a block
     // runs when any sample asks (state_mask.sum() > 0), otherwise the image and context streams take the values the block produced last
@@ -266,11 +325,19 @@ struct Plan {
       // joint attention (attention.py:256-372): image rows first, then text rows
       qkv(xin, b + ".attn.to_qkv", b + ".attn.norm_q.weight", b + ".attn.norm_k.weight", qk_j, vt_j, ldvt_j, MI, d, L, Lj, 0);
       qkv(cin, b + ".attn.add_qkv", b + ".attn.norm_added_q.weight", b + ".attn.norm_added_k.weight", qk_j, vt_j, ldvt_j, MT, d, Lt, Lj, L);
+      if (is_pp()) {
+        gather_kv(qk_j, vt_j, ldvt_j, Lt, ldvt_jt);
+        attention_qk(qk_j, kq_all + d, d, vt_all, ldvt_jt, o_j, heads, Lj, Ljt);
+      } else
       attention(qk_j, d, vt_j, ldvt_j, o_j, heads, Lj);
       // x += gate_msa * to_out(attn[:, :L])                                   (transformer.py:344-345)
       linear(o_j, d, b + ".attn.to_out.0", x, d, MI, d, d, 0, x, d, mi + 2 * d, ntot, L, Lj, 0);
       if (dual) {                                                             // attn2: image-only self-attention (:347-357)
         qkv(x2in, b + ".attn2.to_qkv", b + ".attn2.norm_q.weight", b + ".attn2.norm_k.weight", qk_i, vt_i, ldvt_i, MI, d, L, 0, 0);
+        if (is_pp()) {
+          gather_kv(qk_i, vt_i, ldvt_i, 0, ldvt_it);
+          attention_qk(qk_i, kq_all + d, d, vt_all, ldvt_it, o_i, heads, L, Ltot);
+        } else
         attention(qk_i, d, vt_i, ldvt_i, o_i, heads, L);
         linear(o_i, d, b + ".attn2.to_out.0", x, d, MI, d, d, 0, x, d, mi + 8 * d, ntot, L);
       }
@@ -314,11 +381,14 @@ int check_cfg(const mx_mmdit_config* c) {
 
 int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
                  const void* pooled, void* out, int batch, int H, int W, int ctx_len, void* workspace, size_t workspace_bytes,
-                 const char* stage, void* stage_out, size_t stage_bytes, bool dry, size_t* peak, bool lookup = false) {
+                 const char* stage, void* stage_out, size_t stage_bytes, bool dry, size_t* peak, bool lookup = false,
+                 const mx_pp_comm* comm = nullptr, const mx_pp_stale* stale = nullptr, size_t* state_need = nullptr) {
   MX_CHECK(u != nullptr, "mmdit: null handle");
   MX_CHECK(batch > 0 && H > 0 && W > 0 && ctx_len > 0, "mmdit: bad shape");
   MX_CHECK(H % u->cfg.patch_size == 0 && W % u->cfg.patch_size == 0, "mmdit: H, W must be multiples of patch_size");
   MX_CHECK(H / u->cfg.patch_size <= u->cfg.pos_embed_max_size && W / u->cfg.patch_size <= u->cfg.pos_embed_max_size, "mmdit: latent larger than the positional table");
+  const bool pp = comm != nullptr && comm->world > 1;
+  if (pp) MX_CHECK(comm->rank >= 0 && comm->rank < comm->world && (dry || comm->all_gather != nullptr), "mmdit pp: bad communicator");
   if (!dry) {
     MX_CHECK(latents && timesteps && ehs && pooled && out && workspace, "mmdit: null operand");
     MX_CHECK(u->blob != nullptr, "mmdit: weights not set");
@@ -331,13 +401,15 @@ int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, c
     p.u = u; p.stream = s; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
     p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
     p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
+    if (pp) p.px.set(comm, stale);
     const bool okr = p.run(latents, io_dtype, timesteps, ehs, pooled, out);
     plan_peak = p.ar.peak;
+    if (state_need) *state_need = p.px.state_top;
     if (!okr) err = p.err;
     return okr;
   };
   bool okr;
-  if (dry || stage) {
+  if (dry || stage || pp) {     // (the all-gather callbacks of a patch-parallel forward cannot be captured)
     okr = enqueue((hipStream_t)stream);
   } else {
     const std::vector<uint64_t> key = {(uint64_t)batch, (uint64_t)H, (uint64_t)W, (uint64_t)ctx_len, (uint64_t)io_dtype,
@@ -396,6 +468,47 @@ extern "C" int mx_mmdit_forward(mx_mmdit* u, void* stream, const void* latents, 
                                 void* workspace, size_t workspace_bytes) {
   return forward_impl(u, stream, latents, io_dtype, timesteps, ehs, pooled, out, batch, H, W, ctx_len, workspace, workspace_bytes,
                       nullptr, nullptr, 0, false, nullptr);
+}
+
+/* ---- patch parallelism (distrifuser models/distri_sd3_transformer_pp.py, modules/pp/attn.py:202-277) ---- */
+extern "C" size_t mx_mmdit_workspace_bytes_pp(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, int world) {
+  if (!u) return 0;
+  size_t peak = 0;
+  mx_pp_comm c; c.rank = 0; c.world = world; c.all_gather = nullptr; c.ctx = nullptr;
+  if (forward_impl(const_cast<mx_mmdit*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, batch, H_local, W, ctx_len, nullptr, 0,
+                   nullptr, nullptr, 0, true, &peak, false, &c))
+    return 0;
+  return peak + 4096;
+}
+
+extern "C" size_t mx_mmdit_pp_state_bytes(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, int world) {
+  if (!u) return 0;
+  size_t need = 0;
+  mx_pp_comm c; c.rank = 0; c.world = world; c.all_gather = nullptr; c.ctx = nullptr;
+  mx_pp_stale st{}; st.mode = MX_PP_WARMUP;
+  if (forward_impl(const_cast<mx_mmdit*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, batch, H_local, W, ctx_len, nullptr, 0,
+                   nullptr, nullptr, 0, true, nullptr, false, &c, &st, &need))
+    return 0;
+  return need + 256;
+}
+
+extern "C" int mx_mmdit_forward_pp(mx_mmdit* u, void* stream, const void* latents_local, int io_dtype, const float* timesteps, const void* ehs,
+                                   const void* pooled, void* out_local, int batch, int H_local, int W, int ctx_len, const mx_pp_comm* comm,
+                                   const mx_pp_stale* stale, void* workspace, size_t workspace_bytes) {
+  MX_CHECK(comm != nullptr, "mmdit_forward_pp: null communicator");
+  if (stale) {
+    MX_CHECK(stale->mode == MX_PP_WARMUP || stale->mode == MX_PP_STALE, "mmdit_forward_pp: stale->mode must be MX_PP_WARMUP or MX_PP_STALE");
+    MX_CHECK(stale->state != nullptr && ((uintptr_t)stale->state & 255) == 0, "mmdit_forward_pp: state must be 256-byte aligned device memory");
+    MX_CHECK(stale->mode != MX_PP_STALE || stale->all_gather_async != nullptr, "mmdit_forward_pp: a stale step needs all_gather_async");
+  }
+  return forward_impl(u, stream, latents_local, io_dtype, timesteps, ehs, pooled, out_local, batch, H_local, W, ctx_len, workspace, workspace_bytes,
+                      nullptr, nullptr, 0, false, nullptr, false, comm, stale);
+}
+
+extern "C" int mx_mmdit_pp_comm_plan(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, const mx_pp_comm* comm) {
+  MX_CHECK(u && comm && comm->all_gather, "mmdit_pp_comm_plan: bad arguments");
+  return forward_impl(const_cast<mx_mmdit*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, batch, H_local, W, ctx_len, nullptr, 0,
+                      nullptr, nullptr, 0, true, nullptr, false, comm);
 }
 
 /* ---- block-skip cache (include/mxdenoise.h; SD3Transformer.py:151-228 with cache_manager.py:163-191) ---- */

@@ -17,7 +17,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <algorithm>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -27,6 +26,7 @@
 #include "../../include/mxdenoise.h"
 #include "common.h"
 #include "graph_cache.h"
+#include "pp_exchange.h"
 
 namespace mx {
 int launch_prep_latent(hipStream_t s, const void* in, int dtype, void* out, int B, int Cin, int HW, int CP);
@@ -80,11 +80,7 @@ struct Plan {
   bool dry;                 // size-only pass: no launches
   bool mute = false;        // block-skip cache: walk a block's plan (allocations, weight / K-V / time-embedding cursors) without launching it
   bool quiet() const { return dry || mute; }
-  // stale-asynchronous patch parallelism (mx_unet_forward_pp_stale): every exchange owns a region of the persistent state
-  int pp_mode = 0;                // MX_PP_SYNC / MX_PP_WARMUP / MX_PP_STALE
-  bool pp_corrected_gn = false;
-  char* pp_state = nullptr; size_t pp_state_bytes = 0, pp_state_top = 0;
-  mx_allgather_inplace_fn pp_ag_async = nullptr;
+  mx::PPExchange px;              // the exchange itself, synchronous / warm-up / stale (pp_exchange.h)
   mx_block_cache* bc = nullptr;   // mx_unet_forward_cached
   char* bc_top = nullptr;         // bump pointer into bc->state: same order and sizes every step
   unsigned blocks_run = 0;
@@ -94,7 +90,6 @@ struct Plan {
   std::string err;
   // patch-parallel (mx_unet_forward_pp): this rank owns H (local) of Htot latent rows; distrifuser sync mode (utils.py:119-214)
   int pp_rank = 0, pp_world = 1, Htot = 0;
-  mx_allgather_fn pp_ag = nullptr; void* pp_ctx = nullptr;
   bool is_pp() const { return pp_world > 1; }
   // per-forward tensors
   float* temb_all = nullptr; int temb_total = 0; int temb_off = 0;
@@ -125,33 +120,9 @@ struct Plan {
   bool ok() const { return err.empty(); }
 
   // ---- patch-parallel helpers --------------------------------------------------------------
-  // keep_stale_own (stale mode only): recv keeps the stale copy of this rank's slot too (the corrected GroupNorm needs it)
   bool all_gather(const void* send, void* recv, size_t bytes_per_rank, bool keep_stale_own = false) {
     if (!ok()) return false;
-    char* region = nullptr;
-    if (pp_mode != MX_PP_SYNC) {             // the exchanges of a forward come in a fixed order: exchange k owns region k of the state
-      region = pp_state + pp_state_top;
-      pp_state_top += ((size_t)pp_world * bytes_per_rank + 255) & ~(size_t)255;
-      if (!dry && pp_state_top > pp_state_bytes) return fail("patch-parallel: state buffer too small (mx_unet_pp_state_bytes)");
-    }
-    if (dry && !pp_ag) return true;          // sizing pass
-    if (dry || pp_mode != MX_PP_STALE) {
-      // dry with a callback (mx_unet_pp_comm_plan): the callback sees the arena's placeholder addresses (0x1000 + offset)
-      if (pp_ag(pp_ctx, stream, send, recv, bytes_per_rank)) return fail("patch-parallel all_gather failed");
-      // a warm-up step leaves what it gathered behind for the first stale step (distrifuser: the buffers registered during warm-up)
-      if (!dry && pp_mode == MX_PP_WARMUP &&
-          hipMemcpyAsync(region, recv, (size_t)pp_world * bytes_per_rank, hipMemcpyDeviceToDevice, stream) != hipSuccess)
-        return fail("patch-parallel: state copy failed");
-      return true;
-    }
-    // stale step (utils.py:180-214, modules/pp/*.py `counter > warmup_steps`): the other ranks' slots are what they sent LAST step, this
-    // rank's slot is fresh; the fresh slot goes out through the asynchronous collective and is read by the others NEXT step
-    const size_t own = (size_t)pp_rank * bytes_per_rank;
-    bool e = hipMemcpyAsync(recv, region, (size_t)pp_world * bytes_per_rank, hipMemcpyDeviceToDevice, stream) != hipSuccess;
-    if (!keep_stale_own) e |= hipMemcpyAsync((char*)recv + own, send, bytes_per_rank, hipMemcpyDeviceToDevice, stream) != hipSuccess;
-    e |= hipMemcpyAsync(region + own, send, bytes_per_rank, hipMemcpyDeviceToDevice, stream) != hipSuccess;
-    if (e) return fail("patch-parallel: stale assembly failed");
-    if (pp_ag_async(pp_ctx, stream, region, bytes_per_rank)) return fail("patch-parallel asynchronous all_gather failed");
+    if (const char* e = px.all_gather(stream, dry, send, recv, bytes_per_rank, keep_stale_own)) return fail(e);
     return true;
   }
   // [B, h + 2, wd, C] image with one halo row above and below; returns the base (the top halo row of image 0)
@@ -205,7 +176,7 @@ struct Plan {
       if (mx::launch_gn_pp_partial(stream, x, C1, x2, B, h, wd, C, G, ws, sums)) return fail(std::string("groupnorm: ") + mx_last_error());
       // stale steps: "stale_gn" = fresh own sums beside the others' stale ones; "corrected_async_gn" (distrifuser's default,
       // modules/pp/groupnorm.py:52-66) = the stale whole-image moments plus this rank's (fresh - stale) change, local variance if negative
-      const bool corrected = pp_mode == MX_PP_STALE && pp_corrected_gn;
+      const bool corrected = px.mode == MX_PP_STALE && px.corrected_gn;
       if (!all_gather(sums, all, (size_t)B * G * 2 * sizeof(double), corrected)) return false;
       if (mx::launch_gn_pp_finish(stream, x, C1, x2, y, y_img, g, b, all, pp_world, B, h, wd, C, G, Htot >> level, eps, silu ? 1 : 0, ws,
                                   corrected ? sums : nullptr, pp_rank))
@@ -753,14 +724,11 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
     p.gn_patch = (gn_patch >= H && gn_patch >= W) ? 0 : gn_patch;
     p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
     p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
-    if (pp) { p.pp_rank = comm->rank; p.pp_world = comm->world; p.pp_ag = comm->all_gather; p.pp_ctx = comm->ctx; p.Htot = H * comm->world; }
-    if (pp && stale) {
-      p.pp_mode = stale->mode; p.pp_corrected_gn = stale->corrected_gn != 0; p.pp_state = (char*)stale->state;
-      p.pp_state_bytes = stale->state_bytes; p.pp_ag_async = stale->all_gather_async;
-    }
+    if (pp) { p.pp_rank = comm->rank; p.pp_world = comm->world; p.Htot = H * comm->world; }
+    if (pp) p.px.set(comm, stale);
     const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
     plan_peak = p.ar.peak;
-    if (state_need) *state_need = p.pp_state_top;
+    if (state_need) *state_need = p.px.state_top;
     if (!okr) err = p.err;
     return okr;
   };

@@ -130,6 +130,10 @@ SYMBOLS = {
     "mx_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_unet_validate": (_i, [_vp, _i, _i, _i, _i]),
     "mx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
+    "mx_mmdit_workspace_bytes_pp": (_sz, [_vp, _i, _i, _i, _i, _i]),
+    "mx_mmdit_pp_state_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
+    "mx_mmdit_forward_pp": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),
+    "mx_mmdit_pp_comm_plan": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "mx_unet_pp_state_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "mx_unet_forward_pp_stale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "mx_unet_block_cache_bytes": (_sz, [_vp, _i, _i, _i]),

@@ -50,7 +50,7 @@ class PatchParallelUNet:
     rank (rows all-gathered).  ``group`` is the torch.distributed group of the ranks sharing the request (distrifuser's
     batch_group, utils.py:93-97)."""
 
-    def __init__(self, unet: MxUNet, group=None, log: Optional[CommLog] = None, mode: str = "sync", warmup_steps: int = 4):
+    def __init__(self, unet, group=None, log: Optional[CommLog] = None, mode: str = "sync", warmup_steps: int = 4):
         """mode: "sync" (every step exchanges fresh tensors; distrifuser "full_sync"), "stale_gn" or "corrected_async_gn" (distrifuser's
         default, utils.py:30-32): `warmup_steps` synchronous steps, then stale-asynchronous ones (mx_unet_forward_pp_stale).  Call
         ``reset()`` when a new request starts (distrifuser resets its counters per generation, models/base_model.py)."""
@@ -191,3 +191,58 @@ class PatchParallelUNet:
         parts = [torch.empty_like(local) for _ in range(self.world)]
         self.dist.all_gather(parts, local, group=self.group)
         return torch.cat(parts, dim=2)
+
+
+class PatchParallelSD3(PatchParallelUNet):
+    """The same for the SD3 / SD3.5 transformer (``mx_mmdit_forward_pp``; distrifuser models/distri_sd3_transformer_pp.py:87-97,
+    modules/pp/attn.py:202-277): rank r owns the image tokens of its latent rows, every rank computes the text stream, each joint block
+    all-gathers the image K / V^T.  ``forward(latents, timestep, encoder_hidden_states, pooled)``."""
+
+    def forward_local(self, latents_local: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                      pooled: torch.Tensor) -> torch.Tensor:
+        u = self.unet                                        # an MxSD3Transformer
+        x = latents_local.contiguous()
+        b, _c, hl, w = x.shape
+        dev = u.device
+        lt = encoder_hidden_states.shape[1]
+        ts = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+        ts = (ts.expand(b) if ts.numel() == 1 else ts).contiguous()
+        ehs = encoder_hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous()
+        pp = pooled.to(device=dev, dtype=torch.bfloat16).contiguous()
+        need = u._lib.mx_mmdit_workspace_bytes_pp(u._handle, b, hl, w, lt, self.world)
+        if need == 0:
+            raise _lib.MxError("mx_mmdit_workspace_bytes_pp: " + u._lib.mx_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty((b, u.cfg.out_channels, hl, w), dtype=x.dtype, device=dev)
+        comm = _lib.PPComm(self.rank, self.world, self._cb, None)
+        self._err = None
+        stale_ref = None
+        if self.mode != "sync":
+            sneed = u._lib.mx_mmdit_pp_state_bytes(u._handle, b, hl, w, lt, self.world)
+            if sneed == 0:
+                raise _lib.MxError("mx_mmdit_pp_state_bytes: " + u._lib.mx_last_error().decode())
+            if self._state is None or self._state.numel() < sneed:
+                self._state = torch.empty(sneed, dtype=torch.uint8, device=dev)
+                self.counter = 0
+            self.wait_pending()
+            stale = _lib.PPStale(self._state.data_ptr(), self._state.numel(),
+                                 _lib.PP_WARMUP if self.counter < self.warmup_steps else _lib.PP_STALE, 0, self._cb_async)
+            self.last_step_mode = stale.mode
+            stale_ref = C.byref(stale)
+            self.counter += 1
+        rc = u._lib.mx_mmdit_forward_pp(u._handle, _lib.current_stream(), x.data_ptr(), _lib.torch_dtype_code(x.dtype), ts.data_ptr(),
+                                        ehs.data_ptr(), pp.data_ptr(), out.data_ptr(), b, hl, w, lt, C.byref(comm), stale_ref,
+                                        self._ws.data_ptr(), self._ws.numel())
+        if self._err is not None:
+            raise self._err
+        _lib.check(rc, "mx_mmdit_forward_pp")
+        return out
+
+    def forward(self, latents: torch.Tensor, timestep, encoder_hidden_states, pooled) -> torch.Tensor:
+        local = self.forward_local(split_rows(latents, self.rank, self.world), timestep, encoder_hidden_states, pooled)
+        host = self.backend == "gloo"
+        mine = local.cpu() if host else local
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        return torch.cat([p.to(local.device) for p in parts], dim=2)

@@ -112,3 +112,34 @@ def test_pp_plan_rejects_bad_geometry():
     assert l.mx_unet_workspace_bytes_pp(h, 2, 8, 64, 77, 8) == 0 and b"multiple of 64" in l.mx_last_error()
     assert l.mx_unet_workspace_bytes_pp(h, 2, 6, 64, 77, 2) == 0            # local rows not divisible by 2^(levels-1)
     l.mx_unet_destroy(h)
+
+
+def test_mmdit_pp_plan_and_state_size_on_host():
+    """the SD3 plan's exchanges, walked on the host: two per joint block (q|k rows, V^T), two more per dual block; state = their receive sizes"""
+    from sduss_amd import config, lib
+    from sduss_amd.transformer_sd3 import mmdit_config_c
+    l = lib.load()
+    pcfg = config.MMDiTConfig.tiny()
+    h = l.mx_mmdit_create(C.byref(mmdit_config_c(pcfg)))
+    assert h
+    world, B, Hl, W, Lt = 2, 2, 16, 32, 77
+    calls = []
+
+    def ag(_ctx, _stream, send, recv, nbytes):
+        calls.append((send - 0x1000, recv - 0x1000, nbytes)); return 0
+    cb = lib.ALLGATHER_FN(ag)
+    comm = lib.PPComm(1, world, cb, None)
+    assert l.mx_mmdit_pp_comm_plan(h, B, Hl, W, Lt, C.byref(comm)) == 0, l.mx_last_error()
+    d = pcfg.num_attention_heads * 64
+    L = (Hl // pcfg.patch_size) * (W // pcfg.patch_size)
+    n_dual = len(pcfg.dual_attention_layers)
+    assert len(calls) == 2 * pcfg.num_layers + 2 * n_dual
+    assert calls[0][2] == B * (L + Lt) * 2 * d * 2               # the local q|k rows of the joint sequence
+    need = l.mx_mmdit_workspace_bytes_pp(h, B, Hl, W, Lt, world)
+    from sduss_amd.patch_parallel import CommLog
+    log = CommLog(); log.calls = calls
+    log.check(need, world)
+    want = sum((world * nb + 255) // 256 * 256 for _s, _r, nb in calls) + 256
+    assert l.mx_mmdit_pp_state_bytes(h, B, Hl, W, Lt, world) == want
+    assert l.mx_mmdit_workspace_bytes_pp(h, B, 2, 4, Lt, world) == 0 and b"multiple of 16" in l.mx_last_error()
+    l.mx_mmdit_destroy(h)

@@ -136,3 +136,73 @@ def test_stale_async_steps(cuda_device):
             assert lag < 0.75 * moved, f"{mode}: stale step too far from the synchronous result (rel L2 {lag}; the inputs moved it {moved})"
             assert lag < old, f"{mode}: the stale step must be nearer the new synchronous result than the old one"
             assert settled < lag, f"{mode}: the lag must shrink once the inputs stop moving"
+
+
+def _sd3_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import sd3_mmdit_ref as ref
+        from sduss_amd import lib
+        from sduss_amd.config import MMDiTConfig
+        from sduss_amd.patch_parallel import CommLog, PatchParallelSD3
+        from sduss_amd.transformer_sd3 import MxSD3Transformer
+        ocfg = ref.MMDiTConfig.tiny()
+        P = ref.init_params(ocfg)
+        net = MxSD3Transformer(MMDiTConfig.tiny(), P, device="cuda:0")
+        lat, t, e, p = ref.make_inputs(ocfg, 2, 32, ctx_len=77)
+        x0 = lat.cuda().to(torch.bfloat16)
+        g = torch.Generator().manual_seed(5)
+        x1 = (lat + 0.1 * torch.randn(lat.shape, generator=g)).cuda().to(torch.bfloat16)
+        args = (t.cuda(), e.cuda(), p.cuda())
+        log = CommLog()
+        sync = PatchParallelSD3(net, log=log)
+        got0 = sync.forward(x0, *args)
+        ncalls = len(log.calls)
+        log.check(sync._ws.numel(), world)
+        got1 = sync.forward(x1, *args)
+        want0, want1 = net.forward_one(x0, *args), net.forward_one(x1, *args)
+        oracle = ref.mmdit_forward(P, ocfg, lat, t, e, p)
+        pp = PatchParallelSD3(net, mode="stale_gn", warmup_steps=1)
+        a = pp.forward(x0, *args)
+        b = pp.forward(x0, *args)
+        assert pp.last_step_mode == lib.PP_STALE
+        c = pp.forward(x1, *args)
+        d = pp.forward(x1, *args)
+        pp.reset()
+        torch.cuda.synchronize()
+        nrm = float(want1.float().norm())
+        l2 = lambda u, v: float((u.float() - v.float()).norm()) / nrm
+        rng = float(want0.float().abs().max())
+        q.put((rank, dict(sync_vs_single=float((got0.float() - want0.float()).abs().max()) / rng,
+                          sync_vs_single1=float((got1.float() - want1.float()).abs().max()) / rng,
+                          oracle=float((got0.float().cpu() - oracle).abs().max()) / float(oracle.abs().max()), ncalls=ncalls,
+                          warm_eq=bool(torch.equal(a, got0)), same_eq=bool(torch.equal(b, got0)), lag=l2(c, got1), old=l2(c, got0),
+                          settled=l2(d, got1), moved=l2(got1, got0))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sd3_two_ranks_equal_one_rank_and_stale_steps(cuda_device):
+    """mx_mmdit_forward_pp: token-split SD3 transformer over two ranks.  Synchronous: the gathered output against the single-rank forward
+    (same arithmetic, other GEMM tiles: the bf16 noise floor) and the fp32 oracle.  Stale: as for the UNet."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sd3_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        r = res[rank]
+        print(f"rank {rank} sd3 pp: {r}")
+        assert r["sync_vs_single"] <= 0.03 and r["sync_vs_single1"] <= 0.03 and r["oracle"] <= 0.04
+        tiny_layers = 4
+        assert r["ncalls"] == 2 * tiny_layers + 2 * 2           # q|k and V^T per joint block, twice more for the two dual blocks
+        assert r["warm_eq"] and r["same_eq"]
+        assert r["lag"] < 0.75 * r["moved"] and r["lag"] < r["old"] and r["settled"] < r["lag"]
