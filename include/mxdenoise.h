@@ -467,6 +467,13 @@ int mx_t5_encode(mx_t5* t, void* stream, const int32_t* ids, void* out, int batc
 #define MX_MSE_UNCACHED 9.2233720368547758e18f      /* float(sys.maxsize), cache_manager.py:19 */
 typedef int (*mx_skip_predict_fn)(void* ctx, int block, int is_up, int n_samples, int n_feat, const float* timesteps, const float* mse,
                                   unsigned char* run_out);
+/* Host-side (no GPU) evaluation of a fitted binary random forest, the form the reference's predictors have (cuML forests; here fitted with
+ * scikit-learn by tools/fit_skip_predictor.py and flattened by sduss_amd/block_cache.py CompiledForest): all trees' nodes in one array, node i
+ * goes to left[i] when x[feature[i]] <= threshold[i] (x in fp32, as scikit-learn evaluates), else right[i]; left[i] < 0 marks a leaf whose
+ * class-1 probability is p1[i]; out[r] = mean over trees > 0.5.  A mx_skip_predict_fn built on it costs microseconds per block. */
+int mx_forest_predict(const int32_t* left, const int32_t* right, const int32_t* feature, const double* threshold, const double* p1,
+                      const int32_t* roots, int n_trees, const float* X, int n_rows, int n_feat, unsigned char* out);
+typedef void (*mx_skip_observe_fn)(void* ctx, int block, int n_samples, const float* out_mse);
 typedef struct mx_block_cache {
   mx_skip_predict_fn predict;
   void* ctx;
@@ -477,6 +484,9 @@ typedef struct mx_block_cache {
   int cached_valid, cached_batch, cached_h, cached_w;
   unsigned blocks_run;        /* out: bit i set = block i ran in the last forward */
   unsigned blocks_run_hi;     /* out: blocks 32..63 (MMDiT) */
+  mx_skip_observe_fn observe; /* optional (NULL): after a block RAN while its previous output was cached, the per-sample mean squared difference
+                                 between the new and the previous hidden-state output -- the label a predictor is fitted on (the reference's
+                                 files are named for it: exp/sdxl-upsample-threshold0.01.pkl); tools/fit_skip_predictor.py */
 } mx_block_cache;
 size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, int W);
 int mx_unet_forward_cached(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,

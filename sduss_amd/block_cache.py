@@ -8,7 +8,8 @@ per sample and answers run / reuse, and a sample that reused a block four times 
   * ``BlockSkipCache`` keeps the device state, the per-sample reuse counters and the ctypes callback;
   * the predictors the reference loads are cuML random forests pickled with joblib (ESYMRED_UPSAMPLE_PATH /
     ESYMRED_DOWNSAMPLE_PATH) and cannot be loaded without cuML -- any object with ``.predict(features) -> 0/1 per row`` is
-    accepted, and ``ThresholdPredictor`` is the rule shipped here.
+    accepted; tools/fit_skip_predictor.py re-fits scikit-learn forests of the same kind from traces of this denoiser,
+    ``CompiledForest`` evaluates them natively (mx_forest_predict), and ``ThresholdPredictor`` is the rule shipped without any fitting.
 
 Granularity is the step batch (see the header): the library reuses a block only when no sample asks to run it.
 """
@@ -37,6 +38,44 @@ class ThresholdPredictor:
         return (features[:, 2:].max(axis=1) > self.threshold).astype(np.int64)
 
 
+class CompiledForest:
+    """A fitted scikit-learn RandomForestClassifier (binary) flattened for mx_forest_predict: same answers as ``forest.predict`` without
+    its per-call overhead (0.4 ms per call through joblib / validation -- 24 calls per SD3 step cost more than the blocks they save)."""
+
+    def __init__(self, forest):
+        classes = list(getattr(forest, "classes_", [0, 1]))
+        left, right, feat, thr, p1, roots = [], [], [], [], [], []
+        base = 0
+        for est in forest.estimators_:
+            t = est.tree_
+            n = t.node_count
+            roots.append(base)
+            cl, cr = t.children_left.astype(np.int64), t.children_right.astype(np.int64)
+            left.append(np.where(cl >= 0, cl + base, -1)); right.append(np.where(cr >= 0, cr + base, -1))
+            feat.append(t.feature.astype(np.int64)); thr.append(t.threshold.astype(np.float64))
+            v = t.value[:, 0, :].astype(np.float64)                 # [nodes, classes]: counts or fractions, normalised per node below
+            tot = v.sum(axis=1)
+            one = v[:, classes.index(1)] if 1 in classes else np.zeros(n)
+            p1.append(np.where(tot > 0, one / np.where(tot > 0, tot, 1.0), 0.0))
+            base += n
+        as32 = lambda a: np.ascontiguousarray(np.concatenate(a), dtype=np.int32)
+        self.left, self.right, self.feature = as32(left), as32(right), as32(feat)
+        self.threshold = np.ascontiguousarray(np.concatenate(thr), dtype=np.float64)
+        self.p1 = np.ascontiguousarray(np.concatenate(p1), dtype=np.float64)
+        self.roots = np.ascontiguousarray(roots, dtype=np.int32)
+        self.n_features = int(forest.n_features_in_)
+        self._lib = _lib.load()
+
+    def predict(self, features: np.ndarray) -> np.ndarray:
+        X = np.ascontiguousarray(features, dtype=np.float32)
+        assert X.ndim == 2 and X.shape[1] == self.n_features
+        out = np.zeros(X.shape[0], dtype=np.uint8)
+        _lib.check(self._lib.mx_forest_predict(self.left.ctypes.data, self.right.ctypes.data, self.feature.ctypes.data, self.threshold.ctypes.data,
+                                               self.p1.ctypes.data, self.roots.ctypes.data, len(self.roots), X.ctypes.data, X.shape[0], X.shape[1],
+                                               out.ctypes.data), "mx_forest_predict")
+        return out.astype(np.int64)
+
+
 def decide(mask: np.ndarray, previous: np.ndarray, forced_after: int = FORCED_RUN_AFTER):
     """The reference's post-processing of a predictor's answer (cache_manager.py:134-136 = 154-156): a sample whose counter reached
     ``forced_after`` runs; the counter resets on a run and counts reuses otherwise.  Returns (run mask, new counters)."""
@@ -52,13 +91,22 @@ class BlockSkipCache:
     """State for one stream of steps over one batch composition.  ``down`` decides the down and mid blocks, ``up`` the up blocks
     (downsample_predictor / upsample_predictor of the reference)."""
 
-    def __init__(self, down, up=None, forced_after: int = FORCED_RUN_AFTER):
-        self.down, self.up = down, (up if up is not None else down)
+    def __init__(self, down, up=None, forced_after: int = FORCED_RUN_AFTER, observe: bool = False):
+        """observe=True records, for every block that ran, how far its output moved since its last run (``self.observed``: (block,
+        mse per sample)) next to the feature rows the predictor saw (``self.features``) -- what tools/fit_skip_predictor.py fits on."""
+        # fitted scikit-learn forests are flattened once and evaluated natively (CompiledForest: same answers, ~100x less per call)
+        wrap = lambda p: CompiledForest(p) if hasattr(p, "estimators_") and hasattr(p, "n_features_in_") else p
+        self.down, self.up = wrap(down), wrap(up if up is not None else down)
         self.forced_after = forced_after
         self.state: Optional[torch.Tensor] = None
         self.desc = _lib.BlockCacheC()
         self._cb = _lib.SKIP_PREDICT_FN(self._predict)       # kept alive with the object
         self.desc.predict = self._cb
+        self.observed, self.features = [], []
+        self._record = observe
+        if observe:
+            self._cb_obs = _lib.SKIP_OBSERVE_FN(self._observe)
+            self.desc.observe = self._cb_obs
         self.previous = {}                                   # block -> int64[batch]
         self.decisions = []                                  # (block, run mask) of the last forward
         self.history = []                                    # blocks_run bit mask per forward
@@ -70,6 +118,8 @@ class BlockSkipCache:
             ts = np.ctypeslib.as_array(timesteps, shape=(n,)).astype(np.float64)
             m = np.ctypeslib.as_array(mse, shape=(n, nf)).astype(np.float64)
             feats = np.concatenate([np.full((n, 1), float(block)), ts[:, None], m], axis=1)
+            if self._record:
+                self.features.append(feats.copy())
             prev = self.previous.get(block)
             if prev is None or prev.shape[0] != n or bool((m[:, 0] >= MSE_UNCACHED * 0.5).any()):
                 prev = np.zeros(n, dtype=np.int64)           # "0 if not in the cache" (cache_manager.py:128,150)
@@ -82,6 +132,9 @@ class BlockSkipCache:
         except BaseException as e:                           # never unwind through the C frame
             self.error = e
             return 1
+
+    def _observe(self, _ctx, block, n, out_mse):
+        self.observed.append((int(block), np.ctypeslib.as_array(out_mse, shape=(n,)).astype(np.float64).copy()))
 
     def bind(self, model, batch: int, h: int, w: int, batch_key: int, ctx_len: Optional[int] = None):
         """size / (re)allocate the device state for `model` (MxUNet, or MxMMDiT when ctx_len is given) and return the descriptor"""

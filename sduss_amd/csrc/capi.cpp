@@ -85,3 +85,25 @@ extern "C" int mx_profile_records(double* out, int max_records) {
   }
   return n;
 }
+
+/* ---- host-side evaluation of a fitted random forest (the block-skip predictor; include/mxdenoise.h) ---- */
+extern "C" int mx_forest_predict(const int32_t* left, const int32_t* right, const int32_t* feature, const double* threshold, const double* p1,
+                                 const int32_t* roots, int n_trees, const float* X, int n_rows, int n_feat, unsigned char* out) {
+  MX_CHECK(left && right && feature && threshold && p1 && roots && X && out && n_trees > 0 && n_rows >= 0 && n_feat > 0,
+           "forest_predict: bad arguments");
+  for (int r = 0; r < n_rows; ++r) {
+    const float* x = X + (size_t)r * n_feat;
+    double acc = 0.0;
+    for (int t = 0; t < n_trees; ++t) {
+      int node = roots[t];
+      while (left[node] >= 0) {                            // leaves carry -1 (sklearn TREE_LEAF)
+        const int f = feature[node];
+        if (f < 0 || f >= n_feat) { mx::set_error("forest_predict: feature index outside the row"); return 1; }
+        node = (double)x[f] <= threshold[node] ? left[node] : right[node];
+      }
+      acc += p1[node];
+    }
+    out[r] = acc / n_trees > 0.5 ? 1 : 0;                  // argmax of the mean class probabilities (ties: class 0)
+  }
+  return 0;
+}

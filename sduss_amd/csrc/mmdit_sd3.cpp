@@ -300,6 +300,20 @@ struct Plan {
     };
     auto after = [&](int i, bool ran, bool last) {
       char* st = (char*)bc->state + bc_scratch + (size_t)i * (2 * bc_x + bc_c);
+      if (ran && bc->cached_valid && bc->observe) {          // how far the block's image-stream output moved since its last run (fitting labels)
+        double* part = (double*)bc->state;
+        std::vector<double> hp((size_t)B * 64);
+        std::vector<float> om(B);
+        if (mx::launch_sq_diff_partial(stream, x, st + bc_x, (long)L * d, B, part)) { fail(mx_last_error()); return; }
+        if (hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) { fail("block cache: reading the output differences failed"); return; }
+        for (int s = 0; s < B; ++s) {
+          double t = 0.0;
+          for (int k = 0; k < 64; ++k) t += hp[(size_t)s * 64 + k];
+          om[s] = (float)(t / ((double)L * d));
+        }
+        bc->observe(bc->ctx, i, B, om.data());
+      }
       hipError_t e = ran ? hipMemcpyAsync(st + bc_x, x, (size_t)MI * d * 2, hipMemcpyDeviceToDevice, stream)
                          : hipMemcpyAsync(x, st + bc_x, (size_t)MI * d * 2, hipMemcpyDeviceToDevice, stream);
       if (e == hipSuccess && !last)

@@ -634,6 +634,20 @@ struct Plan {
         char* oc = bc_top; bc_top += (o.per_sample * B * 2 + 255) & ~(size_t)255;
         if ((size_t)(bc_top - (char*)bc->state) > bc->state_bytes) { fail("block cache: state buffer too small (mx_unet_block_cache_bytes)"); return; }
         if (!ok()) return;
+        if (any && bc->cached_valid && bc->observe && o.p == x) {      // how far the block's output moved since its last run (fitting labels)
+          double* part = (double*)bc->state;
+          std::vector<double> hp((size_t)B * 64);
+          std::vector<float> om(B);
+          if (mx::launch_sq_diff_partial(stream, o.p, oc, (long)o.per_sample, B, part)) { fail(mx_last_error()); return; }
+          if (hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+              hipStreamSynchronize(stream) != hipSuccess) { fail("block cache: reading the output differences failed"); return; }
+          for (int b = 0; b < B; ++b) {
+            double t = 0.0;
+            for (int k = 0; k < 64; ++k) t += hp[(size_t)b * 64 + k];
+            om[b] = (float)(t / (double)o.per_sample);
+          }
+          bc->observe(bc->ctx, idx, B, om.data());
+        }
         const hipError_t e = any ? hipMemcpyAsync(oc, o.p, o.per_sample * B * 2, hipMemcpyDeviceToDevice, stream)
                                  : hipMemcpyAsync(o.p, oc, o.per_sample * B * 2, hipMemcpyDeviceToDevice, stream);
         if (e != hipSuccess) { fail("block cache: output copy failed"); return; }

@@ -76,10 +76,13 @@ SKIP_PREDICT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.
 MSE_UNCACHED = 9.2233720368547758e18
 
 
+SKIP_OBSERVE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
+
+
 class BlockCacheC(C.Structure):
     _fields_ = [("predict", SKIP_PREDICT_FN), ("ctx", C.c_void_p), ("state", C.c_void_p), ("state_bytes", C.c_size_t),
                 ("batch_key", C.c_uint64), ("cached_key", C.c_uint64), ("cached_valid", C.c_int), ("cached_batch", C.c_int),
-                ("cached_h", C.c_int), ("cached_w", C.c_int), ("blocks_run", C.c_uint), ("blocks_run_hi", C.c_uint)]
+                ("cached_h", C.c_int), ("cached_w", C.c_int), ("blocks_run", C.c_uint), ("blocks_run_hi", C.c_uint), ("observe", SKIP_OBSERVE_FN)]
 
 
 class CLIPConfigC(C.Structure):
@@ -130,6 +133,7 @@ SYMBOLS = {
     "mx_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_unet_validate": (_i, [_vp, _i, _i, _i, _i]),
     "mx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
+    "mx_forest_predict": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "mx_mmdit_workspace_bytes_pp": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "mx_mmdit_pp_state_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "mx_mmdit_forward_pp": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),

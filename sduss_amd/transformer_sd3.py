@@ -138,12 +138,12 @@ class MxSD3Transformer:
             row += n
         return (out,)
 
-    def enable_block_cache(self, predictor, forced_after: Optional[int] = None) -> None:
+    def enable_block_cache(self, predictor, forced_after: Optional[int] = None, observe: bool = False) -> None:
         """Route forward() through the block-skip cache, one state per resolution key (SD3Transformer.py:151-228 with
         ESYMRED_USE_CACHE=TRUE).  `predictor`: an object with .predict(features) (block_cache.py)."""
         from .block_cache import BlockSkipCache, FORCED_RUN_AFTER_SD3
         fa = FORCED_RUN_AFTER_SD3 if forced_after is None else forced_after
-        self._new_block_cache = lambda: BlockSkipCache(predictor, forced_after=fa)
+        self._new_block_cache = lambda: BlockSkipCache(predictor, forced_after=fa, observe=observe)
         self._block_caches = {}
 
     def disable_block_cache(self) -> None:

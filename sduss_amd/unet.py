@@ -198,12 +198,12 @@ class MxUNet:
             row += n
         return (out,)
 
-    def enable_block_cache(self, down, up=None, forced_after: Optional[int] = None) -> None:
+    def enable_block_cache(self, down, up=None, forced_after: Optional[int] = None, observe: bool = False) -> None:
         """Route forward() through the block-skip cache, one state per resolution key: what ESYMRED_USE_CACHE=TRUE does to the
         reference's model (cache_manager.py:46-50).  `down` / `up`: objects with .predict(features) (block_cache.py)."""
         from .block_cache import BlockSkipCache, FORCED_RUN_AFTER
         fa = FORCED_RUN_AFTER if forced_after is None else forced_after
-        self._new_block_cache = lambda: BlockSkipCache(down, up, forced_after=fa)
+        self._new_block_cache = lambda: BlockSkipCache(down, up, forced_after=fa, observe=observe)
         self._block_caches = {}
 
     def disable_block_cache(self) -> None:

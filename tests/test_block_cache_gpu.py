@@ -328,3 +328,36 @@ def test_model_slot_forward_with_the_cache_enabled(tiny):
     out = net.forward({key: s}, t, e, added_cond_kwargs={"text_embeds": te, "time_ids": ti}, return_dict=False, is_sliced=False,
                       patch_size=256, input_indices={key: ["0", "1"]})[0][key]
     assert torch.equal(out, net.forward_one(s, t, e, te, ti))
+
+
+def test_observer_reports_output_movement_and_fitted_forest_plugs_in(tiny):
+    """observe=True: per block that ran while cached, the mean squared movement of its output (the fitting label, tools/fit_skip_predictor.py);
+    a scikit-learn forest fitted on the recorded rows is a valid predictor object."""
+    from sklearn.ensemble import RandomForestClassifier
+    from sduss_amd.block_cache import BlockSkipCache, MSE_UNCACHED
+    ocfg, net = tiny
+    bc = BlockSkipCache(Always(1), observe=True)
+    s0, t, e, te, ti = _inputs(ocfg, 2, 32, 0)
+    s1, *_ = _inputs(ocfg, 2, 32, 1)
+    net.forward_one_cached(bc, s0, t, e, te, ti, batch_key=1)
+    assert bc.observed == [] and len(bc.features) == 7
+    net.forward_one_cached(bc, s0, t, e, te, ti, batch_key=1)              # nothing moved
+    assert [b for b, _ in bc.observed] == list(range(7)) and all((m == 0).all() for _, m in bc.observed)
+    net.forward_one_cached(bc, s1, t, e, te, ti, batch_key=1)
+    moved = bc.observed[7:]
+    assert [b for b, _ in moved] == list(range(7)) and all((m > 0).all() and m.shape == (2,) for _, m in moved)
+    # rows with a cached input pair one-to-one with the observations
+    cached_rows = [f for f in bc.features if not (f[:, 2] >= MSE_UNCACHED * 0.5).any()]
+    assert len(cached_rows) == len(bc.observed) == 14
+    X = np.concatenate([f for f in cached_rows if f.shape[1] == 3])
+    y = np.concatenate([(m > 1e-6).astype(np.int64) for f, (_, m) in zip(cached_rows, bc.observed) if f.shape[1] == 3])
+    down = RandomForestClassifier(n_estimators=16, bootstrap=False, random_state=0).fit(X, y)
+    Xu = np.concatenate([f for f in cached_rows if f.shape[1] == 6])
+    yu = np.concatenate([(m > 1e-6).astype(np.int64) for f, (_, m) in zip(cached_rows, bc.observed) if f.shape[1] == 6])
+    up = RandomForestClassifier(n_estimators=16, bootstrap=False, random_state=0).fit(Xu, yu)
+    bc2 = BlockSkipCache(down, up)
+    a = net.forward_one_cached(bc2, s0, t, e, te, ti, batch_key=1)
+    b = net.forward_one_cached(bc2, s0, t, e, te, ti, batch_key=1)         # zero movement: the forests learnt "reuse" for it
+    assert bc2.history == [0x7f, 0] and torch.equal(a, b)
+    c = net.forward_one_cached(bc2, s1, t, e, te, ti, batch_key=1)
+    assert bc2.history[-1] == 0x7f and torch.equal(c, net.forward_one(s1, t, e, te, ti))

@@ -546,3 +546,24 @@ def test_mmdit_block_cache_state_size():
     assert l.mx_mmdit_block_cache_bytes(h, B, H, H, Lt) == want
     assert l.mx_mmdit_block_cache_bytes(h, B, H + 1, H, Lt) == 0
     l.mx_mmdit_destroy(h)
+
+
+def test_compiled_forest_equals_sklearn_predict():
+    """CompiledForest / mx_forest_predict: the same answers as RandomForestClassifier.predict on the predictor's feature rows (block index,
+    timestep, input differences spanning 1e-6 .. the uncached marker)"""
+    from sklearn.ensemble import RandomForestClassifier
+    from sduss_amd.block_cache import CompiledForest, MSE_UNCACHED
+    rng = np.random.default_rng(0)
+    for n_feat in (3, 6):
+        X = np.column_stack([rng.integers(0, 7, 4000).astype(np.float64), rng.uniform(0, 1000, 4000)] +
+                            [10.0 ** rng.uniform(-6, 1, 4000) for _ in range(n_feat - 2)])
+        y = ((X[:, 2:].max(axis=1) > 0.01 * (1 + X[:, 0])) ^ (rng.uniform(size=4000) < 0.05)).astype(np.int64)
+        rf = RandomForestClassifier(n_estimators=32, max_depth=8, random_state=0).fit(X, y)
+        cf = CompiledForest(rf)
+        T = np.column_stack([rng.integers(0, 7, 2000).astype(np.float64), rng.uniform(0, 1000, 2000)] +
+                            [10.0 ** rng.uniform(-7, 2, 2000) for _ in range(n_feat - 2)])
+        T[:50, 2:] = MSE_UNCACHED
+        T[50:100, 2] = 0.0
+        assert np.array_equal(cf.predict(T), rf.predict(T))
+    with pytest.raises(AssertionError):
+        cf.predict(np.zeros((2, 4)))
