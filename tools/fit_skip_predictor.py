@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--requests", type=int, default=2)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--threshold", type=float, default=0.01)
+    ap.add_argument("--threshold-quantile", type=float, default=0.0,
+                    help="instead of --threshold: label this fraction of the observed block outputs reusable (random-init weights move far more "
+                         "per step than a trained model, so 0.01 labels nothing)")
     ap.add_argument("--tiny", action="store_true", help="the tiny test configuration (plumbing check)")
     ap.add_argument("--out-dir", default="gpurun_out")
     args = ap.parse_args()
@@ -101,6 +104,11 @@ def main():
     traced, _ = run("cached entry, every block run, observer on")
     assert torch.equal(traced, exact), "every block run must be the exact path"
     cache = net._block_caches[res]
+    moved = np.concatenate([m for _b, m in cache.observed])
+    print("observed output movement (mse) percentiles 5/25/50/75/95: " + " ".join(f"{v:.3g}" for v in np.percentile(moved, [5, 25, 50, 75, 95])))
+    if args.threshold_quantile > 0:
+        args.threshold = float(np.quantile(moved, args.threshold_quantile))
+        print(f"threshold from the {args.threshold_quantile:.2f} quantile: {args.threshold:.4g}")
     X, y = rows_and_labels(cache, args.threshold)
     net.disable_block_cache()
     # 2-3. fit
@@ -108,7 +116,7 @@ def main():
     preds = {}
     for name, n_feat in (("downsample", 3), ("upsample", 6)) if args.model == "sdxl" else (("state", 3),):
         rf, rows, lab = fit(X, y, n_feat)
-        path = os.path.join(args.out_dir, f"{args.model}-{name}-threshold{args.threshold}-mi355x.pkl")
+        path = os.path.join(args.out_dir, f"{args.model}-{name}-threshold{args.threshold:.3g}-mi355x.pkl")
         joblib.dump(rf, path)
         preds[name] = joblib.load(path)
         print(f"{name}: {len(rows)} rows, {100 * (1 - lab.mean()):.1f} % labelled reusable, training accuracy {rf.score(rows, lab):.3f}, "
