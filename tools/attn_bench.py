@@ -12,6 +12,10 @@ from sduss_amd import ops  # noqa: E402
 SHAPES = [(8, 10, 4096, 4096), (8, 20, 1024, 1024), (8, 24, 4429, 4429), (8, 20, 1024, 77), (8, 10, 4096, 77)]   # (B, H, Lq, Lk)
 
 
+if os.environ.get("ATTN_SHAPES") == "cross":      # the short-key launches of a step: 4 requests / 1 request, levels 2 and 1
+    SHAPES = [(8, 20, 1024, 77), (2, 20, 1024, 77), (8, 10, 4096, 77), (2, 10, 4096, 77), (8, 20, 576, 77), (8, 20, 256, 77)]
+
+
 def main():
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
