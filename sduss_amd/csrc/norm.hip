@@ -83,8 +83,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// one wave per (group, image): fp64 fold of tiles x channels-per-group, patch by patch.
-__global__ __launch_bounds__(64) void gn_fold_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+// one workgroup (four waves) per (group, image): fp64 fold of tiles x channels-per-group, patch by patch.  Four waves because the fold is a
+// chain of dependent loads: with one wave the 640..1280 items of a 128 x 128 level took 11 us per launch, 46 launches a step.
+constexpr int kFoldThreads = 256;
+__global__ __launch_bounds__(kFoldThreads) void gn_fold_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ coef,
                                                      GnGeom g, int groups, float eps, int patch) {
   const int grp = blockIdx.x;
@@ -100,19 +102,25 @@ __global__ __launch_bounds__(64) void gn_fold_kernel(const float* __restrict__ p
   const int nitems = tpy * tpx * cpg;
   const double cnt = (double)tpy * tpx * g.th * g.tw * cpg;
   double acc_mean = 0.0, acc_var = 0.0;
+  __shared__ double wsum[kFoldThreads / 64][2];
   for (int pidx = 0; pidx < npatch; ++pidx) {
     const int py = pidx / ppx, px = pidx - py * ppx;
     double s = 0.0, q = 0.0;
-    for (int it = lane; it < nitems; it += 64) {
+    for (int it = lane; it < nitems; it += kFoldThreads) {
       const int tl = it / cpg, c = it - tl * cpg;
       const int iy = tl / tpx, ix = tl - iy * tpx;
       const int tile = (py * tpy + iy) * g.tiles_x + px * tpx + ix;
-      const float* src = part + (((long)b * ntiles + tile) * g.C + grp * cpg + c) * 2;
-      s += (double)src[0];
-      q += (double)src[1];
+      const float2 v = *reinterpret_cast<const float2*>(part + (((long)b * ntiles + tile) * g.C + grp * cpg + c) * 2);
+      s += (double)v.x;
+      q += (double)v.y;
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
+    __syncthreads();                                        // (the previous patch's readers are done with wsum)
+    if ((lane & 63) == 0) { wsum[lane >> 6][0] = s; wsum[lane >> 6][1] = q; }
+    __syncthreads();
+    s = (wsum[0][0] + wsum[1][0]) + (wsum[2][0] + wsum[3][0]);   // fixed order: every thread holds the same sums
+    q = (wsum[0][1] + wsum[1][1]) + (wsum[2][1] + wsum[3][1]);
     const double mean = s / cnt;
     double var = q / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(64) void gn_fold_kernel(const float* __restrict__ p
   }
   const double mean = acc_mean / npatch;
   const double rstd = 1.0 / sqrt(acc_var / npatch + (double)eps);
-  for (int c = lane; c < cpg; c += 64) {
+  for (int c = lane; c < cpg; c += kFoldThreads) {
     const int ch = grp * cpg + c;
     const float sc = (float)(rstd * (double)gamma[ch]);
     const float sf = (float)((double)beta[ch] - rstd * (double)gamma[ch] * mean);
@@ -280,7 +288,7 @@ extern "C" int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const 
   prof_begin(s, PROF_NORM, 0.0, 3.0 * 2.0 * B * H * (double)W * C);  // stats read + apply read + write
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ntiles, B), dim3(threads), smem, s, (const bf16_t*)x, part, g);
   MX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_fold_kernel, dim3(groups, B), dim3(64), 0, s, (const float*)part, gamma, beta, coef, g,
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(groups, B), dim3(kFoldThreads), 0, s, (const float*)part, gamma, beta, coef, g,
                      groups, eps, patch);
   MX_LAUNCH_CHECK();
   const int hw = H * W;
