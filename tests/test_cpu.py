@@ -567,3 +567,38 @@ def test_compiled_forest_equals_sklearn_predict():
         assert np.array_equal(cf.predict(T), rf.predict(T))
     with pytest.raises(AssertionError):
         cf.predict(np.zeros((2, 4)))
+
+
+def test_block_skip_bookkeeping_equals_the_reference_restatement():
+    """BlockSkipCache._predict against oracle/cache_ref.py (cache_manager.py:101-161 line by line) on random predictor answers: same feature
+    rows, same run masks, step after step, for a fixed batch composition (the product keys its state by the composition; a change refills it,
+    where the reference keeps the ids that stay) -- down-type and up-type blocks, both forced-run settings."""
+    from oracle.cache_ref import CacheManagerRef, MAX
+    from sduss_amd.block_cache import BlockSkipCache, MSE_UNCACHED
+    assert np.float32(MAX) == np.float32(MSE_UNCACHED)
+
+    class Scripted:
+        def __init__(self, rng):
+            self.rng, self.last = rng, None
+
+        def predict(self, f):
+            self.last = np.array(f, dtype=np.float64)
+            return (self.rng.uniform(size=len(f)) < 0.35).astype(np.int64)
+    fp = C.POINTER(C.c_float)
+    for forced in (4, 2):
+        for nres in (0, 3):
+            rng_a, rng_b, data = np.random.default_rng(7), np.random.default_rng(7), np.random.default_rng(1)
+            pa, pb = Scripted(rng_a), Scripted(rng_b)
+            refm = CacheManagerRef(pa, forced_after=forced)
+            bc = BlockSkipCache(pb, forced_after=forced)
+            ids = ["r3", "r9", "r4"]
+            n, block = len(ids), 5
+            for step in range(40):
+                ts = data.uniform(0, 1000, n).astype(np.float32)
+                mse = data.uniform(0, 2, (n, 1 + nres)).astype(np.float32)
+                want, feat = refm.get_mask(ids, mse[:, 0], block, ts, res_mse=mse[:, 1:] if nres else None)
+                sent = mse.copy() if step > 0 else np.full_like(mse, MSE_UNCACHED)       # what the library sends for an uncached block
+                out = (C.c_ubyte * n)()
+                assert bc._predict(None, block, int(nres > 0), n, 1 + nres, C.cast(ts.ctypes.data, fp), C.cast(sent.ctypes.data, fp), out) == 0
+                assert np.array_equal(np.array(list(out)) > 0, want), (forced, nres, step)
+                assert np.allclose(pb.last, feat.astype(np.float32).astype(np.float64), rtol=1e-6), (forced, nres, step)
