@@ -367,7 +367,8 @@ int mx_mmdit_forward_trace(mx_mmdit* u, void* stream, const void* latents, int i
  * for the whole grid, then the image tokens are sliced by rank; modules/pp/attn.py:202-277: the joint attention keeps its local queries -- this
  * rank's image tokens and the text tokens -- and gathers the other ranks' image K / V; the text stream is computed by every rank).
  * Rank r owns latent rows [r * H_local, (r + 1) * H_local); (H_local / patch_size) * (W / patch_size) must be a multiple of 16.
- * Per joint block: one all-gather of the local q|k rows, one of the local V^T (attn2 of the dual blocks: two more).  stale = NULL: every step
+ * Per joint block: one all-gather of the image tokens' K rows [batch][L_local][d], one of their V^T columns [batch][d][L_local] (attn2 of the
+ * dual blocks: two more).  stale = NULL: every step
  * synchronous; otherwise as mx_unet_forward_pp_stale.  Equal to mx_mmdit_forward on the whole latent up to the GEMM tile selection. */
 size_t mx_mmdit_workspace_bytes_pp(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, int world);
 size_t mx_mmdit_pp_state_bytes(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, int world);

@@ -149,11 +149,11 @@ struct Plan {
       return fail(std::string("attention: ") + mx_last_error());
     return true;
   }
-  // queries and keys from different buffers / of different counts (patch-parallel: local queries, gathered keys)
+  // queries from the local q|k rows, keys from a packed K buffer of another length (patch-parallel: local queries, gathered keys)
   bool attention_qk(const bf16_t* q, const bf16_t* k, int d_model, const bf16_t* vt, int ldvt, bf16_t* o, int heads, int Lq, int Lk) {
     if (!ok()) return false;
     if (quiet()) return true;
-    if (mx_attention_prescaled(stream, q, 2 * d_model, k, 2 * d_model, vt, ldvt, (int64_t)d_model * ldvt, o, d_model, B, heads, Lq, Lk))
+    if (mx_attention_prescaled(stream, q, 2 * d_model, k, d_model, vt, ldvt, (int64_t)d_model * ldvt, o, d_model, B, heads, Lq, Lk))
       return fail(std::string("attention: ") + mx_last_error());
     return true;
   }
@@ -239,28 +239,34 @@ struct Plan {
     bf16_t* o_i = alloc<bf16_t>((size_t)MI * d);
     bf16_t* ff = alloc<bf16_t>((size_t)MI * 4 * d);
     bf16_t* ffc = alloc<bf16_t>((size_t)MT * 4 * d);
-    // patch-parallel: receive buffers of the two all-gathers (rank-major copies of the local q|k rows and V^T) and the assembled operands
-    bf16_t *qk_g = nullptr, *vt_g = nullptr, *kq_all = nullptr, *vt_all = nullptr;
+    // patch-parallel: only the image tokens' K rows and V^T columns travel (what distrifuser gathers, modules/pp/attn.py:222-233): they are packed
+    // into contiguous send buffers first -- the QKV epilogue writes q|k interleaved and V^T rows padded, with the text tokens behind the image ones
+    bf16_t *k_send = nullptr, *v_send = nullptr, *k_g = nullptr, *v_g = nullptr, *k_all = nullptr, *vt_all = nullptr;
     if (is_pp()) {
-      qk_g = alloc<bf16_t>((size_t)world * B * Lj * 2 * d);
-      vt_g = alloc<bf16_t>((size_t)world * B * d * ldvt_j);
-      kq_all = alloc<bf16_t>((size_t)B * Ljt * 2 * d);
+      k_send = alloc<bf16_t>((size_t)B * L * d);
+      v_send = alloc<bf16_t>((size_t)B * d * L);
+      k_g = alloc<bf16_t>((size_t)world * B * L * d);
+      v_g = alloc<bf16_t>((size_t)world * B * d * L);
+      k_all = alloc<bf16_t>((size_t)B * Ljt * d);
       vt_all = alloc<bf16_t>((size_t)B * d * ldvt_jt);
     }
-    // K rows and V^T columns of every rank's `L` image tokens, then the `tail` local-only (text) tokens, per sample:
-    // kq_all [B][world * L + tail][2d] (whole q|k rows are moved, k is the second half), vt_all [B][d][ld_all]
+    // keys of the joint attention per sample: every rank's `L` image tokens in rank order, then the `tail` local-only (text) tokens:
+    // k_all [B][world * L + tail][d], vt_all [B][d][ld_all]
     auto gather_kv = [&](bf16_t* qk_loc, bf16_t* vt_loc, int ld_loc, int tail, int ld_all) {
       const int rows_loc = L + tail, rows_all = Ltot + tail;
-      const size_t qrow = (size_t)2 * d * 2;
-      all_gather(qk_loc, qk_g, (size_t)B * rows_loc * qrow);
-      all_gather(vt_loc, vt_g, (size_t)B * d * ld_loc * 2);
+      const size_t krow = (size_t)d * 2, qrow = 2 * krow;
+      for (int b = 0; b < B && ok(); ++b)               // K half of this sample's image rows
+        copy2d((char*)k_send + (size_t)b * L * krow, krow, (char*)qk_loc + (size_t)b * rows_loc * qrow + krow, qrow, krow, L);
+      copy2d(v_send, (size_t)L * 2, vt_loc, (size_t)ld_loc * 2, (size_t)L * 2, (size_t)B * d);
+      all_gather(k_send, k_g, (size_t)B * L * krow);
+      all_gather(v_send, v_g, (size_t)B * d * L * 2);
       for (int r = 0; r < world && ok(); ++r) {
-        copy2d((char*)kq_all + (size_t)r * L * qrow, rows_all * qrow, (char*)qk_g + (size_t)r * B * rows_loc * qrow, rows_loc * qrow, L * qrow, B);
-        copy2d((char*)vt_all + (size_t)r * L * 2, (size_t)ld_all * 2, (char*)vt_g + (size_t)r * B * d * ld_loc * 2, (size_t)ld_loc * 2, (size_t)L * 2,
-               (size_t)B * d);
+        copy2d((char*)k_all + (size_t)r * L * krow, rows_all * krow, (char*)k_g + (size_t)r * B * L * krow, L * krow, L * krow, B);
+        copy2d((char*)vt_all + (size_t)r * L * 2, (size_t)ld_all * 2, (char*)v_g + (size_t)r * B * d * L * 2, (size_t)L * 2, (size_t)L * 2, (size_t)B * d);
       }
       if (tail) {
-        copy2d((char*)kq_all + (size_t)Ltot * qrow, rows_all * qrow, (char*)qk_loc + (size_t)L * qrow, rows_loc * qrow, tail * qrow, B);
+        for (int b = 0; b < B && ok(); ++b)
+          copy2d((char*)k_all + ((size_t)b * rows_all + Ltot) * krow, krow, (char*)qk_loc + ((size_t)b * rows_loc + L) * qrow + krow, qrow, krow, tail);
         copy2d((char*)vt_all + (size_t)Ltot * 2, (size_t)ld_all * 2, (char*)vt_loc + (size_t)L * 2, (size_t)ld_loc * 2, (size_t)MX_VT_LD(tail) * 2,
                (size_t)B * d);
       }
@@ -341,7 +347,7 @@ struct Plan {
       qkv(cin, b + ".attn.add_qkv", b + ".attn.norm_added_q.weight", b + ".attn.norm_added_k.weight", qk_j, vt_j, ldvt_j, MT, d, Lt, Lj, L);
       if (is_pp()) {
         gather_kv(qk_j, vt_j, ldvt_j, Lt, ldvt_jt);
-        attention_qk(qk_j, kq_all + d, d, vt_all, ldvt_jt, o_j, heads, Lj, Ljt);
+        attention_qk(qk_j, k_all, d, vt_all, ldvt_jt, o_j, heads, Lj, Ljt);
       } else
       attention(qk_j, d, vt_j, ldvt_j, o_j, heads, Lj);
       // x += gate_msa * to_out(attn[:, :L])                                   (transformer.py:344-345)
@@ -350,7 +356,7 @@ struct Plan {
         qkv(x2in, b + ".attn2.to_qkv", b + ".attn2.norm_q.weight", b + ".attn2.norm_k.weight", qk_i, vt_i, ldvt_i, MI, d, L, 0, 0);
         if (is_pp()) {
           gather_kv(qk_i, vt_i, ldvt_i, 0, ldvt_it);
-          attention_qk(qk_i, kq_all + d, d, vt_all, ldvt_it, o_i, heads, L, Ltot);
+          attention_qk(qk_i, k_all, d, vt_all, ldvt_it, o_i, heads, L, Ltot);
         } else
         attention(qk_i, d, vt_i, ldvt_i, o_i, heads, L);
         linear(o_i, d, b + ".attn2.to_out.0", x, d, MI, d, d, 0, x, d, mi + 8 * d, ntot, L);

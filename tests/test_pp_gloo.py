@@ -134,7 +134,7 @@ def test_mmdit_pp_plan_and_state_size_on_host():
     L = (Hl // pcfg.patch_size) * (W // pcfg.patch_size)
     n_dual = len(pcfg.dual_attention_layers)
     assert len(calls) == 2 * pcfg.num_layers + 2 * n_dual
-    assert calls[0][2] == B * (L + Lt) * 2 * d * 2               # the local q|k rows of the joint sequence
+    assert calls[0][2] == B * L * d * 2 and calls[1][2] == B * d * L * 2     # K rows, V^T columns of the local image tokens: nothing else travels
     need = l.mx_mmdit_workspace_bytes_pp(h, B, Hl, W, Lt, world)
     from sduss_amd.patch_parallel import CommLog
     log = CommLog(); log.calls = calls
