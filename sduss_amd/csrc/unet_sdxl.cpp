@@ -378,10 +378,12 @@ struct Plan {
     };
     linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, pass1 ? nullptr : &st);
     // patch-parallel: every rank gathers the other ranks' K rows and V^T columns (modules/pp/attn.py:137: all_gather(kv))
-    bf16_t* qk_all = nullptr; bf16_t* vt_all = nullptr;
+    // -- K alone travels: the QKV epilogue writes q|k interleaved, so the K halves are packed into a contiguous send buffer first
+    bf16_t* k_send = nullptr; bf16_t* k_all = nullptr; bf16_t* vt_all = nullptr;
     if (is_pp()) {
       if (L % 64 != 0) fail("patch-parallel: local tokens per image must be a multiple of 64 at every attention level");
-      qk_all = alloc<bf16_t>((size_t)pp_world * M * 2 * C);
+      k_send = alloc<bf16_t>((size_t)M * C);
+      k_all = alloc<bf16_t>((size_t)pp_world * M * C);
       vt_all = alloc<bf16_t>((size_t)pp_world * B * C * ldvt);
     }
     KV* kvp = kv_for(C);
@@ -396,11 +398,13 @@ struct Plan {
         gemm(d, false);
       }
       if (is_pp()) {
-        all_gather(qk, qk_all, (size_t)M * 2 * C * 2);
+        if (ok() && !dry && hipMemcpy2DAsync(k_send, (size_t)C * 2, qk + C, (size_t)2 * C * 2, (size_t)C * 2, M, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+          fail("patch-parallel: K pack failed");
+        all_gather(k_send, k_all, (size_t)M * C * 2);
         all_gather(vt, vt_all, (size_t)B * C * ldvt * 2);
         if (ok() && !dry &&
-            mx_attention_prescaled_chunked(stream, qk, 2 * C, qk_all + C, 2 * C, vt_all, ldvt, (int64_t)C * ldvt, ao, C, B, heads, L, pp_world * L, L,
-                                           (int64_t)L * 2 * C, (int64_t)M * 2 * C, (int64_t)B * C * ldvt))
+            mx_attention_prescaled_chunked(stream, qk, 2 * C, k_all, C, vt_all, ldvt, (int64_t)C * ldvt, ao, C, B, heads, L, pp_world * L, L,
+                                           (int64_t)L * C, (int64_t)M * C, (int64_t)B * C * ldvt))
           fail(std::string("attention: ") + mx_last_error());
       } else {
         attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
