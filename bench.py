@@ -293,12 +293,19 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MX_BENCH_REHEARSE=1: all ranks on cuda:0 over gloo -- walks the N > 1 control flow (barriers, max over ranks, gathers, rank-0 line)
+    # on a one-GPU box; the numbers of such a run mean nothing and the line says so
+    rehearse = os.environ.get("MX_BENCH_REHEARSE") == "1" and world > 1
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)   # RCCL; used for the barrier + max-over-ranks only: replicas share nothing
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)   # RCCL; used for the barrier + max-over-ranks only: replicas share nothing
 
     from sduss_amd import lib
     if args.model == "sd3":
@@ -341,7 +348,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     from sduss_amd import dp
-    elapsed = dp.max_over_ranks(elapsed, dist, device)
+    elapsed = dp.max_over_ranks(elapsed, dist, None if rehearse else device)
     step_s = elapsed / args.steps
     images_per_s = world * args.batch / (STEPS_PER_IMAGE * step_s)
     finite = all(torch.isfinite(r.latents.float()).all().item() for r in reqs)
@@ -349,6 +356,7 @@ def main():
     result = {
         "metric": f"images/sec (node), {'SDXL' if args.model == 'sdxl' else 'SD3.5-medium'} {args.res}^2 {STEPS_PER_IMAGE}-step, fixed prompt, CFG",
         "value": images_per_s, "unit": "images/s",
+        **({"rehearsal": "MX_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- control-flow check only, the numbers mean nothing"} if rehearse else {}),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{mdl['name']} {args.res}x{args.res} {STEPS_PER_IMAGE}-step {mdl['sched']}, CFG {mdl['cfg']}, {args.batch} requests/step "
