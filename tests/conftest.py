@@ -18,3 +18,21 @@ def cuda_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def full_width_sdxl(cuda_device):
+    """ONE set of full-width SDXL-base parameters (2.57 B, random init), their device-held form for the oracle (weights.params_as_held) and ONE
+    packed model on the GPU, shared by every full-width forward of the session (generating, folding and packing them takes half a minute)."""
+    import torch
+    from oracle import sdxl_unet_ref as ref
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.unet import MxUNet
+    from sduss_amd.weights import params_as_held
+    ocfg = ref.UNetConfig.sdxl_base()
+    P = ref.fast_params(ocfg)
+    held = params_as_held(UNetConfig.sdxl_base(), P)
+    net = MxUNet(UNetConfig.sdxl_base(), P, device="cuda:0")
+    yield ocfg, P, held, net
+    del net
+    torch.cuda.empty_cache()

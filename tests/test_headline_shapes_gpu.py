@@ -247,20 +247,15 @@ def _check_forward(got, want, what, max_rel=0.04, l2_rel=0.02):
     assert err <= max_rel * scale and l2 <= l2_rel, f"{what}: max err {err} (range {scale}), rel L2 {l2}"
 
 
-def test_sdxl_base_forward_1024(cuda_device):
+def test_sdxl_base_forward_1024(full_width_sdxl):
     """SDXL-base (2.57 B params, random init, bf16-representable) on 128 x 128 latents, UNet batch 2 (one request under
     CFG): the configuration of BASELINE configs[1] at a quarter of the bench batch.  The oracle runs on the weights as the device holds
     them (weights.params_as_held: the LayerNorm-folded linears hold bf16(W * gamma)), as it already runs on bf16-rounded weights: the
     bound is on the kernels' arithmetic, not on one more weight rounding."""
-    from sduss_amd.config import UNetConfig
-    from sduss_amd.unet import MxUNet
-    from sduss_amd.weights import params_as_held
-    ocfg = ref.UNetConfig.sdxl_base()
-    P = ref.fast_params(ocfg)
+    ocfg, _P, held, net = full_width_sdxl
     s, t, e, te, ti = ref.make_inputs(ocfg, 2, 128)
     with torch.inference_mode():
-        want = ref.unet_forward(params_as_held(UNetConfig.sdxl_base(), P), ocfg, s, t, e, te, ti)
-    net = MxUNet(UNetConfig.sdxl_base(), P, device="cuda:0")
+        want = ref.unet_forward(held, ocfg, s, t, e, te, ti)
     got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
     # error budget of tests/test_unet_gpu.py::test_unet_per_stage_error_budget (0.35 % * sqrt(n) + 0.2 % after n bf16-stored stages) at this
     # model's depth -- 17 resnets + 70 transformer layers + 9 convs, n ~ 96 -> 3.6 %; measured 1.9-2.0 % over the round's kernel changes, so the
@@ -269,14 +264,15 @@ def test_sdxl_base_forward_1024(cuda_device):
 
 
 def test_sd35_medium_forward_1024(cuda_device):
-    """SD3.5-medium (24 joint blocks, 13 dual) on 128 x 128 latents with 333 text tokens, batch 2: BASELINE configs[2]."""
+    """SD3.5-medium (24 joint blocks, 13 dual) on 128 x 128 latents with 333 text tokens: BASELINE configs[2] at batch 1 (the fp32 CPU oracle
+    of this forward costs 75 s per sample; batches > 1 are covered at medium width in tests/test_mmdit_gpu.py)."""
     from sduss_amd.config import MMDiTConfig
     from sduss_amd.transformer_sd3 import MxSD3Transformer
     ocfg = sd3_mmdit_ref.MMDiTConfig.sd35_medium()
     P = sd3_mmdit_ref.init_params(ocfg)
-    lat, t, e, p = sd3_mmdit_ref.make_inputs(ocfg, 2, 128, ctx_len=333)
+    lat, t, e, p = sd3_mmdit_ref.make_inputs(ocfg, 1, 128, ctx_len=333)
     with torch.inference_mode():
         want = sd3_mmdit_ref.mmdit_forward(P, ocfg, lat, t, e, p)
     net = MxSD3Transformer(MMDiTConfig.sd35_medium(), P, device="cuda:0")
     got = net.forward_one(lat.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), p.cuda())
-    _check_forward(got, want, "SD3.5-medium 1024^2 forward, batch 2")
+    _check_forward(got, want, "SD3.5-medium 1024^2 forward, batch 1")

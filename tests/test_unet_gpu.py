@@ -114,25 +114,10 @@ def test_denoising_step_two_steps(tiny):
     _check(got, lat, "denoising_step x2", max_rel=0.06, l2_rel=0.04)
 
 
-@pytest.fixture(scope="module")
-def full_width(cuda_device):
-    """one set of full-width parameters (2.57 B), their device-held form for the oracle, and one packed model for the tests below"""
-    from sduss_amd.config import UNetConfig
-    from sduss_amd.unet import MxUNet
-    from sduss_amd.weights import params_as_held
-    ocfg = ref.UNetConfig.sdxl_base()
-    P = ref.fast_params(ocfg)
-    held = params_as_held(UNetConfig.sdxl_base(), P)
-    net = MxUNet(UNetConfig.sdxl_base(), P, device="cuda:0")
-    yield ocfg, P, held, net
-    del net
-    torch.cuda.empty_cache()
-
-
-def test_unet_full_width_sdxl(full_width):
+def test_unet_full_width_sdxl(full_width_sdxl):
     """The real SDXL-base widths (320/640/1280, 70 transformer layers, 2.57 B params) on a 256x256-pixel latent, batch 2:
     exercises the BN=64 tile (N=320), channels-per-group 10/20/30/40/60/80, K=2880..23040 and the 10/20-head attention."""
-    ocfg, P, _held, net = full_width
+    ocfg, P, _held, net = full_width_sdxl
     s, t, e, te, ti = ref.make_inputs(ocfg, 2, 32)
     with torch.inference_mode():
         want = ref.unet_forward(P, ocfg, s, t, e, te, ti)
@@ -140,11 +125,11 @@ def test_unet_full_width_sdxl(full_width):
     _check(got, want, "unet full width 32x32", max_rel=0.05, l2_rel=0.03)
 
 
-def test_unet_full_width_sdxl_batch8(full_width):
+def test_unet_full_width_sdxl_batch8(full_width_sdxl):
     """the same widths at UNet batch 8 (M = 8192 tokens at the 640-wide level, 2048 at the 1280-wide one): both LayerNorm routes of the
     step plan in one forward -- a normalisation pass in front of the 256 x 256 kernel where the batch makes it the tile of choice, row
     statistics from the producing GEMM's epilogue elsewhere -- against the oracle on the weights as the device holds them"""
-    ocfg, _P, held, net = full_width
+    ocfg, _P, held, net = full_width_sdxl
     s, t, e, te, ti = ref.make_inputs(ocfg, 8, 32)
     with torch.inference_mode():
         want = ref.unet_forward(held, ocfg, s, t, e, te, ti)
@@ -153,11 +138,11 @@ def test_unet_full_width_sdxl_batch8(full_width):
 
 
 @pytest.mark.parametrize("batch,hw", [(3, 24), (5, 40), (1, 48)])
-def test_unet_full_width_sdxl_ragged(full_width, batch, hw):
+def test_unet_full_width_sdxl_ragged(full_width_sdxl, batch, hw):
     """the real widths on token counts that are not multiples of the GEMM tiles (batch 3 x 24 x 24 latents: M = 1728 / 432 tokens; 5 x 40 x 40:
     8000 / 2000; 1 x 48 x 48: 2304 / 576): the last row tile of every GEMM is partial, so the producers' row statistics and the consumers'
     folded LayerNorm run on tiles that end inside a tile; odd image sizes for the convs and the GroupNorm tiles"""
-    ocfg, _P, held, net = full_width
+    ocfg, _P, held, net = full_width_sdxl
     s, t, e, te, ti = ref.make_inputs(ocfg, batch, hw)
     with torch.inference_mode():
         want = ref.unet_forward(held, ocfg, s, t, e, te, ti)
