@@ -488,6 +488,14 @@ typedef struct mx_block_cache {
   mx_skip_observe_fn observe; /* optional (NULL): after a block RAN while its previous output was cached, the per-sample mean squared difference
                                  between the new and the previous hidden-state output -- the label a predictor is fitted on (the reference's
                                  files are named for it: exp/sdxl-upsample-threshold0.01.pkl); tools/fit_skip_predictor.py */
+  /* Optional: one state row per REQUEST instead of per batch position -- what the reference's dictionaries keyed by request id give
+   * (cache_manager.py:105-133: a request that stays while the batch around it changes keeps its cached tensors; a new one has none and makes
+   * the block run).  slots (host array [batch]): the state row of each sample, distinct, in [0, n_slots); slot_valid (host array [batch]):
+   * 1 = that row holds this sample's tensors of an earlier step at this latent size.  The caller owns the request -> row table
+   * (sduss_amd/block_cache.py); the state is then mx_*_block_cache_bytes(u, n_slots, ...) large and batch_key / cached_* are not consulted. */
+  const int32_t* slots;
+  const unsigned char* slot_valid;
+  int n_slots;
 } mx_block_cache;
 size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, int W);
 int mx_unet_forward_cached(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,

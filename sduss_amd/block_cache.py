@@ -103,6 +103,7 @@ class BlockSkipCache:
         self._cb = _lib.SKIP_PREDICT_FN(self._predict)       # kept alive with the object
         self.desc.predict = self._cb
         self.observed, self.features = [], []
+        self._row_ids, self._geom, self._slot_of, self._cap = None, None, {}, 0
         self._record = observe
         if observe:
             self._cb_obs = _lib.SKIP_OBSERVE_FN(self._observe)
@@ -120,11 +121,18 @@ class BlockSkipCache:
             feats = np.concatenate([np.full((n, 1), float(block)), ts[:, None], m], axis=1)
             if self._record:
                 self.features.append(feats.copy())
-            prev = self.previous.get(block)
-            if prev is None or prev.shape[0] != n or bool((m[:, 0] >= MSE_UNCACHED * 0.5).any()):
-                prev = np.zeros(n, dtype=np.int64)           # "0 if not in the cache" (cache_manager.py:128,150)
+            ids = getattr(self, "_row_ids", None)
+            uncached = m[:, 0] >= MSE_UNCACHED * 0.5
+            if ids is not None:                              # per request: "0 if not in the cache else previous" (cache_manager.py:128,150)
+                counts = self.previous.get(block, {})
+                prev = np.array([0 if uncached[i] else counts.get(ids[i], 0) for i in range(n)], dtype=np.int64)
+            else:
+                prev = self.previous.get(block)
+                if prev is None or isinstance(prev, dict) or prev.shape[0] != n or bool(uncached.any()):
+                    prev = np.zeros(n, dtype=np.int64)
             raw = np.asarray((self.up if is_up else self.down).predict(feats))
-            run, self.previous[block] = decide(raw, prev, self.forced_after)
+            run, new_prev = decide(raw, prev, self.forced_after)
+            self.previous[block] = {ids[i]: int(new_prev[i]) for i in range(n)} if ids is not None else new_prev
             self.decisions.append((block, run.copy()))
             for i in range(n):
                 run_out[i] = 1 if run[i] else 0
@@ -136,9 +144,17 @@ class BlockSkipCache:
     def _observe(self, _ctx, block, n, out_mse):
         self.observed.append((int(block), np.ctypeslib.as_array(out_mse, shape=(n,)).astype(np.float64).copy()))
 
-    def bind(self, model, batch: int, h: int, w: int, batch_key: int, ctx_len: Optional[int] = None):
-        """size / (re)allocate the device state for `model` (MxUNet, or MxMMDiT when ctx_len is given) and return the descriptor"""
+    def bind(self, model, batch: int, h: int, w: int, batch_key: int, ctx_len: Optional[int] = None, row_ids: Optional[Sequence] = None):
+        """size / (re)allocate the device state for `model` (MxUNet, or MxMMDiT when ctx_len is given) and return the descriptor.
+        row_ids (one hashable id per sample, e.g. "<request id>#<cfg half>"): the state is kept per REQUEST, as the reference's dictionaries
+        keyed by request id do (cache_manager.py:105-133) -- a request that stays while the batch around it changes keeps its cached tensors and
+        its reuse counters, one that left is forgotten, a new one makes the blocks run once.  Without row_ids the state belongs to the batch
+        composition named by batch_key."""
         unet = model
+        if row_ids is not None:
+            return self._bind_rows(model, batch, h, w, ctx_len, list(row_ids))
+        self._row_ids = None
+        self.desc.slots = None; self.desc.slot_valid = None; self.desc.n_slots = 0
         if ctx_len is None:
             need = model._lib.mx_unet_block_cache_bytes(model._handle, batch, h, w)
         else:
@@ -157,12 +173,55 @@ class BlockSkipCache:
         self.error = None
         return C.byref(self.desc)
 
+    def _bind_rows(self, model, batch, h, w, ctx_len, row_ids):
+        assert len(row_ids) == batch and len(set(row_ids)) == batch, "one distinct id per sample"
+        geom = (h, w, ctx_len)
+        if getattr(self, "_geom", None) != geom:              # another latent size: nothing cached applies
+            self._geom, self._slot_of, self._cap = geom, {}, 0
+            self.previous = {}
+        if batch > self._cap:                                  # grow the state (rarely: sized for twice the largest batch seen)
+            self._cap = max(2 * batch, 8)
+            if ctx_len is None:
+                need = model._lib.mx_unet_block_cache_bytes(model._handle, self._cap, h, w)
+            else:
+                need = model._lib.mx_mmdit_block_cache_bytes(model._handle, self._cap, h, w, ctx_len)
+            if need == 0:
+                raise _lib.MxError("block_cache_bytes: " + model._lib.mx_last_error().decode())
+            self.state = torch.empty(need, dtype=torch.uint8, device=model.device)
+            self._slot_of = {}
+            self.previous = {}
+        # "self.cache = {only the ids of this call}" (cache_manager.py:131,153): ids that left are forgotten, their rows are free again
+        keep = {k: v for k, v in self._slot_of.items() if k in set(row_ids)}
+        free = sorted(set(range(self._cap)) - set(keep.values()))
+        valid = []
+        for rid in row_ids:
+            if rid in keep:
+                valid.append(1)
+            else:
+                keep[rid] = free.pop(0)
+                valid.append(0)
+        self._slot_of = keep
+        self._row_ids = row_ids
+        self._slots_arr = (C.c_int32 * batch)(*[keep[r] for r in row_ids])
+        self._valid_arr = (C.c_ubyte * batch)(*valid)
+        for blk, counts in list(self.previous.items()):        # counters follow the requests
+            self.previous[blk] = {k: v for k, v in counts.items() if k in keep}
+        self.desc.state = self.state.data_ptr()
+        self.desc.state_bytes = self.state.numel()
+        self.desc.slots = C.cast(self._slots_arr, C.POINTER(C.c_int32))
+        self.desc.slot_valid = C.cast(self._valid_arr, C.POINTER(C.c_ubyte))
+        self.desc.n_slots = self._cap
+        self.decisions = []
+        self.error = None
+        return C.byref(self.desc)
+
     def after_forward(self):
         self.history.append(int(self.desc.blocks_run) | int(self.desc.blocks_run_hi) << 32)
 
     def invalidate(self):
         self.desc.cached_valid = 0
         self.previous = {}
+        self._slot_of = {}
 
     @staticmethod
     def blocks_of(mask: int) -> Sequence[int]:

@@ -1,5 +1,7 @@
 // Small HBM-bound glue kernels of the step plan (gfx950): layout conversion at the model boundary,
 // sinusoidal embeddings, channel concat, and the fused scheduler / CFG steps either side of the UNet.
+#include <algorithm>
+
 #include "common.h"
 #include "../../include/mxdenoise.h"
 
@@ -464,11 +466,13 @@ namespace mx {
 constexpr int kMseChunks = 64;
 // partial[b][chunk] = sum over the chunk of (a - b)^2 (fp32 in-thread, fp64 across the block); the host adds the 64 partials of a sample: the
 // result does not depend on launch order
-__global__ __launch_bounds__(256) void sq_diff_partial_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long elems, double* __restrict__ partial) {
+// slot (optional): sample i of `b` lives at row slot[i] (the block-skip cache keeps one row per request, not per batch position)
+__global__ __launch_bounds__(256) void sq_diff_partial_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long elems, double* __restrict__ partial,
+                                                              const int* __restrict__ slot) {
   const int smp = blockIdx.y, chunk = blockIdx.x;
   const long per = (elems / 8 + kMseChunks - 1) / kMseChunks;           // 16-byte vectors per chunk
   const long v0 = (long)chunk * per, v1 = min(v0 + per, elems / 8);
-  const bf16_t* pa = a + (long)smp * elems; const bf16_t* pb = b + (long)smp * elems;
+  const bf16_t* pa = a + (long)smp * elems; const bf16_t* pb = b + (long)(slot ? slot[smp] : smp) * elems;
   float acc = 0.f;
   for (long v = v0 + threadIdx.x; v < v1; v += 256) {
     const u32x4 x = *reinterpret_cast<const u32x4*>(pa + v * 8), y = *reinterpret_cast<const u32x4*>(pb + v * 8);
@@ -486,9 +490,27 @@ __global__ __launch_bounds__(256) void sq_diff_partial_kernel(const bf16_t* __re
   __syncthreads();
   if (threadIdx.x == 0) partial[(long)smp * kMseChunks + chunk] = red[0] + red[1] + red[2] + red[3];
 }
-int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial) {
+int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial, const int* slot) {
   MX_CHECK(elems_per_sample % 8 == 0, "sq_diff: elements per sample must be a multiple of 8");
-  hipLaunchKernelGGL(sq_diff_partial_kernel, dim3(kMseChunks, B), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, elems_per_sample, partial);
+  hipLaunchKernelGGL(sq_diff_partial_kernel, dim3(kMseChunks, B), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, elems_per_sample, partial, slot);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+// rows of `bytes` (a multiple of 16) between a batch-ordered tensor and a slot-ordered one: scatter: slotted[slot[i]] = batch[i]; gather: batch[i] =
+// slotted[slot[i]]
+__global__ __launch_bounds__(256) void copy_rows_kernel(char* __restrict__ batch, char* __restrict__ slotted, long vecs, const int* __restrict__ slot, int scatter) {
+  const int smp = blockIdx.y;
+  u32x4* pb = reinterpret_cast<u32x4*>(batch) + (long)smp * vecs;
+  u32x4* ps = reinterpret_cast<u32x4*>(slotted) + (long)slot[smp] * vecs;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < vecs; v += (long)gridDim.x * 256) {
+    if (scatter) ps[v] = pb[v]; else pb[v] = ps[v];
+  }
+}
+int launch_copy_rows(hipStream_t s, void* batch, void* slotted, size_t bytes_per_sample, int B, const int* slot, int scatter) {
+  MX_CHECK(bytes_per_sample % 16 == 0 && slot != nullptr, "copy_rows: rows must be multiples of 16 bytes");
+  const long vecs = (long)(bytes_per_sample / 16);
+  const int gx = (int)std::min<long>((vecs + 255) / 256, 256);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(gx, B), dim3(256), 0, s, (char*)batch, (char*)slotted, vecs, slot, scatter);
   MX_LAUNCH_CHECK();
   return 0;
 }

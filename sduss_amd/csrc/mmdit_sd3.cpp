@@ -31,7 +31,8 @@ int launch_patchify(hipStream_t s, const void* in, int dtype, void* out, int B, 
 int launch_unpatchify(hipStream_t s, const void* in, void* out, int dtype, int B, int C, int H, int W, int ps, int ld);
 int launch_crop_pos(hipStream_t s, const void* table, void* out, int m, int h, int w, int d);
 int launch_sinus_embed(hipStream_t s, const float* t, void* out, int B, int dim);
-int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial);
+int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial, const int* slot = nullptr);
+int launch_copy_rows(hipStream_t s, void* batch, void* slotted, size_t bytes_per_sample, int B, const int* slot, int scatter);
 }  // namespace mx
 
 using mx::bf16_t;
@@ -84,6 +85,21 @@ struct Plan {
   size_t bc_bytes = 0;             // state bytes the plan needs (also the dry answer of mx_mmdit_block_cache_bytes)
   unsigned long long blocks_run = 0;
   std::vector<float> h_timesteps;
+  int bc_rows = 0;                 // samples a state tensor holds: the batch, or bc->n_slots with one slot per request
+  const int* bc_dslot = nullptr;   // device copy of bc->slots
+  std::vector<unsigned char> bc_valid;
+  bool bc_all_valid = false, bc_any_valid = false;
+  static size_t bc_scratch_bytes(int rows) { return ((size_t)rows * 64 * sizeof(double) + (size_t)rows * sizeof(int) + 255) & ~(size_t)255; }
+  bool bc_store(char* region, const void* t, size_t per_sample_bytes) {
+    if (bc_dslot) { if (mx::launch_copy_rows(stream, (void*)t, region, per_sample_bytes, B, bc_dslot, 1)) return fail(mx_last_error()); return true; }
+    if (hipMemcpyAsync(region, t, per_sample_bytes * B, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("block cache: copy into the state failed");
+    return true;
+  }
+  bool bc_load(void* t, char* region, size_t per_sample_bytes) {
+    if (bc_dslot) { if (mx::launch_copy_rows(stream, t, region, per_sample_bytes, B, bc_dslot, 0)) return fail(mx_last_error()); return true; }
+    if (hipMemcpyAsync(t, region, per_sample_bytes * B, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("block cache: copy out of the state failed");
+    return true;
+  }
   const char* stage = nullptr; void* stage_out = nullptr; size_t stage_bytes = 0; bool stage_hit = false;
   std::string err;
 
@@ -275,8 +291,9 @@ struct Plan {
     // Block-skip cache (mx_mmdit_forward_cached; the reference's per-block CacheManagers, SD3Transformer.py:54-57,151,172,219-228): a block
     // runs when any sample asks (state_mask.sum() > 0), otherwise the image and context streams take the values the block produced last
     // time.  State per block: [input x | output x | output context], each 256-byte aligned, after the comparison scratch.
-    const size_t bc_x = ((size_t)MI * d * 2 + 255) & ~(size_t)255, bc_c = ((size_t)MT * d * 2 + 255) & ~(size_t)255;
-    const size_t bc_scratch = ((size_t)B * 64 * sizeof(double) + 255) & ~(size_t)255;
+    if (bc && bc_rows < B) bc_rows = B;
+    const size_t bc_x = ((size_t)bc_rows * L * d * 2 + 255) & ~(size_t)255, bc_c = ((size_t)bc_rows * Lt * d * 2 + 255) & ~(size_t)255;
+    const size_t bc_scratch = bc_scratch_bytes(bc_rows);
     if (bc) {
       bc_bytes = bc_scratch + (size_t)c.num_layers * (2 * bc_x + bc_c);
       if (!dry && bc_bytes > bc->state_bytes) fail("block cache: state buffer too small (mx_mmdit_block_cache_bytes)");
@@ -285,13 +302,14 @@ struct Plan {
     auto decide = [&](int i) -> bool {
       char* st = (char*)bc->state + bc_scratch + (size_t)i * (2 * bc_x + bc_c);
       std::vector<float> mse(B, MX_MSE_UNCACHED);
-      if (bc->cached_valid) {
+      if (bc_any_valid) {
         double* part = (double*)bc->state;
         std::vector<double> hp((size_t)B * 64);
-        if (mx::launch_sq_diff_partial(stream, x, st, (long)L * d, B, part)) { fail(mx_last_error()); return true; }
+        if (mx::launch_sq_diff_partial(stream, x, st, (long)L * d, B, part, bc_dslot)) { fail(mx_last_error()); return true; }
         if (hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) { fail("block cache: reading the input differences failed"); return true; }
         for (int s = 0; s < B; ++s) {
+          if (!bc_valid[s]) continue;
           double t = 0.0;
           for (int k = 0; k < 64; ++k) t += hp[(size_t)s * 64 + k];
           mse[s] = (float)(t / ((double)L * d));
@@ -299,18 +317,18 @@ struct Plan {
       }
       std::vector<unsigned char> run(B, 1);
       if (bc->predict(bc->ctx, i, 0, B, 1, h_timesteps.data(), mse.data(), run.data())) { fail("block cache: the predictor failed"); return true; }
-      bool any = !bc->cached_valid;
+      bool any = !bc_all_valid;
       for (int s = 0; s < B; ++s) any = any || run[s] != 0;
-      if (hipMemcpyAsync(st, x, (size_t)MI * d * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess) fail("block cache: input copy failed");
+      bc_store(st, x, (size_t)L * d * 2);
       return any;
     };
     auto after = [&](int i, bool ran, bool last) {
       char* st = (char*)bc->state + bc_scratch + (size_t)i * (2 * bc_x + bc_c);
-      if (ran && bc->cached_valid && bc->observe) {          // how far the block's image-stream output moved since its last run (fitting labels)
+      if (ran && bc_all_valid && bc->observe) {              // how far the block's image-stream output moved since its last run (fitting labels)
         double* part = (double*)bc->state;
         std::vector<double> hp((size_t)B * 64);
         std::vector<float> om(B);
-        if (mx::launch_sq_diff_partial(stream, x, st + bc_x, (long)L * d, B, part)) { fail(mx_last_error()); return; }
+        if (mx::launch_sq_diff_partial(stream, x, st + bc_x, (long)L * d, B, part, bc_dslot)) { fail(mx_last_error()); return; }
         if (hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) { fail("block cache: reading the output differences failed"); return; }
         for (int s = 0; s < B; ++s) {
@@ -320,12 +338,8 @@ struct Plan {
         }
         bc->observe(bc->ctx, i, B, om.data());
       }
-      hipError_t e = ran ? hipMemcpyAsync(st + bc_x, x, (size_t)MI * d * 2, hipMemcpyDeviceToDevice, stream)
-                         : hipMemcpyAsync(x, st + bc_x, (size_t)MI * d * 2, hipMemcpyDeviceToDevice, stream);
-      if (e == hipSuccess && !last)
-        e = ran ? hipMemcpyAsync(st + 2 * bc_x, ctx, (size_t)MT * d * 2, hipMemcpyDeviceToDevice, stream)
-                : hipMemcpyAsync(ctx, st + 2 * bc_x, (size_t)MT * d * 2, hipMemcpyDeviceToDevice, stream);
-      if (e != hipSuccess) fail("block cache: output copy failed");
+      bool okc = ran ? bc_store(st + bc_x, x, (size_t)L * d * 2) : bc_load(x, st + bc_x, (size_t)L * d * 2);
+      if (okc && !last) okc = ran ? bc_store(st + 2 * bc_x, ctx, (size_t)Lt * d * 2) : bc_load(ctx, st + 2 * bc_x, (size_t)Lt * d * 2);
       if (ran) blocks_run |= 1ull << i;
     };
 
@@ -538,7 +552,7 @@ extern "C" size_t mx_mmdit_block_cache_bytes(const mx_mmdit* u, int batch, int H
   mx_block_cache sizing{};
   p.u = const_cast<mx_mmdit*>(u); p.stream = nullptr; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
   p.dry = true; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
-  p.bc = &sizing;
+  p.bc = &sizing; p.bc_rows = batch;
   if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
   return p.bc_bytes;
 }
@@ -556,13 +570,38 @@ extern "C" int mx_mmdit_forward_cached(mx_mmdit* u, void* stream, const void* la
   MX_CHECK(u->blob != nullptr, "mmdit: weights not set");
   MX_CHECK(io_dtype == MX_F32 || io_dtype == MX_F16 || io_dtype == MX_BF16, "mmdit: bad io dtype");
   MX_CHECK(((uintptr_t)cache->state & 255) == 0, "mmdit_forward_cached: cache->state must be 256-byte aligned");
-  cache->cached_valid = cache->cached_valid && cache->cached_key == cache->batch_key && cache->cached_batch == batch && cache->cached_h == H &&
-                        cache->cached_w == W;
   Plan p;
+  p.bc_valid.assign(batch, 0);
+  if (cache->slots) {                      // one state row per request (see mx_block_cache)
+    MX_CHECK(cache->slot_valid != nullptr && cache->n_slots >= batch, "mmdit_forward_cached: slots need slot_valid and n_slots >= batch");
+    std::vector<char> seen(cache->n_slots, 0);
+    for (int b = 0; b < batch; ++b) {
+      MX_CHECK(cache->slots[b] >= 0 && cache->slots[b] < cache->n_slots && !seen[cache->slots[b]], "mmdit_forward_cached: slots must be distinct and inside [0, n_slots)");
+      seen[cache->slots[b]] = 1;
+      p.bc_valid[b] = cache->slot_valid[b] ? 1 : 0;
+    }
+    p.bc_rows = cache->n_slots;
+  } else {
+    cache->cached_valid = cache->cached_valid && cache->cached_key == cache->batch_key && cache->cached_batch == batch && cache->cached_h == H &&
+                          cache->cached_w == W;
+    p.bc_valid.assign(batch, cache->cached_valid ? 1 : 0);
+    p.bc_rows = batch;
+  }
+  p.bc_all_valid = true; p.bc_any_valid = false;
+  for (int b = 0; b < batch; ++b) { p.bc_all_valid = p.bc_all_valid && p.bc_valid[b]; p.bc_any_valid = p.bc_any_valid || p.bc_valid[b]; }
   p.u = u; p.stream = (hipStream_t)stream; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
   p.dry = false;
   p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = false;
   p.bc = cache;
+  if (cache->slots) {
+    MX_CHECK(Plan::bc_scratch_bytes(p.bc_rows) <= cache->state_bytes, "mmdit_forward_cached: state buffer too small");
+    int* dslot = (int*)((char*)cache->state + (size_t)p.bc_rows * 64 * sizeof(double));
+    if (hipMemcpyAsync(dslot, cache->slots, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, p.stream) != hipSuccess) {
+      mx::set_error("mmdit_forward_cached: sending the slot table failed");
+      return 1;
+    }
+    p.bc_dslot = dslot;
+  }
   p.h_timesteps.resize(batch);
   if (hipMemcpyAsync(p.h_timesteps.data(), timesteps, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, p.stream) != hipSuccess ||
       hipStreamSynchronize(p.stream) != hipSuccess) {

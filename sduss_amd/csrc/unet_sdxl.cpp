@@ -35,7 +35,8 @@ int launch_time_embed(hipStream_t s, const float* timesteps, const void* text_em
                       void* tsin, void* addin, int B, int d0, int text_dim, int da);
 int launch_concat(hipStream_t s, const void* a, const void* b, void* out, long M, int C1, int C2);
 size_t gn_workspace_exact(int B, int H, int W, int C, int patch);
-int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial);
+int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long elems_per_sample, int B, double* partial, const int* slot = nullptr);
+int launch_copy_rows(hipStream_t s, void* batch, void* slotted, size_t bytes_per_sample, int B, const int* slot, int scatter);
 int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, int B, int H, int W, int C, int groups, void* workspace, double* sums);
 int launch_gn_pp_finish(hipStream_t s, const void* x, int C1, const void* x2, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
                         int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace,
@@ -83,6 +84,22 @@ struct Plan {
   mx::PPExchange px;              // the exchange itself, synchronous / warm-up / stale (pp_exchange.h)
   mx_block_cache* bc = nullptr;   // mx_unet_forward_cached
   char* bc_top = nullptr;         // bump pointer into bc->state: same order and sizes every step
+  int bc_rows = 0;                // samples a state tensor holds: the batch, or bc->n_slots when the caller keeps one slot per request
+  const int* bc_dslot = nullptr;  // device copy of bc->slots (null: sample i lives in row i)
+  std::vector<unsigned char> bc_valid;   // per sample: the state holds its tensors of an earlier step
+  bool bc_all_valid = false, bc_any_valid = false;
+  static size_t bc_scratch_bytes(int lpb, int rows) { return (((size_t)(lpb + 2) * rows * 64 * sizeof(double) + (size_t)rows * sizeof(int)) + 255) & ~(size_t)255; }
+  // batch-ordered tensor <-> its rows in the state
+  bool bc_store(char* region, const void* t, size_t per_sample_bytes) {
+    if (bc_dslot) { if (mx::launch_copy_rows(stream, (void*)t, region, per_sample_bytes, B, bc_dslot, 1)) return fail(mx_last_error()); return true; }
+    if (hipMemcpyAsync(region, t, per_sample_bytes * B, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("block cache: copy into the state failed");
+    return true;
+  }
+  bool bc_load(void* t, char* region, size_t per_sample_bytes) {
+    if (bc_dslot) { if (mx::launch_copy_rows(stream, t, region, per_sample_bytes, B, bc_dslot, 0)) return fail(mx_last_error()); return true; }
+    if (hipMemcpyAsync(t, region, per_sample_bytes * B, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("block cache: copy out of the state failed");
+    return true;
+  }
   unsigned blocks_run = 0;
   std::vector<float> h_timesteps; // host copy of the timesteps for the predictor
   bool lookup = false;      // dry pass that still resolves every weight (mx_unet_validate)
@@ -589,31 +606,34 @@ struct Plan {
     auto run_block = [&](int idx, bool is_up, const std::vector<Ten>& ins, const std::function<void()>& body) {
       if (!bc) { body(); return; }
       const int nf = (int)ins.size();
+      const size_t R = (size_t)bc_rows;
+      auto region = [&](size_t per_sample) { char* r = bc_top; bc_top += (per_sample * R * 2 + 255) & ~(size_t)255; return r; };
       if (dry) {                                                 // mx_unet_block_cache_bytes: the same bump pointer, no launches
-        for (int f = 0; f < nf; ++f) bc_top += (ins[f].per_sample * B * 2 + 255) & ~(size_t)255;
+        for (int f = 0; f < nf; ++f) region(ins[f].per_sample);
         const size_t n0 = skips.size();
         body();
         size_t n_out = 0;
         bool x_listed = false;
         if (!is_up) for (size_t k = std::min(n0, skips.size()); k < skips.size(); ++k) {
-          bc_top += ((size_t)skips[k].h * skips[k].wd * skips[k].C * B * 2 + 255) & ~(size_t)255; ++n_out; x_listed = skips[k].t == x;
+          region((size_t)skips[k].h * skips[k].wd * skips[k].C); ++n_out; x_listed = skips[k].t == x;
         }
-        if (!n_out || !x_listed) bc_top += ((size_t)h * wd * Ccur * B * 2 + 255) & ~(size_t)255;
+        if (!n_out || !x_listed) region((size_t)h * wd * Ccur);
         return;
       }
       std::vector<float> mse((size_t)B * nf, MX_MSE_UNCACHED);
       std::vector<char*> in_cache(nf);
-      for (int f = 0; f < nf; ++f) { in_cache[f] = bc_top; bc_top += (ins[f].per_sample * B * 2 + 255) & ~(size_t)255; }
+      for (int f = 0; f < nf; ++f) in_cache[f] = region(ins[f].per_sample);
       if ((size_t)(bc_top - (char*)bc->state) > bc->state_bytes) { fail("block cache: state buffer too small (mx_unet_block_cache_bytes)"); return; }
-      if (bc->cached_valid && ok()) {
-        double* part = (double*)bc->state;                       // the first bc_scratch() bytes of the state
+      if (bc_any_valid && ok()) {
+        double* part = (double*)bc->state;                       // the head of the state is scratch (bc_scratch_bytes)
         for (int f = 0; f < nf && ok(); ++f)
-          if (mx::launch_sq_diff_partial(stream, ins[f].p, in_cache[f], (long)ins[f].per_sample, B, part + (size_t)f * B * 64)) fail(mx_last_error());
+          if (mx::launch_sq_diff_partial(stream, ins[f].p, in_cache[f], (long)ins[f].per_sample, B, part + (size_t)f * B * 64, bc_dslot)) fail(mx_last_error());
         std::vector<double> hp((size_t)nf * B * 64);
         if (ok() && (hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
                      hipStreamSynchronize(stream) != hipSuccess)) fail("block cache: reading the input differences failed");
         for (int f = 0; f < nf; ++f)
           for (int b = 0; b < B; ++b) {
+            if (!bc_valid[b]) continue;                          // nothing cached for this sample: the marker stays (cache_manager.py:110,139)
             double t = 0.0;
             for (int k = 0; k < 64; ++k) t += hp[((size_t)f * B + b) * 64 + k];
             mse[(size_t)b * nf + f] = (float)(t / (double)ins[f].per_sample);
@@ -622,10 +642,10 @@ struct Plan {
       if (!ok()) return;
       std::vector<unsigned char> run(B, 1);
       if (bc->predict(bc->ctx, idx, is_up ? 1 : 0, B, nf, h_timesteps.data(), mse.data(), run.data())) { fail("block cache: the predictor failed"); return; }
-      bool any = !bc->cached_valid;
+      bool any = !bc_all_valid;                                  // a sample without cached tensors has nothing to reuse
       for (int b = 0; b < B; ++b) any = any || run[b] != 0;
       for (int f = 0; f < nf && ok(); ++f)                       // the cached input is always the latest one (cache_manager.py:133,153)
-        if (hipMemcpyAsync(in_cache[f], ins[f].p, ins[f].per_sample * B * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess) fail("block cache: input copy failed");
+        bc_store(in_cache[f], ins[f].p, ins[f].per_sample * 2);
       const size_t n_skips0 = skips.size();
       mute = !any;
       body();
@@ -635,14 +655,14 @@ struct Plan {
       if (!is_up) for (size_t k = std::min(n_skips0, skips.size()); k < skips.size(); ++k) outs.push_back({skips[k].t, (size_t)skips[k].h * skips[k].wd * skips[k].C});
       if (outs.empty() || outs.back().p != x) outs.push_back({x, (size_t)h * wd * Ccur});
       for (auto& o : outs) {
-        char* oc = bc_top; bc_top += (o.per_sample * B * 2 + 255) & ~(size_t)255;
+        char* oc = region(o.per_sample);
         if ((size_t)(bc_top - (char*)bc->state) > bc->state_bytes) { fail("block cache: state buffer too small (mx_unet_block_cache_bytes)"); return; }
         if (!ok()) return;
-        if (any && bc->cached_valid && bc->observe && o.p == x) {      // how far the block's output moved since its last run (fitting labels)
+        if (any && bc_all_valid && bc->observe && o.p == x) {     // how far the block's output moved since its last run (fitting labels)
           double* part = (double*)bc->state;
           std::vector<double> hp((size_t)B * 64);
           std::vector<float> om(B);
-          if (mx::launch_sq_diff_partial(stream, o.p, oc, (long)o.per_sample, B, part)) { fail(mx_last_error()); return; }
+          if (mx::launch_sq_diff_partial(stream, o.p, oc, (long)o.per_sample, B, part, bc_dslot)) { fail(mx_last_error()); return; }
           if (hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
               hipStreamSynchronize(stream) != hipSuccess) { fail("block cache: reading the output differences failed"); return; }
           for (int b = 0; b < B; ++b) {
@@ -652,9 +672,7 @@ struct Plan {
           }
           bc->observe(bc->ctx, idx, B, om.data());
         }
-        const hipError_t e = any ? hipMemcpyAsync(oc, o.p, o.per_sample * B * 2, hipMemcpyDeviceToDevice, stream)
-                                 : hipMemcpyAsync(o.p, oc, o.per_sample * B * 2, hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) { fail("block cache: output copy failed"); return; }
+        if (any ? !bc_store(oc, o.p, o.per_sample * 2) : !bc_load(o.p, oc, o.per_sample * 2)) return;
       }
       if (any) blocks_run |= 1u << idx;
     };
@@ -664,7 +682,10 @@ struct Plan {
       return v;
     };
     int block = 0;
-    if (bc) bc_top = (dry ? (char*)nullptr : (char*)bc->state) + (((size_t)(c.layers_per_block + 2) * B * 64 * sizeof(double) + 255) & ~(size_t)255);
+    if (bc) {
+      if (bc_rows < B) bc_rows = B;
+      bc_top = (dry ? (char*)nullptr : (char*)bc->state) + bc_scratch_bytes(c.layers_per_block, bc_rows);
+    }
     for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, false, {{x, (size_t)h * wd * Ccur}}, [&] { down_block(i); });
     if (ok()) { run_block(block, false, {{x, (size_t)h * wd * Ccur}}, [&] { mid_block(); }); ++block; }
     for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, true, up_inputs(c.layers_per_block + 1), [&] { up_block(i); });
@@ -831,7 +852,7 @@ extern "C" size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, 
   mx_block_cache sizing{};
   p.u = const_cast<mx_unet*>(u); p.stream = nullptr; p.B = batch; p.H = H; p.W = W; p.ctx_len = 64; p.gn_patch = 0;
   p.dry = true; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
-  p.bc = &sizing;
+  p.bc = &sizing; p.bc_rows = batch;
   if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
   return (size_t)(p.bc_top - (char*)nullptr) + 256;
 }
@@ -853,14 +874,41 @@ extern "C" int mx_unet_forward_cached(mx_unet* u, void* stream, const void* late
   MX_CHECK(u->blob != nullptr, "unet: weights not set");
   MX_CHECK(io_dtype == MX_F32 || io_dtype == MX_F16 || io_dtype == MX_BF16, "unet: bad io dtype");
   MX_CHECK(((uintptr_t)cache->state & 255) == 0, "unet_forward_cached: cache->state must be 256-byte aligned");
-  cache->cached_valid = cache->cached_valid && cache->cached_key == cache->batch_key && cache->cached_batch == batch && cache->cached_h == H &&
-                        cache->cached_w == W;
   Plan p;
+  p.bc_valid.assign(batch, 0);
+  if (cache->slots) {
+    // one state row per request (the reference's dictionaries are keyed by request id, cache_manager.py:105-133): the caller says where each sample
+    // lives and whether that row holds tensors of an earlier step at this latent size
+    MX_CHECK(cache->slot_valid != nullptr && cache->n_slots >= batch, "unet_forward_cached: slots need slot_valid and n_slots >= batch");
+    std::vector<char> seen(cache->n_slots, 0);
+    for (int b = 0; b < batch; ++b) {
+      MX_CHECK(cache->slots[b] >= 0 && cache->slots[b] < cache->n_slots && !seen[cache->slots[b]], "unet_forward_cached: slots must be distinct and inside [0, n_slots)");
+      seen[cache->slots[b]] = 1;
+      p.bc_valid[b] = cache->slot_valid[b] ? 1 : 0;
+    }
+    p.bc_rows = cache->n_slots;
+  } else {
+    cache->cached_valid = cache->cached_valid && cache->cached_key == cache->batch_key && cache->cached_batch == batch && cache->cached_h == H &&
+                          cache->cached_w == W;
+    p.bc_valid.assign(batch, cache->cached_valid ? 1 : 0);
+    p.bc_rows = batch;
+  }
+  p.bc_all_valid = true; p.bc_any_valid = false;
+  for (int b = 0; b < batch; ++b) { p.bc_all_valid = p.bc_all_valid && p.bc_valid[b]; p.bc_any_valid = p.bc_any_valid || p.bc_valid[b]; }
   p.u = u; p.stream = (hipStream_t)stream; p.B = batch; p.H = H; p.W = W; p.ctx_len = ctx_len;
   p.gn_patch = (gn_patch >= H && gn_patch >= W) ? 0 : gn_patch;
   p.dry = false;
   p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = false;
   p.bc = cache;
+  if (cache->slots) {
+    MX_CHECK(Plan::bc_scratch_bytes(u->cfg.layers_per_block, p.bc_rows) <= cache->state_bytes, "unet_forward_cached: state buffer too small");
+    int* dslot = (int*)((char*)cache->state + (size_t)(u->cfg.layers_per_block + 2) * p.bc_rows * 64 * sizeof(double));
+    if (hipMemcpyAsync(dslot, cache->slots, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, p.stream) != hipSuccess) {
+      mx::set_error("unet_forward_cached: sending the slot table failed");
+      return 1;
+    }
+    p.bc_dslot = dslot;
+  }
   p.h_timesteps.resize(batch);
   // the predictor's timestep feature: the per-sample timesteps live in device memory like the rest of the step's operands
   if (hipMemcpyAsync(p.h_timesteps.data(), timesteps, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, p.stream) != hipSuccess ||

@@ -82,7 +82,8 @@ SKIP_OBSERVE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_
 class BlockCacheC(C.Structure):
     _fields_ = [("predict", SKIP_PREDICT_FN), ("ctx", C.c_void_p), ("state", C.c_void_p), ("state_bytes", C.c_size_t),
                 ("batch_key", C.c_uint64), ("cached_key", C.c_uint64), ("cached_valid", C.c_int), ("cached_batch", C.c_int),
-                ("cached_h", C.c_int), ("cached_w", C.c_int), ("blocks_run", C.c_uint), ("blocks_run_hi", C.c_uint), ("observe", SKIP_OBSERVE_FN)]
+                ("cached_h", C.c_int), ("cached_w", C.c_int), ("blocks_run", C.c_uint), ("blocks_run_hi", C.c_uint), ("observe", SKIP_OBSERVE_FN),
+                ("slots", C.POINTER(C.c_int32)), ("slot_valid", C.POINTER(C.c_ubyte)), ("n_slots", C.c_int)]
 
 
 class CLIPConfigC(C.Structure):

@@ -11,7 +11,7 @@ import torch
 
 from . import lib as _lib
 from .config import MMDiTConfig
-from .unet import _Config, _stable_key
+from .unet import _Config, _row_ids
 from .weights import PackedWeights, pack_mmdit
 
 
@@ -59,7 +59,7 @@ class MxSD3Transformer:
         return self
 
     def forward_one(self, latents: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
-                    pooled: torch.Tensor, stage: Optional[str] = None, stage_shape=None, cache=None, batch_key: int = 0) -> torch.Tensor:
+                    pooled: torch.Tensor, stage: Optional[str] = None, stage_shape=None, cache=None, batch_key: int = 0, row_ids=None) -> torch.Tensor:
         """`cache` (sduss_amd/block_cache.py BlockSkipCache, forced_after=2) routes the step through mx_mmdit_forward_cached: the
         reference's ESYMRED_USE_CACHE=TRUE path (SD3Transformer.py:151-228).  Approximate by design; off by default."""
         assert latents.is_cuda and latents.ndim == 4
@@ -90,7 +90,7 @@ class MxSD3Transformer:
         out = torch.empty((b, self.cfg.out_channels, h, w), dtype=latents.dtype, device=self.device)
         if cache is not None:
             assert stage is None
-            desc = cache.bind(self, b, h, w, batch_key, ctx_len=lt)
+            desc = cache.bind(self, b, h, w, batch_key, ctx_len=lt, row_ids=row_ids)
             rc = self._lib.mx_mmdit_forward_cached(self._handle, stream, latents.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
                                                    pp.data_ptr(), out.data_ptr(), b, h, w, lt, ws.data_ptr(), ws.numel(), desc)
             if rc and cache.error is not None:
@@ -132,7 +132,7 @@ class MxSD3Transformer:
                 bc = caches.get(key)
                 if bc is None:
                     bc = caches[key] = self._new_block_cache()
-                out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], pooled_projections[sl], cache=bc, batch_key=_stable_key(ids))
+                out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], pooled_projections[sl], cache=bc, row_ids=_row_ids(ids, n))
             else:
                 out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], pooled_projections[sl])
             row += n

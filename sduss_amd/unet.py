@@ -22,10 +22,9 @@ class _Config(dict):
     __getattr__ = dict.__getitem__
 
 
-def _stable_key(ids) -> int:
-    """64-bit key of a batch composition (the request ids of a resolution in row order)"""
-    import hashlib
-    return int.from_bytes(hashlib.blake2b("\x1f".join(str(i) for i in ids).encode(), digest_size=8).digest(), "little")
+def _row_ids(ids, n_rows):
+    """one id per row of a resolution's batch: the request ids repeat once per classifier-free-guidance half ([uncond..., cond...])"""
+    return [f"{ids[i % len(ids)]}#{i // len(ids)}" for i in range(n_rows)]
 
 
 class MxUNet:
@@ -127,7 +126,7 @@ class MxUNet:
         return st
 
     def forward_one_cached(self, cache, sample: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
-                           text_embeds: torch.Tensor, time_ids: torch.Tensor, batch_key: int, gn_patch: int = 0) -> torch.Tensor:
+                           text_embeds: torch.Tensor, time_ids: torch.Tensor, batch_key: int = 0, gn_patch: int = 0, row_ids=None) -> torch.Tensor:
         """forward_one through the block-skip cache (sduss_amd/block_cache.py BlockSkipCache; the reference's ESYMRED_USE_CACHE=TRUE
         path, cache_manager.py:101-161).  Approximate by design; forward_one never consults it."""
         assert sample.is_cuda and sample.ndim == 4
@@ -145,7 +144,7 @@ class MxUNet:
         out = torch.empty((b, self.cfg.out_channels, h, w), dtype=sample.dtype, device=self.device)
         stream = _lib.current_stream()
         ws = self._workspace(b, h, w, ctx_len, int(stream or 0))
-        desc = cache.bind(self, b, h, w, batch_key)
+        desc = cache.bind(self, b, h, w, batch_key, row_ids=row_ids)
         rc = self._lib.mx_unet_forward_cached(self._handle, stream, sample.data_ptr(), _lib.torch_dtype_code(sample.dtype),
                                               ts.data_ptr(), ehs.data_ptr(), te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, h, w,
                                               ctx_len, gn_patch, ws.data_ptr(), ws.numel(), desc)
@@ -191,8 +190,8 @@ class MxUNet:
                 bc = caches.get(key)
                 if bc is None:
                     bc = caches[key] = self._new_block_cache()
-                out[key] = self.forward_one_cached(bc, x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl],
-                                                   batch_key=_stable_key(ids), gn_patch=gn_patch)
+                out[key] = self.forward_one_cached(bc, x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl], gn_patch=gn_patch,
+                                                   row_ids=_row_ids(ids, n))
             else:
                 out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl], gn_patch)
             row += n

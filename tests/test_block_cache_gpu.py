@@ -317,8 +317,12 @@ def test_model_slot_forward_with_the_cache_enabled(tiny):
         den.denoising_step(got)
         assert all(c.history[-1] == 0 for c in net._block_caches.values())
         assert all(not torch.equal(a, r.latents) for a, r in zip(before, got["256"]))
-        # a request leaves the 256 px batch: that resolution's state is refilled, the other one keeps reusing
+        # a request leaves the 256 px batch: the one that stays keeps its cached tensors (the reference's dictionaries are keyed by request id)
         got["256"] = got["256"][:1]
+        den.denoising_step(got)
+        assert net._block_caches["256"].history[-1] == 0 and net._block_caches["128"].history[-1] == 0
+        # a new request joins it: it has nothing cached, so every block runs once, for the whole batch
+        got["256"].append(synthetic_request(77, 256, 10, cfg, den, torch.device("cuda:0"), shared=shared))
         den.denoising_step(got)
         assert net._block_caches["256"].history[-1] == 0x7f and net._block_caches["128"].history[-1] == 0
     finally:
@@ -361,3 +365,61 @@ def test_observer_reports_output_movement_and_fitted_forest_plugs_in(tiny):
     assert bc2.history == [0x7f, 0] and torch.equal(a, b)
     c = net.forward_one_cached(bc2, s1, t, e, te, ti, batch_key=1)
     assert bc2.history[-1] == 0x7f and torch.equal(c, net.forward_one(s1, t, e, te, ti))
+
+
+def test_state_follows_the_requests_not_the_batch_positions(tiny):
+    """row_ids: one state row per request.  A request that stays while others leave, join or change position keeps its cached tensors and its
+    counters; what comes out of a reused block is that REQUEST's cached output wherever it now sits in the batch."""
+    from sduss_amd.block_cache import BlockSkipCache
+    ocfg, net = tiny
+    bc = BlockSkipCache(Always(0), forced_after=1 << 30)
+    s, t, e, te, ti = _inputs(ocfg, 3, 32, 0)                   # samples a, b, c
+    sa, sb, sc = s[0:1], s[1:2], s[2:3]
+    row = lambda *idx: (torch.cat([s[i:i + 1] for i in idx]), t[list(idx)], e[list(idx)], te[list(idx)], ti[list(idx)])
+    noise = lambda x, k: (x.float() + 0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(k)).cuda()).to(torch.bfloat16)
+    # step 1: [a, b] -- nothing cached, every block runs
+    x, tt, ee, tte, tti = row(0, 1)
+    out1 = net.forward_one_cached(bc, x, tt, ee, tte, tti, row_ids=["a", "b"])
+    assert bc.history[-1] == 0x7f and torch.equal(out1, net.forward_one(x, tt, ee, tte, tti))
+    # step 2: a left; b alone with moved latents -- everything reused: b's cached output, although b now sits in position 0
+    x, tt, ee, tte, tti = row(1)
+    out2 = net.forward_one_cached(bc, noise(x, 1), tt, ee, tte, tti, row_ids=["b"])
+    # (the layers after the last block -- conv_norm_out, conv_out -- run at batch 1 now: same arithmetic, possibly another rounding sequence)
+    assert bc.history[-1] == 0 and (out2.float() - out1[1:2].float()).abs().max() <= 0.01 * out1.float().abs().max()
+    # step 3: c joins -- c has nothing cached, every block runs for the batch: the exact forward
+    x, tt, ee, tte, tti = row(1, 2)
+    x3 = noise(x, 2)
+    out3 = net.forward_one_cached(bc, x3, tt, ee, tte, tti, row_ids=["b", "c"])
+    assert bc.history[-1] == 0x7f and torch.equal(out3, net.forward_one(x3, tt, ee, tte, tti))
+    # step 4: the two swap positions, latents move -- reused: each request's own cached output, in the new order
+    x, tt, ee, tte, tti = row(2, 1)
+    out4 = net.forward_one_cached(bc, noise(x, 3), tt, ee, tte, tti, row_ids=["c", "b"])
+    assert bc.history[-1] == 0 and torch.equal(out4, torch.cat([out3[1:2], out3[0:1]]))
+    # step 5: a comes back: it was forgotten when it left (cache_manager.py:131), so the blocks run again
+    x, tt, ee, tte, tti = row(0, 2, 1)
+    x5 = noise(x, 4)
+    out5 = net.forward_one_cached(bc, x5, tt, ee, tte, tti, row_ids=["a", "c", "b"])
+    assert bc.history[-1] == 0x7f and torch.equal(out5, net.forward_one(x5, tt, ee, tte, tti))
+    # the features the predictor saw in step 5: a uncached, c and b carry finite differences
+    from sduss_amd.block_cache import MSE_UNCACHED
+    last = bc.down.rows[-7]
+    assert last[0, 2] >= MSE_UNCACHED * 0.5 and (last[1:, 2] < 1e6).all()
+
+
+def test_reuse_counters_follow_the_requests(tiny):
+    """forced run after two reuses, per request (cache_manager.py:128-136 with per-id previous_mask).  The predictor here answers "reuse" even
+    for a request with nothing cached, so -- as in the reference's bookkeeping -- a request's first step already counts one; b and c then reach
+    their forced runs at different steps because c joined later."""
+    from sduss_amd.block_cache import BlockSkipCache
+    ocfg, net = tiny
+    bc = BlockSkipCache(Always(0), forced_after=2)
+    s, t, e, te, ti = _inputs(ocfg, 2, 32, 0)
+    one = lambda i: (s[i:i + 1], t[i:i + 1], e[i:i + 1], te[i:i + 1], ti[i:i + 1])
+    net.forward_one_cached(bc, *one(0), row_ids=["b"])                       # b uncached: runs; b = 1
+    net.forward_one_cached(bc, *one(0), row_ids=["b"])                       # reuse; b = 2
+    net.forward_one_cached(bc, s, t, e, te, ti, row_ids=["b", "c"])          # b forced (and c uncached): runs; b = 0, c = 1
+    net.forward_one_cached(bc, s, t, e, te, ti, row_ids=["b", "c"])          # reuse; b = 1, c = 2
+    net.forward_one_cached(bc, s, t, e, te, ti, row_ids=["b", "c"])          # c forced: runs for the batch; c = 0, b = 2
+    net.forward_one_cached(bc, s, t, e, te, ti, row_ids=["b", "c"])          # b forced: runs; b = 0, c = 1
+    net.forward_one_cached(bc, s[1:2], t[1:2], e[1:2], te[1:2], ti[1:2], row_ids=["c"])   # c alone keeps its counter: reuse; c = 2
+    assert bc.history == [0x7f, 0, 0x7f, 0, 0x7f, 0x7f, 0]

@@ -510,7 +510,7 @@ def test_block_cache_state_size_is_the_sum_of_block_inputs_and_outputs(tiny):
     r256 = lambda n: (n + 255) // 256 * 256
     ten = lambda hw, ch: r256(B * hw * hw * ch * 2)
     ch = list(pcfg.block_out_channels)
-    want = r256(4 * B * 64 * 8)
+    want = r256(4 * B * 64 * 8 + B * 4)            # comparison scratch + the slot table
     hw, cin, skips = H, ch[0], [(H, ch[0])]
     for i in range(3):
         want += ten(hw, cin)
@@ -542,7 +542,7 @@ def test_mmdit_block_cache_state_size():
     B, H, Lt = 3, 24, 77
     d, L = pcfg.num_attention_heads * 64, (H // pcfg.patch_size) ** 2
     r256 = lambda n: (n + 255) // 256 * 256
-    want = r256(B * 64 * 8) + pcfg.num_layers * (2 * r256(B * L * d * 2) + r256(B * Lt * d * 2))
+    want = r256(B * 64 * 8 + B * 4) + pcfg.num_layers * (2 * r256(B * L * d * 2) + r256(B * Lt * d * 2))
     assert l.mx_mmdit_block_cache_bytes(h, B, H, H, Lt) == want
     assert l.mx_mmdit_block_cache_bytes(h, B, H + 1, H, Lt) == 0
     l.mx_mmdit_destroy(h)
