@@ -602,3 +602,52 @@ def test_block_skip_bookkeeping_equals_the_reference_restatement():
                 assert bc._predict(None, block, int(nres > 0), n, 1 + nres, C.cast(ts.ctypes.data, fp), C.cast(sent.ctypes.data, fp), out) == 0
                 assert np.array_equal(np.array(list(out)) > 0, want), (forced, nres, step)
                 assert np.allclose(pb.last, feat.astype(np.float32).astype(np.float64), rtol=1e-6), (forced, nres, step)
+
+
+def test_block_cache_slot_table_follows_the_requests(tiny):
+    """BlockSkipCache._bind_rows on the host (state tensor on the CPU, sizes from the library's dry walk): distinct rows, a request keeps its row
+    while it stays, is forgotten when it leaves (cache_manager.py:131: the dictionaries are rebuilt from the ids of each call), a returning or new
+    request starts invalid, the counters follow the ids, a larger batch grows the state and forgets everything, another latent size too."""
+    from sduss_amd import config, lib
+    from sduss_amd.block_cache import BlockSkipCache
+    l = lib.load()
+    pcfg = config.UNetConfig.tiny()
+    cc = lib.UNetConfigC()
+    cc.in_channels, cc.out_channels, cc.n_levels, cc.layers_per_block = 4, 4, 3, 2
+    for i, v in enumerate(pcfg.block_out_channels):
+        cc.block_out_channels[i] = v; cc.down_has_attn[i] = int(pcfg.down_has_attn[i])
+        cc.transformer_layers[i] = pcfg.transformer_layers_per_block[i]; cc.num_heads[i] = pcfg.num_heads[i]
+    cc.cross_attention_dim, cc.addition_time_embed_dim = pcfg.cross_attention_dim, pcfg.addition_time_embed_dim
+    cc.projection_class_embeddings_input_dim, cc.norm_num_groups = pcfg.projection_class_embeddings_input_dim, 32
+    h = l.mx_unet_create(C.byref(cc))
+
+    class Model:
+        _lib, _handle, device = l, h, torch.device("cpu")
+
+    class Zero:
+        def predict(self, f):
+            return np.zeros(len(f))
+    bc = BlockSkipCache(Zero(), forced_after=3)
+
+    def bind(ids, hw=16):
+        bc.bind(Model, len(ids), hw, hw, 0, row_ids=ids)
+        return list(bc._slots_arr), list(bc._valid_arr)
+    s1, v1 = bind(["a", "b", "c"])
+    assert len(set(s1)) == 3 and v1 == [0, 0, 0] and bc.desc.n_slots == 8
+    assert bc.state.numel() == l.mx_unet_block_cache_bytes(h, 8, 16, 16)
+    bc.previous = {0: {"a": 1, "b": 2, "c": 0}}
+    s2, v2 = bind(["c", "a"])                                   # b left; order changed
+    assert s2 == [s1[2], s1[0]] and v2 == [1, 1] and bc.previous[0] == {"a": 1, "c": 0}
+    s3, v3 = bind(["a", "b", "d"])                              # b comes back (forgotten), d is new, c left
+    assert s3[0] == s1[0] and v3 == [1, 0, 0] and len(set(s3)) == 3 and bc.previous[0] == {"a": 1}
+    state_before = bc.state
+    s4, v4 = bind([f"r{i}" for i in range(9)])                  # more requests than rows: the state grows, nothing cached survives
+    assert bc.desc.n_slots == 18 and v4 == [0] * 9 and bc.state is not state_before and bc.previous == {}
+    s5, v5 = bind(["r0", "r1"], hw=24)                          # another latent size
+    assert v5 == [0, 0] and bc.desc.n_slots == 8
+    with pytest.raises(AssertionError):
+        bind(["x", "x"])
+    # without row ids the descriptor goes back to the batch-composition rule
+    bc.bind(Model, 2, 16, 16, 5)
+    assert not bc.desc.slots and bc.desc.n_slots == 0 and bc.desc.batch_key == 5
+    l.mx_unet_destroy(h)
