@@ -90,6 +90,30 @@ enum {
   MX_EPI_GEGLU_TANH = 1 << 9 /* with MX_EPI_GEGLU: the gate takes the tanh form of GELU ("gelu_new": T5 v1.1 gated-gelu) */
 };
 
+/* One problem of a GROUPED launch (mx_gemm_desc.segs): mixed-resolution batches run every op of the step plan ONCE over the requests of all
+ * resolutions present (the reference's reason to exist: modules/unet.py:104-185 cuts the latents of all resolutions into one patch batch).
+ * The problems of a group share w, bias, N, K, the leading dimensions, flags and every scalar of the descriptor; each has its own rows,
+ * per-batch structure and operand bases.  Output tiles never straddle two problems (a workgroup finds its problem from its tile index with
+ * two compares and then runs the ordinary kernel body on it), nothing is padded in memory, and every output element sees exactly the
+ * arithmetic of a separate launch with the same tile shape.  Pointer fields that the descriptor leaves NULL must be NULL here too. */
+#define MX_MAX_SEGS 4
+typedef struct mx_gemm_seg {
+  const void* a;          /* this problem's A rows (conv: its first image) */
+  const void* a2;
+  void* c;
+  const void* residual;
+  void* vt;
+  const float* rowbias;   /* row 0 = this problem's first sample */
+  const float* gate;
+  const float* ln_stats;
+  float* stats_out;
+  int M;                  /* rows (conv: B * Hout * Wout) */
+  int rows_per_batch;
+  int ldvt;
+  int B, Hin, Win, Hout, Wout;                              /* conv geometry */
+  int a_batch_rows, a_row_off, c_batch_rows, c_row_off;     /* joint-sequence remap */
+} mx_gemm_seg;
+
 typedef struct mx_gemm_desc {
   const void* a;        /* bf16 [M, K] row stride lda (elements); conv: NHWC input [B, Hin, Win, Cin] */
   const void* w;        /* bf16 [N, K] row-major (K = 9*Cin tap-major for conv) */
@@ -151,6 +175,10 @@ typedef struct mx_gemm_desc {
   int ln_slabs;
   float ln_eps;
   float* stats_out;
+  /* grouped launch: n_segs in [1, MX_MAX_SEGS] problems (see mx_gemm_seg); 0 = the single problem described above.  With segs the
+   * descriptor's own a / c / residual / vt / rowbias / gate / ln_stats / stats_out only say WHICH operands exist (non-NULL), M is ignored. */
+  const mx_gemm_seg* segs;
+  int n_segs;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -305,7 +333,8 @@ size_t mx_unet_workspace_bytes_pp(const mx_unet* u, int batch, int H_local, int 
 int mx_unet_forward_pp(mx_unet* u, void* stream, const void* latents_local, int io_dtype, const float* timesteps, const void* ehs,
                        const void* text_embeds, const float* time_ids, void* out_local, int batch, int H_local, int W, int ctx_len,
                        const mx_pp_comm* comm, void* workspace, size_t workspace_bytes);
-/* Stale-asynchronous steps: distrifuser's default mode after `warmup_steps` (= 4) synchronous steps (utils.py:30-32, 180-214;
+/* Stale-asynchronous steps: distrifuser's default mode after its warm-up (synchronous while counter <= warmup_steps: warmup_steps + 1 = 5
+ * synchronous steps at the default of 4; utils.py:30-32, 180-214;
  * modules/pp/conv2d.py:97-117, attn.py:136-146, groupnorm.py:46-66).  Every exchange k of a forward owns region k of a state buffer the caller
  * keeps across steps.  A WARMUP step is a synchronous step that also leaves what it gathered in the state.  A STALE step reads, for every
  * exchange, the OTHER ranks' slots as they were sent one step earlier and its own slot fresh, and hands its fresh slot to
@@ -452,7 +481,8 @@ int mx_t5_encode(mx_t5* t, void* stream, const int32_t* ids, void* out, int batc
  * Block-skip cache ("Mix-Cache"): the reference's CacheManager with ESYMRED_USE_CACHE=TRUE (modules/cache_manager.py:101-191, called at the
  * top of each of the UNet's seven blocks -- three down, mid, three up: unet_2d_blocks.py:40,102,180,250,345).  Before a block runs, every
  * sample's block input (for the up blocks also each skip tensor it consumes) is compared with the input that block saw at its last run: the
- * mean squared difference.  The host predictor sees the reference's feature rows [block index, timestep, mse (, mse of each skip)] and answers
+ * mean squared difference.  The host predictor sees the reference's feature rows [block index, timestep, mse (, mse of each skip: oldest skip
+ * first, the first-consumed one last, as res_hidden_states_tuple is ordered: cache_manager.py:110-121)] and answers
  * run / reuse per sample; a reused block's outputs (hidden state and, for the down blocks, the skip tensors) come from the cache.
  * Approximate by design and OFF on the exact path (mx_unet_forward never consults it).
  * Granularity: the step batch, as the reference's block-level caches -- a block's outputs come from the cache only when NO sample asks to run

@@ -104,6 +104,7 @@ class BlockSkipCache:
         self.desc.predict = self._cb
         self.observed, self.features = [], []
         self._row_ids, self._geom, self._slot_of, self._cap = None, None, {}, 0
+        self._pending = None                                 # request -> row table of a forward in flight (committed by after_forward)
         self._record = observe
         if observe:
             self._cb_obs = _lib.SKIP_OBSERVE_FN(self._observe)
@@ -175,6 +176,8 @@ class BlockSkipCache:
 
     def _bind_rows(self, model, batch, h, w, ctx_len, row_ids):
         assert len(row_ids) == batch and len(set(row_ids)) == batch, "one distinct id per sample"
+        if getattr(self, "_pending", None) is not None:        # the previous forward never reached after_forward(): it failed part-way, so
+            self.invalidate()                                  # some blocks' rows were stored and others not -- nothing cached can be trusted
         geom = (h, w, ctx_len)
         if getattr(self, "_geom", None) != geom:              # another latent size: nothing cached applies
             self._geom, self._slot_of, self._cap = geom, {}, 0
@@ -200,7 +203,9 @@ class BlockSkipCache:
             else:
                 keep[rid] = free.pop(0)
                 valid.append(0)
-        self._slot_of = keep
+        # The new table is only STAGED here and committed by after_forward(): a forward that fails part-way (predictor exception, short
+        # workspace) has not stored the new requests' rows for its later blocks, and must not leave them marked valid for the next step.
+        self._pending = keep
         self._row_ids = row_ids
         self._slots_arr = (C.c_int32 * batch)(*[keep[r] for r in row_ids])
         self._valid_arr = (C.c_ubyte * batch)(*valid)
@@ -216,12 +221,17 @@ class BlockSkipCache:
         return C.byref(self.desc)
 
     def after_forward(self):
+        """the forward succeeded: commit the request -> row table staged by bind()"""
+        if getattr(self, "_pending", None) is not None:
+            self._slot_of, self._pending = self._pending, None
         self.history.append(int(self.desc.blocks_run) | int(self.desc.blocks_run_hi) << 32)
 
     def invalidate(self):
+        """forget everything cached (called when a forward failed, and by callers that change the model's inputs out of band)"""
         self.desc.cached_valid = 0
         self.previous = {}
         self._slot_of = {}
+        self._pending = None
 
     @staticmethod
     def blocks_of(mask: int) -> Sequence[int]:

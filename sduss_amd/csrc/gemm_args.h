@@ -8,6 +8,16 @@
 
 namespace mx {
 
+// one problem of a grouped launch (mx_gemm_seg + the first m-tile index of the problem in the launch's tile list)
+constexpr int kMaxSegs = MX_MAX_SEGS;
+struct GemmSeg {
+  const bf16_t* a; const bf16_t* a2; void* c; const bf16_t* residual; bf16_t* vt; const float* rowbias; const float* gate;
+  const float* ln_stats; float* stats_out;
+  int M, tile0, rows_per_batch, ldvt;
+  int B, Hin, Win, Hout, Wout;
+  int a_batch_rows, a_row_off, c_batch_rows, c_row_off;
+};
+
 struct GemmArgs {
   const bf16_t* a;
   const bf16_t* w;
@@ -39,7 +49,30 @@ struct GemmArgs {
   int ln_slabs;
   float ln_eps;
   float* stats_out;        // row statistics of the stored values, one slab per wave column panel; nullptr = off
+  // grouped launch (mx_gemm_desc.segs): nseg problems along M, prob[i].tile0 = first m-tile of problem i, mt_total = all m-tiles; nseg == 0: M above
+  int nseg, mt_total;
+  GemmSeg prob[kMaxSegs];
 };
+
+// Grouped launch: m-tile `tm` of the whole launch -> its problem.  `q` (a copy of the kernel argument) becomes that problem -- rows, per-batch
+// structure, operand bases -- and tm the tile index inside it.  Everything here is wave-uniform (scalar registers / scalar loads from the
+// kernel-argument segment); the kernel body that follows is the ordinary one.  Returns the problem index.
+__device__ __forceinline__ int gemm_select_seg(GemmArgs& q, const GemmArgs& p, int& tm) {
+  if (p.nseg <= 0) return 0;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxSegs; ++i) if (i < p.nseg && tm >= p.prob[i].tile0) s = i;
+  const GemmSeg& g = p.prob[s];
+  tm -= g.tile0;
+  q.a = g.a; q.a2 = g.a2; q.c = g.c; q.residual = g.residual; q.vt = g.vt; q.rowbias = g.rowbias; q.gate = g.gate;
+  q.ln_stats = g.ln_stats; q.stats_out = g.stats_out;
+  q.M = g.M; q.rows_per_batch = g.rows_per_batch; q.ldvt = g.ldvt;
+  q.B = g.B; q.Hin = g.Hin; q.Win = g.Win; q.Hout = g.Hout; q.Wout = g.Wout;
+  q.a_batch_rows = g.a_batch_rows; q.a_row_off = g.a_row_off; q.c_batch_rows = g.c_batch_rows; q.c_row_off = g.c_row_off;
+  return s;
+}
+// m-tiles of the whole launch for tiles of `rows` rows
+__device__ __forceinline__ int gemm_m_tiles(const GemmArgs& p, int rows) { return p.nseg > 0 ? p.mt_total : (p.M + rows - 1) / rows; }
 
 // sum over the four lanes of a token (lane bits 4 and 5) without the LDS crossbar: v_permlane16_swap / v_permlane32_swap exchange
 // 16-lane rows / wave halves between two registers (inline asm: the builtins fold their two results when both inputs are one value)

@@ -19,6 +19,7 @@
 //
 // Reference call sites this serves: F.linear / F.conv2d issued by sduss/model_executor/modules/
 // resnet.py:106,132,163 and attention.py:73-96,148-151,220 (through un-vendored diffusers/torch).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -33,7 +34,7 @@ constexpr int BK = 64;
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 template <int BN, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs pk) {
   constexpr int NI = BN / 32;  // 16-wide feature blocks per wave (wave covers BN/2 features)
   constexpr int MI = 4;        // 16-wide token blocks per wave (wave covers 64 tokens)
   constexpr int WROWS = BN / 32;  // W rows staged per thread
@@ -45,7 +46,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   const int wave = tid >> 6;
   const int wm = wave >> 1;  // token half
   const int wn = wave & 1;   // feature half
-  const int m0 = blockIdx.x * BM;
+  GemmArgs p = pk;              // grouped launch (gemm_args.h): blockIdx.x counts the m-tiles of all problems; p becomes this tile's problem
+  int tm = blockIdx.x;
+  gemm_select_seg(p, pk, tm);
+  const int m0 = tm * BM;
   const int n0 = blockIdx.y * BN;
   const int nk = p.K / BK;
 
@@ -181,7 +185,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 }
 
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
-int launch_v3(hipStream_t s, const GemmArgs& a);
 int launch_v4(hipStream_t s, const GemmArgs& a);
 
 // Tile choice for the pipelined kernels.  Candidates (token rows x features): 256x256 (gemm_bf16_v3.hip), 256x160, 256x128,
@@ -191,34 +194,59 @@ int launch_v4(hipStream_t s, const GemmArgs& a);
 // the tiling with the fewest rounds and the largest tile (fewest bytes per FLOP; the 256x256 kernel is further discounted by
 // its measured advantage).  rows == 0: use the generic 128-row kernel.
 struct TileChoice { int bn; int rows; };
+// m-tiles of the launch for tiles of `rows` rows: the problems of a grouped launch are tiled one by one (no tile straddles two of them)
+static long m_tiles_of(const mx_gemm_desc* d, int rows) {
+  if (d->n_segs <= 0) return cdiv(d->M, rows);
+  long t = 0;
+  for (int i = 0; i < d->n_segs; ++i) t += cdiv(d->segs[i].M, rows);
+  return t;
+}
+static long rows_of(const mx_gemm_desc* d) {
+  if (d->n_segs <= 0) return d->M;
+  long m = 0;
+  for (int i = 0; i < d->n_segs; ++i) m += d->segs[i].M;
+  return m;
+}
 static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   static const bool disabled = [] { const char* e = getenv("MX_GEMM_V2"); return e && e[0] == '0'; }();
-  static const bool v3_disabled = [] { const char* e = getenv("MX_GEMM_V3"); return e && e[0] == '0'; }();
+  static const bool v3_disabled = [] { const char* e = getenv("MX_GEMM_256"); return e && e[0] == '0'; }();     // A/B: keep launches off the 256 x 256 kernel
   static const bool small_disabled = [] { const char* e = getenv("MX_GEMM_ROWS128"); return e && e[0] == '0'; }();
   static const double v3_discount = [] { const char* e = getenv("MX_V3_DISCOUNT"); return e ? atof(e) : 0.87; }();
   const TileChoice none = {0, 0};
-  if (disabled || d->M < 128 || d->K < 128) return none;
+  const long Mtot = rows_of(d);
+  if (disabled || Mtot < 128 || d->K < 128) return none;
   if (d->flags & MX_EPI_OUT_F32) return none;     // the register-exchange epilogue of the 256-row kernels writes bf16 only
   // their LDS-staged epilogue moves 16-byte pieces of C and of the residual
   if (d->ldc % 8 != 0 || ((uintptr_t)d->c & 15) != 0) return none;
   if (d->residual && (d->ldr % 8 != 0 || ((uintptr_t)d->residual & 15) != 0)) return none;
   const bool geglu = (d->flags & MX_EPI_GEGLU) != 0, qkv = (d->flags & MX_EPI_QKV) != 0;
-  // the 256x256 kernel addresses its operands with 32-bit byte offsets from the base pointers
-  const long in_rows = d->a_batch_rows > 0 ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
-  const bool fits32 = in_rows * d->lda * 2 < (1L << 32) && (long)d->N * d->K * 2 < (1L << 32);
+  // the 256x256 kernel addresses its operands with 32-bit byte offsets from the base pointers (grouped: from the lowest problem base)
+  bool fits32 = (long)d->N * d->K * 2 < (1L << 32);
+  if (d->n_segs <= 0) {
+    const long in_rows = d->a_batch_rows > 0 ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
+    fits32 = fits32 && in_rows * d->lda * 2 < (1L << 32);
+  } else {
+    uintptr_t lo = (uintptr_t)d->segs[0].a;
+    for (int i = 1; i < d->n_segs; ++i) lo = std::min(lo, (uintptr_t)d->segs[i].a);
+    for (int i = 0; i < d->n_segs; ++i) {
+      const mx_gemm_seg& g = d->segs[i];
+      const long in_rows = g.a_batch_rows > 0 ? (long)(g.M / std::max(g.rows_per_batch, 1) + 1) * g.a_batch_rows : g.M;
+      fits32 = fits32 && (long)((uintptr_t)g.a - lo) + in_rows * d->lda * 2 < (1L << 32);
+    }
+  }
   TileChoice best = none;
   double best_cost = 0;
   const TileChoice cands[5] = {{256, 256}, {160, 256}, {128, 256}, {160, 128}, {128, 128}};
   for (int c = 0; c < 5; ++c) {
     const int bn = cands[c].bn, rows = cands[c].rows;
-    if (d->N % bn != 0 || d->M < rows) continue;
+    if (d->N % bn != 0 || Mtot < rows) continue;
     if (bn == 256 && (conv || v3_disabled || !fits32 || d->a2 || d->ln_stats || d->stats_out)) continue;   // (built without those hooks)
     if (rows == 128 && small_disabled) continue;
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;
     if ((d->flags & MX_EPI_RMSNORM) && bn == 160) continue;   // a 64-wide head must lie inside one wave panel (gemm_epilogue_regs)
     if (qkv && bn != 256 && d->seg % (bn / 2) != 0) continue;
-    const long tiles = (long)cdiv(d->M, rows) * (d->N / bn);
+    const long tiles = m_tiles_of(d, rows) * (d->N / bn);
     const int ncu = cu_count();
     const double cost = (double)((tiles + ncu - 1) / ncu) * (rows + bn) * (bn == 256 ? v3_discount : 1.0);
     if (best.rows == 0 || cost < best_cost) { best = cands[c]; best_cost = cost; }
@@ -240,7 +268,31 @@ static int stats_slabs_of(const mx_gemm_desc* d, bool conv, const TileChoice& tc
 static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   MX_CHECK(d != nullptr, "gemm: null descriptor");
   MX_CHECK(d->a && d->w && (d->c || (d->flags & MX_EPI_QKV)), "gemm: null operand");
-  MX_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem");
+  MX_CHECK(d->n_segs >= 0 && d->n_segs <= MX_MAX_SEGS && (d->n_segs == 0 || d->segs != nullptr), "gemm: bad n_segs / segs");
+  MX_CHECK((d->n_segs > 0 || d->M > 0) && d->N > 0 && d->K > 0, "gemm: empty problem");
+  for (int i = 0; i < d->n_segs; ++i) {          // a problem of a grouped launch has exactly the operands the descriptor names
+    const mx_gemm_seg& g = d->segs[i];
+    MX_CHECK(g.M > 0 && g.a && (g.c != nullptr) == (d->c != nullptr), "gemm: grouped launch: empty problem or missing a / c");
+    MX_CHECK((g.a2 != nullptr) == (d->a2 != nullptr && !conv) && (g.residual != nullptr) == (d->residual != nullptr) && (g.vt != nullptr) == (d->vt != nullptr) &&
+             (g.rowbias != nullptr) == (d->rowbias != nullptr) && (g.gate != nullptr) == (d->gate != nullptr) &&
+             (g.ln_stats != nullptr) == (d->ln_stats != nullptr) && (g.stats_out != nullptr) == (d->stats_out != nullptr),
+             "gemm: grouped launch: a problem's optional operands must match the descriptor's");
+    const void* ptrs[] = {g.a, g.a2, g.c, g.residual, g.vt, g.rowbias, g.gate, g.ln_stats, g.stats_out};
+    for (const void* q : ptrs) MX_CHECK(((uintptr_t)q & 15) == 0, "gemm: grouped launch: operand pointers must be 16-byte aligned");
+    if (d->rowbias || d->gate || g.a_batch_rows > 0 || g.c_batch_rows > 0 || (d->flags & (MX_EPI_QKV | MX_EPI_RES_BCAST)))
+      MX_CHECK(g.rows_per_batch > 0, "gemm: grouped launch: rows_per_batch required");
+    if (g.a_batch_rows > 0) MX_CHECK(!conv && g.a_row_off >= 0 && g.a_row_off + g.rows_per_batch <= g.a_batch_rows, "gemm: grouped launch: bad input row remap");
+    if (g.c_batch_rows > 0) MX_CHECK(g.c_row_off >= 0 && g.c_row_off + g.rows_per_batch <= g.c_batch_rows, "gemm: grouped launch: bad output row remap");
+    if (d->flags & MX_EPI_QKV)
+      MX_CHECK(g.M % g.rows_per_batch == 0 && g.ldvt >= MX_VT_LD(g.c_batch_rows > 0 ? g.c_batch_rows : g.rows_per_batch) && g.ldvt % 8 == 0,
+               "gemm: grouped launch: QKV needs whole batches and ldvt >= MX_VT_LD(keys per batch)");
+    if (conv) {
+      const int Hv = g.Hin << d->up, Wv = g.Win << d->up;
+      MX_CHECK(g.Hout == (Hv + d->stride - 1) / d->stride && g.Wout == (Wv + d->stride - 1) / d->stride && (long)g.B * g.Hout * g.Wout == g.M,
+               "conv3x3: grouped launch: a problem's output grid does not match its input grid / stride / rows");
+    }
+    MX_CHECK((long)g.M * (conv ? 1 : d->lda) < 2147483647L, "gemm: grouped launch: operand exceeds 32-bit indexing");
+  }
   MX_CHECK(d->K % BK == 0, "gemm: K must be a multiple of 64");
   MX_CHECK(d->N % 4 == 0, "gemm: N must be a multiple of 4");
   GemmArgs a;
@@ -257,6 +309,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   a.gate = d->gate; a.ldg = d->ldg; a.out_scale = d->out_scale;
   a.rms_wq = d->rms_wq; a.rms_wk = d->rms_wk; a.rms_eps = d->rms_eps;
   a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum; a.ln_slabs = d->ln_slabs; a.ln_eps = d->ln_eps; a.stats_out = nullptr;
+  a.nseg = d->n_segs; a.mt_total = 0;
+  const bool grouped = d->n_segs > 0;
   if (d->ln_stats) {
     MX_CHECK(!conv && d->ln_colsum && d->ln_slabs > 0, "gemm: folded LayerNorm needs ln_colsum and ln_slabs > 0 (mx_gemm only)");
     MX_CHECK(!(d->flags & MX_EPI_RMSNORM) && d->a_batch_rows <= 0 && d->c_batch_rows <= 0 && !d->a2, "gemm: folded LayerNorm excludes RMSNORM, the row remaps and the split A operand");
@@ -268,7 +322,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   if (!conv && d->a2) {
     MX_CHECK(d->k_split > 0 && d->k_split < d->K && d->k_split % BK == 0, "gemm: k_split must be a multiple of 64 inside (0, K)");
     MX_CHECK(d->lda >= d->k_split && d->lda % 8 == 0 && d->lda2 >= d->K - d->k_split && d->lda2 % 8 == 0, "gemm: bad lda / lda2 for the split A operand");
-    MX_CHECK(d->a_batch_rows <= 0 && ((uintptr_t)d->a2 & 15) == 0 && (long)d->M * d->lda2 < 2147483647L, "gemm: split A operand excludes the row remap and needs 16-byte alignment");
+    MX_CHECK(d->a_batch_rows <= 0 && ((uintptr_t)d->a2 & 15) == 0 && rows_of(d) * d->lda2 < 2147483647L, "gemm: split A operand excludes the row remap and needs 16-byte alignment");
   } else if (!conv) {
     MX_CHECK(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda must be >= K and a multiple of 8");
   } else {
@@ -276,10 +330,12 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(d->stride == 1 || d->stride == 2, "conv3x3: stride must be 1 or 2");
     MX_CHECK(d->up == 0 || d->up == 1, "conv3x3: up must be 0 or 1");
     MX_CHECK(!(d->up && d->stride != 1), "conv3x3: upsample only with stride 1");
-    const int Hv = d->Hin << d->up, Wv = d->Win << d->up;
-    MX_CHECK(d->Hout == (Hv + d->stride - 1) / d->stride && d->Wout == (Wv + d->stride - 1) / d->stride,
-             "conv3x3: output grid does not match input grid / stride");
-    MX_CHECK((long)d->B * d->Hout * d->Wout == d->M, "conv3x3: M != B*Hout*Wout");
+    if (!grouped) {
+      const int Hv = d->Hin << d->up, Wv = d->Win << d->up;
+      MX_CHECK(d->Hout == (Hv + d->stride - 1) / d->stride && d->Wout == (Wv + d->stride - 1) / d->stride,
+               "conv3x3: output grid does not match input grid / stride");
+      MX_CHECK((long)d->B * d->Hout * d->Wout == d->M, "conv3x3: M != B*Hout*Wout");
+    }
     MX_CHECK(2 * d->Cin <= 16384, "conv3x3: Cin > 8192 (the pipelined loader walks a 16 KB zero page for padding taps)");
     MX_CHECK(!(d->flags & MX_EPI_GEGLU), "conv3x3: no GEGLU epilogue");
     MX_CHECK(d->vhalo == 0 || (d->vhalo == 1 && d->corner_patch == 0), "conv3x3: vhalo must be 0 or 1 and excludes the sliced corner rule");
@@ -289,16 +345,17 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     const void* ptrs[] = {d->a, d->w, d->c, d->bias, d->rowbias, d->residual, d->gate, d->rms_wq, d->rms_wk};
     for (const void* q : ptrs) MX_CHECK(((uintptr_t)q & 15) == 0, "gemm: operand pointers must be 16-byte aligned");
   }
-  if (d->rowbias || d->gate || d->a_batch_rows > 0 || d->c_batch_rows > 0 || (d->flags & (MX_EPI_QKV | MX_EPI_RES_BCAST)))
+  if (!grouped && (d->rowbias || d->gate || d->a_batch_rows > 0 || d->c_batch_rows > 0 || (d->flags & (MX_EPI_QKV | MX_EPI_RES_BCAST))))
     MX_CHECK(d->rows_per_batch > 0, "gemm: rows_per_batch required");
   if (d->gate) MX_CHECK(d->ldg >= d->N && d->ldg % 4 == 0, "gemm: bad ldg");
-  if (d->a_batch_rows > 0) MX_CHECK(!conv && d->a_row_off >= 0 && d->a_row_off + d->rows_per_batch <= d->a_batch_rows, "gemm: bad input row remap");
-  if (d->c_batch_rows > 0) MX_CHECK(d->c_row_off >= 0 && d->c_row_off + d->rows_per_batch <= d->c_batch_rows, "gemm: bad output row remap");
+  if (!grouped && d->a_batch_rows > 0) MX_CHECK(!conv && d->a_row_off >= 0 && d->a_row_off + d->rows_per_batch <= d->a_batch_rows, "gemm: bad input row remap");
+  if (!grouped && d->c_batch_rows > 0) MX_CHECK(d->c_row_off >= 0 && d->c_row_off + d->rows_per_batch <= d->c_batch_rows, "gemm: bad output row remap");
   if (d->rowbias) MX_CHECK(d->ldrb >= d->N && d->ldrb % 4 == 0, "gemm: bad ldrb");
-  {
+  if (!grouped) {
     const long in_rows = (!conv && d->a_batch_rows > 0) ? (long)(d->M / d->rows_per_batch + 1) * d->a_batch_rows : d->M;
-    MX_CHECK(in_rows * (conv ? 1 : d->lda) < 2147483647L && (long)d->N * d->K < 2147483647L, "gemm: operand exceeds 32-bit indexing");
+    MX_CHECK(in_rows * (conv ? 1 : d->lda) < 2147483647L, "gemm: operand exceeds 32-bit indexing");
   }
+  MX_CHECK((long)d->N * d->K < 2147483647L, "gemm: operand exceeds 32-bit indexing");
   if (d->residual) MX_CHECK(d->ldr >= d->N && d->ldr % 4 == 0, "gemm: bad ldr");
   const bool use128 = (d->N % 128 == 0);
   const TileChoice tc = pick_tile(d, conv);
@@ -308,14 +365,38 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(((uintptr_t)d->stats_out & 15) == 0, "gemm: stats_out must be 16-byte aligned");
     a.stats_out = d->stats_out;
   }
+  if (grouped) {
+    // the problems' tiles follow each other in the launch's tile list; the kernel argument's own a is the lowest problem base (the 256 x 256
+    // kernel addresses A by 32-bit offsets from it: pick_tile checked the reach)
+    const int rows = tc.rows > 0 ? tc.rows : BM;
+    uintptr_t lo = (uintptr_t)d->segs[0].a;
+    int t0 = 0;
+    for (int i = 0; i < d->n_segs; ++i) {
+      const mx_gemm_seg& g = d->segs[i];
+      GemmSeg& o = a.prob[i];
+      o.a = (const bf16_t*)g.a; o.a2 = conv ? nullptr : (const bf16_t*)g.a2; o.c = g.c; o.residual = (const bf16_t*)g.residual; o.vt = (bf16_t*)g.vt;
+      o.rowbias = g.rowbias; o.gate = g.gate; o.ln_stats = g.ln_stats; o.stats_out = d->stats_out ? g.stats_out : nullptr;
+      o.M = g.M; o.tile0 = t0; o.rows_per_batch = g.rows_per_batch; o.ldvt = g.ldvt;
+      o.B = g.B; o.Hin = g.Hin; o.Win = g.Win; o.Hout = g.Hout; o.Wout = g.Wout;
+      o.a_batch_rows = g.a_batch_rows; o.a_row_off = g.a_row_off; o.c_batch_rows = g.c_batch_rows; o.c_row_off = g.c_row_off;
+      t0 += cdiv(g.M, rows);
+      lo = std::min(lo, (uintptr_t)g.a);
+    }
+    a.mt_total = t0;
+    a.a = (const bf16_t*)lo;
+    a.M = (int)rows_of(d);
+  }
   if (d->flags & MX_EPI_GEGLU) {
     MX_CHECK(use128, "gemm: GEGLU needs N % 128 == 0");
     MX_CHECK(!(d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32)) && !d->residual && !d->rowbias && d->out_scale == 0.f, "gemm: GEGLU excludes other epilogues");
     MX_CHECK(d->ldc >= d->N / 2 && d->ldc % 4 == 0, "gemm: bad ldc for GEGLU");
   } else if (d->flags & MX_EPI_QKV) {
     MX_CHECK(d->seg > 0 && d->seg % 64 == 0 && d->period >= 2 && d->N % (d->seg * d->period) == 0, "gemm: bad QKV segments");
-    MX_CHECK(d->vt != nullptr && d->ldvt >= MX_VT_LD(d->c_batch_rows > 0 ? d->c_batch_rows : d->rows_per_batch), "gemm: QKV needs vt and ldvt >= MX_VT_LD(keys per batch)");
-    MX_CHECK(d->M % d->rows_per_batch == 0, "gemm: QKV needs M % rows_per_batch == 0");
+    MX_CHECK(d->vt != nullptr, "gemm: QKV needs vt");
+    if (!grouped) {
+      MX_CHECK(d->ldvt >= MX_VT_LD(d->c_batch_rows > 0 ? d->c_batch_rows : d->rows_per_batch), "gemm: QKV needs ldvt >= MX_VT_LD(keys per batch)");
+      MX_CHECK(d->M % d->rows_per_batch == 0, "gemm: QKV needs M % rows_per_batch == 0");
+    }
     MX_CHECK(d->ldc >= d->N / d->period * (d->period - 1) && d->ldc % 4 == 0, "gemm: bad ldc for QKV");
     MX_CHECK(!(d->flags & MX_EPI_OUT_F32), "gemm: QKV output is bf16");
     if (d->flags & MX_EPI_RMSNORM)
@@ -328,23 +409,25 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   if (prof_enabled()) {
     // algorithmic work: true (unpadded) contraction; bytes = operands read once + result written once
     const double kk = conv ? 9.0 * d->Cin : (double)d->K;
-    const double flops = 2.0 * d->M * (double)d->N * kk;
-    const double in_elems = conv ? (double)d->B * d->Hin * d->Win * d->Cin : (double)d->M * d->K;
-    const double bytes = 2.0 * (in_elems + (double)d->N * d->K + (double)d->M * d->N);
+    const double Mt = (double)rows_of(d);
+    double in_elems = conv ? (double)d->B * d->Hin * d->Win * d->Cin : Mt * d->K;
+    if (conv && grouped) { in_elems = 0; for (int i = 0; i < d->n_segs; ++i) in_elems += (double)d->segs[i].B * d->segs[i].Hin * d->segs[i].Win * d->Cin; }
+    const double flops = 2.0 * Mt * (double)d->N * kk;
+    const double bytes = 2.0 * (in_elems + (double)d->N * d->K + Mt * d->N);
     const int kind = v2bn == 256 ? PROF_GEMM_V3_256 : v2bn ? (conv ? PROF_CONV_V2_160 : PROF_GEMM_V2_160) + (v2bn == 160 ? 0 : 2) : (conv ? PROF_CONV128 : PROF_GEMM128) + (use128 ? 0 : 1);
-    prof_begin(s, kind, flops, bytes, d->M, d->N, (int)kk);
+    prof_begin(s, kind, flops, bytes, (int)Mt, d->N, (int)kk);
   }
-  static const bool use_v4 = [] { const char* e = getenv("MX_GEMM_V4"); return !(e && e[0] == '0'); }();   // 8-phase ping-pong (gemm_bf16_v4.hip)
+  const int mt128 = grouped ? a.mt_total : cdiv(d->M, BM);      // m-tiles of the generic kernel
   if (v2bn == 256) {
-    if (use_v4) launch_v4(s, a); else launch_v3(s, a);
+    launch_v4(s, a);                                           // 256 x 256 ping-pong (gemm_bf16_v4.hip)
   } else if (v2bn) {
     launch_v2(s, a, conv, v2bn, tc.rows);
   } else if (use128) {
-    dim3 grid(cdiv(d->M, BM), d->N / 128);
+    dim3 grid(mt128, d->N / 128);
     if (conv) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel<128, false>), grid, block, 0, s, a);
   } else {
-    dim3 grid(cdiv(d->M, BM), cdiv(d->N, 64));
+    dim3 grid(mt128, cdiv(d->N, 64));
     if (conv) hipLaunchKernelGGL((gemm_kernel<64, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel<64, false>), grid, block, 0, s, a);
   }
@@ -357,13 +440,13 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
 
 extern "C" int mx_gemm(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, false); }
 extern "C" int mx_gemm_stats_slabs(const mx_gemm_desc* d) {
-  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  if (!d || mx::rows_of(d) <= 0 || d->N <= 0 || d->K <= 0) return 0;
   mx_gemm_desc q = *d;
   if (!q.stats_out) q.stats_out = reinterpret_cast<float*>(16);      // the tile choice of the launch that asks for statistics
   return mx::stats_slabs_of(&q, false, mx::pick_tile(&q, false));
 }
 extern "C" int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d) {
-  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  if (!d || mx::rows_of(d) <= 0 || d->N <= 0 || d->K <= 0) return 0;
   mx_gemm_desc plain = *d;
   plain.ln_stats = nullptr; plain.stats_out = nullptr;
   return mx::pick_tile(&plain, false).bn == 256;

@@ -48,7 +48,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 }
 
 template <int BN, int MI, bool CONV>      // MI: 16-wide token blocks per wave; tile rows BM2 = 64 * MI (256, or 128 for small M)
-__global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
   constexpr int BM2 = 64 * MI;
   constexpr int NI = BN / 32;                 // 16-wide feature blocks per wave (wave covers BN/2 features)
   constexpr int WCH = BN * 8;                 // 16-byte chunks of the W tile
@@ -63,8 +63,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1;
   const int wn = wave & 1;
-  const int mt = (p.M + BM2 - 1) / BM2;
-  const int total_tiles = mt * (p.N / BN);
+  // this workgroup's output tile; in a grouped launch (gemm_args.h) also its problem: p is that problem from here on
+  GemmArgs p = pk;
+  int tm, tn;
+  gemm_tile_of_block(blockIdx.x, gemm_m_tiles(pk, BM2), pk.N / BN, pk.xcd_map, tm, tn);
+  gemm_select_seg(p, pk, tm);
   const int nk = p.K / BK2;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   const int cs = tid & 7;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   //      it.  issue_group() is branch-free so that it shares a basic block with the MFMAs (the scheduler can then place each
   //      LDS-DMA in an MFMA shadow); everything with control flow -- moving to the next K tile, tap or output tile, or off the
   //      end of the stream -- happens in advance_cursor(), after the MFMAs. ----
-  int is_tile = blockIdx.x;     // tile id the cursor is in (>= total_tiles: past the end)
+  bool parked = false;          // the cursor ran past the end of this workgroup's (single) tile
   int is_kt = 0;
   const char* xsrc[XI];         // source of the thread's X chunks for the next group
   long xjump[XI];               // split A operand: extra byte step of the thread's X chunks when K reaches k_split (into the second source)
@@ -106,9 +109,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   };
 
   // per-thread sources of K tile 0 of tile `t` (m fastest: workgroups with equal id mod 8 -- one XCD -- share X panels)
-  auto setup_tile = [&](int t) __attribute__((always_inline)) {
-    int tm, tn;
-    gemm_tile_of_block(t, mt, p.N / BN, p.xcd_map, tm, tn);
+  auto setup_tile = [&]() __attribute__((always_inline)) {
     const int m0 = tm * BM2;
     const int n0 = tn * BN;
 #pragma unroll
@@ -164,10 +165,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   };
   // move the cursor (and the source pointers) to the next K tile of the stream
   auto advance_cursor = [&]() __attribute__((always_inline)) {
-    if (is_tile >= total_tiles) return;       // parked
-    if (++is_kt == nk) {                      // on to this workgroup's next output tile
+    if (parked) return;
+    if (++is_kt == nk) {                      // one tile per workgroup: the rest of the ring slots get harmless bytes
       is_kt = 0;
-      is_tile = total_tiles;                  // one tile per workgroup: the rest of the ring slots get harmless bytes
+      parked = true;
       park_on_zero_page();
       return;
     }
@@ -227,12 +228,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
   constexpr int NM = NI * MI;
   constexpr int NF = NI + MI;
 
-  setup_tile(is_tile);
+  setup_tile();
   issue_next(0);
   issue_next(1);
 
   int stage = 0;   // ring stage of the K tile being computed (stream position modulo 3)
-  const int tile = blockIdx.x;
   {
     f32x4 acc[NI][MI];
 #pragma unroll
@@ -243,11 +243,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) ln_rstd[j] = 1.0f;
     if constexpr (!CONV) {
-      if (p.ln_stats != nullptr) {
-        int tm_, tn_;
-        gemm_tile_of_block(tile, mt, p.N / BN, p.xcd_map, tm_, tn_);
-        gemm_ln_init<NI, MI>(p, acc, tm_ * BM2 + wm * 16 * MI, tn_ * BN + wn * (BN / 2), fr, fq, ln_rstd);
-      }
+      if (p.ln_stats != nullptr) gemm_ln_init<NI, MI>(p, acc, tm * BM2 + wm * 16 * MI, tn * BN + wn * (BN / 2), fr, fq, ln_rstd);
     }
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -302,8 +298,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
       stage = stage == 2 ? 0 : stage + 1;
     }
 
-    int tm, tn;
-    gemm_tile_of_block(tile, mt, p.N / BN, p.xcd_map, tm, tn);
     const int m0 = tm * BM2, n0 = tn * BN;
 #if MX_EXP == 4   // no epilogue: keep the accumulators alive with a store that never executes on real data
     {
@@ -325,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs p) {
 
 // bn: 160 or 128 features per tile; rows: 256, or 128 when the 256-row tiling would leave most CUs idle (small M)
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows) {
-  const int tiles = cdiv(a.M, rows) * (a.N / bn);
+  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, rows)) * (a.N / bn);
   dim3 grid(tiles), block(512);
 #define MX_V2(BN_, MI_) \
   do { \

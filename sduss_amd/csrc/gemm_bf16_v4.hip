@@ -94,7 +94,7 @@ __device__ unsigned long long g_v4_sums[256 * 8 * 16];
 #endif
 
 template <bool VEC>
-__global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   constexpr int NI = 4;                        // 16-wide feature blocks per wave (64 features)
   constexpr int MI = 8;                        // 16-wide token blocks per wave (128 tokens)
   __shared__ __attribute__((aligned(16))) char smem[NSLOT4 * HT_BYTES];
@@ -104,12 +104,12 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2;                    // 0..1: wave row = ping-pong group
   const int wn = wave & 3;                     // 0..3
-  const int mt = (p.M + BM4 - 1) / BM4;
-  const int nt = p.N / BN4;
+  const int mt = gemm_m_tiles(pk, BM4);         // grouped launch (gemm_args.h): the m-tiles of all problems
+  const int nt = pk.N / BN4;
   const int total_tiles = mt * nt;
-  const int nk = p.K / BK4;
-  const char* abase = reinterpret_cast<const char*>(p.a);
-  const char* wbase = reinterpret_cast<const char*>(p.w);
+  const int nk = pk.K / BK4;
+  const char* abase = reinterpret_cast<const char*>(pk.a);   // grouped: the lowest of the problems' bases (launch_v4 checks the 32-bit reach)
+  const char* wbase = reinterpret_cast<const char*>(pk.w);
   const int cs = tid & 7;
 
   // ---- issue side: four cursors, one per half-tile kind (0 XH0, 1 WH0, 2 WH1, 3 XH1 = stream order inside a K tile).  Cursor c
@@ -119,19 +119,32 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
   unsigned c_off[4][2];
   auto setup = [&](const int c, const int t) __attribute__((always_inline)) {
     int tm, tn;
-    gemm_tile_of_block(t, mt, nt, p.xcd_map, tm, tn);
+    gemm_tile_of_block(t, mt, nt, pk.xcd_map, tm, tn);
+    // the X half-tiles belong to the tile's problem: its rows, its base (as a byte offset from abase), its joint-sequence remap
+    int seg_m = pk.M, rpb = pk.rows_per_batch, abr = pk.a_batch_rows, aro = pk.a_row_off;
+    unsigned abyte = 0;
+    if ((c == 0 || c == 3) && pk.nseg > 0) {
+      int sidx = 0;
+#pragma unroll
+      for (int i = 1; i < kMaxSegs; ++i) if (i < pk.nseg && tm >= pk.prob[i].tile0) sidx = i;
+      const GemmSeg& g = pk.prob[sidx];
+      tm -= g.tile0; seg_m = g.M; rpb = g.rows_per_batch; abr = g.a_batch_rows; aro = g.a_row_off;
+      abyte = (unsigned)(reinterpret_cast<const char*>(g.a) - abase);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (i * 512 + tid) >> 3;    // row of the half-tile this thread's chunk belongs to; slot cs holds chunk swz4(row, cs)
       if (c == 0 || c == 3) {                  // XH[q]: rows 64 w + r  <->  token 128 w + 64 q + r of the tile
         const int q = c == 3;
         const int m = tm * BM4 + 128 * (row >> 6) + 64 * q + (row & 63);
-        const int mc = m < p.M ? m : p.M - 1;  // clamped rows are computed and discarded by the epilogue mask
-        c_off[c][i] = (unsigned)((gemm_in_row(p, mc) * p.lda + swz4(row, cs) * 8) * 2);
+        const int mc = m < seg_m ? m : seg_m - 1;  // clamped rows are computed and discarded by the epilogue mask
+        long in_row = mc;
+        if (abr > 0) { const int b = mc / rpb; in_row = (long)b * abr + aro + (mc - b * rpb); }
+        c_off[c][i] = abyte + (unsigned)((in_row * pk.lda + swz4(row, cs) * 8) * 2);
       } else {                                 // WH[h]: rows 32 w + r  <->  feature 64 w + 32 h + r of the tile
         const int h = c == 2;
         const int n = tn * BN4 + 64 * (row >> 5) + 32 * h + (row & 31);
-        c_off[c][i] = (unsigned)(((long)n * p.K + swz4(row, cs) * 8) * 2);
+        c_off[c][i] = (unsigned)(((long)n * pk.K + swz4(row, cs) * 8) * 2);
       }
     }
   };
@@ -308,7 +321,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
     if (wm == 0) MX_BAR();                     // re-align the two wave rows
 
     int tm, tn;
-    gemm_tile_of_block(tile, mt, nt, p.xcd_map, tm, tn);
+    gemm_tile_of_block(tile, mt, nt, pk.xcd_map, tm, tn);
+    GemmArgs p = pk;
+    gemm_select_seg(p, pk, tm);
     const int m0 = tm * BM4, n0 = tn * BN4;
     if (p.flags & MX_EPI_GEGLU) gemm_epilogue_regs<NI, MI, true, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
     else gemm_epilogue_regs<NI, MI, false, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
@@ -324,12 +339,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs p) {
 extern "C" int mx_debug_v4_sums(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v4_sums), sizeof(g_v4_sums)); }
 #endif
 
-static void v4_unused_marker() {}
-
-
 int launch_v4(hipStream_t s, const GemmArgs& a) {
   const int ncu = cu_count();
-  const int tiles = cdiv(a.M, BM4) * (a.N / BN4);
+  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, BM4)) * (a.N / BN4);
   const dim3 grid(tiles > ncu && ncu > 0 ? ncu : tiles), block(512);
   if (a.rowbias || a.gate) hipLaunchKernelGGL(gemm_v4_kernel<true>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(gemm_v4_kernel<false>, grid, block, 0, s, a);

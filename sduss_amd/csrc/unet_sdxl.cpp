@@ -678,7 +678,10 @@ struct Plan {
     };
     auto up_inputs = [&](int n) {
       std::vector<Ten> v{{x, (size_t)h * wd * Ccur}};
-      for (int k = 0; k < n && k < (int)skips.size(); ++k) { const Skip& sk = skips[skips.size() - 1 - k]; v.push_back({sk.t, (size_t)sk.h * sk.wd * sk.C}); }
+      // column order of the reference's feature row: mse(x), then res_hidden_states_tuple[0 .. n-1] = the block's skips OLDEST first, the
+      // first-consumed one last (cache_manager.py:110-121; unet_2d_blocks.py:250-257 takes res_hidden_states_tuple[-1] first)
+      const int have = std::min<int>(n, (int)skips.size());
+      for (int k = 0; k < have; ++k) { const Skip& sk = skips[skips.size() - have + k]; v.push_back({sk.t, (size_t)sk.h * sk.wd * sk.C}); }
       return v;
     };
     int block = 0;

@@ -55,10 +55,51 @@ class GreedyPlacer:
 
 
 def my_share(n_requests: int, rank: int, world: int, resolutions: Sequence[int] = None) -> List[int]:
-    """indices of the requests this rank serves."""
+    """indices of the requests this rank serves under STATIC pixel balancing: greedy_assign over all requests at once, nothing ever
+    finishing (for one resolution: round-robin).  The dynamic placement the reference's dispatcher produces is ``replay_placement``."""
     res = list(resolutions) if resolutions is not None else [1024] * n_requests
     assign = greedy_assign(res, world)
     return [i for i, r in enumerate(assign) if r == rank]
+
+
+def replay_placement(arrivals: Sequence[float], resolutions: Sequence[int], steps: Sequence[int], world: int,
+                     step_seconds: Dict[int, float], max_batch: int) -> List[int]:
+    """dp_rank of every request when the arrival trace is REPLAYED through the reference's dispatcher bookkeeping (GreedyPlacer: add on
+    arrival, finish on completion), so that the outstanding-pixel loads the placement sees fall as requests complete -- what
+    Dispatcher.dispatch / process_worker_outputs do at run time (dispatcher/dispatcher.py:52-118).  Completion times come from a
+    deterministic service model (a replica steps at most `max_batch` requests together, FCFS; a step costs the largest per-resolution
+    `step_seconds` present, every request in it advances one step), so every rank computes the same table without talking to the others:
+    no collective, no rank-0 broadcast.  The model only has to be monotone in load to reproduce the policy's behaviour (least outstanding
+    pixels wins); it does not set any reported latency."""
+    n = len(arrivals)
+    order = sorted(range(n), key=lambda i: arrivals[i])
+    placer = GreedyPlacer(world)
+    out = [0] * n
+    queue = {r: [] for r in range(world)}        # per replica: [request, remaining steps] in arrival order
+    clock = {r: 0.0 for r in range(world)}
+
+    def advance(rank: int, until: float) -> None:
+        q = queue[rank]
+        while q:
+            batch = q[:max_batch]
+            dt = max(step_seconds.get(int(resolutions[i]), max(step_seconds.values())) for i, _ in batch)
+            start = max(clock[rank], arrivals[batch[0][0]])
+            if start + dt > until:
+                break
+            clock[rank] = start + dt
+            for e in batch:
+                e[1] -= 1
+            done = [e[0] for e in q if e[1] <= 0]
+            if done:
+                placer.finish(done)
+                q[:] = [e for e in q if e[1] > 0]
+    for i in order:
+        for r in range(world):
+            advance(r, arrivals[i])
+        rank = placer.add([i], [int(resolutions[i])])[0]
+        out[i] = rank
+        queue[rank].append([i, int(steps[i])])
+    return out
 
 
 def max_over_ranks(value: float, dist=None, device=None) -> float:

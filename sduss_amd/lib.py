@@ -20,6 +20,20 @@ class MxError(RuntimeError):
     cudaGetLastError and went on -- norm_silu_concat.cu:434-437; SURVEY.md section 8b asks to raise)."""
 
 
+MAX_SEGS = 4
+
+
+class GemmSeg(C.Structure):
+    """mx_gemm_seg: one problem of a grouped launch (include/mxdenoise.h)"""
+    _fields_ = [
+        ("a", C.c_void_p), ("a2", C.c_void_p), ("c", C.c_void_p), ("residual", C.c_void_p), ("vt", C.c_void_p), ("rowbias", C.c_void_p),
+        ("gate", C.c_void_p), ("ln_stats", C.c_void_p), ("stats_out", C.c_void_p),
+        ("M", C.c_int), ("rows_per_batch", C.c_int), ("ldvt", C.c_int),
+        ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+        ("a_batch_rows", C.c_int), ("a_row_off", C.c_int), ("c_batch_rows", C.c_int), ("c_row_off", C.c_int),
+    ]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("a", C.c_void_p), ("w", C.c_void_p), ("c", C.c_void_p), ("bias", C.c_void_p), ("rowbias", C.c_void_p),
@@ -33,6 +47,7 @@ class GemmDesc(C.Structure):
         ("a_batch_rows", C.c_int), ("a_row_off", C.c_int), ("c_batch_rows", C.c_int), ("c_row_off", C.c_int),
         ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("vhalo", C.c_int), ("a2", C.c_void_p), ("lda2", C.c_int), ("k_split", C.c_int),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_slabs", C.c_int), ("ln_eps", C.c_float), ("stats_out", C.c_void_p),
+        ("segs", C.POINTER(GemmSeg)), ("n_segs", C.c_int),
     ]
 
 

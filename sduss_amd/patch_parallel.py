@@ -136,6 +136,23 @@ class PatchParallelUNet:
         self.wait_pending()
         self.counter = 0
 
+    def _stale_desc(self, sneed: int, shape_key: tuple, dev, corrected: int):
+        """The state buffer and the mode of this step.  The state's layout (region offsets, bytes per rank) belongs to ONE problem shape: any
+        change of (batch, local rows, width, context length, world) -- even to an equal or smaller footprint -- makes the next step a warm-up
+        on a fresh layout.  In-flight collectives of the previous step are waited for BEFORE the old buffer is dropped.
+        Warm-up length as distrifuser: exchanges stay synchronous while ``counter <= warmup_steps`` (modules/pp/conv2d.py:97, attn.py:136,
+        groupnorm.py:46, distri_sdxl_unet_pp.py:109), i.e. warmup_steps + 1 = 5 synchronous steps at the default of 4."""
+        self.wait_pending()
+        if self._state is None or self._state.numel() < sneed or getattr(self, "_state_key", None) != shape_key:
+            if self._state is None or self._state.numel() < sneed:
+                self._state = None
+                self._state = torch.empty(sneed, dtype=torch.uint8, device=dev)
+            self._state_key = shape_key
+            self.counter = 0                         # nothing to be stale about yet
+        mode = _lib.PP_WARMUP if self.counter <= self.warmup_steps else _lib.PP_STALE
+        self.last_step_mode = mode
+        return _lib.PPStale(self._state.data_ptr(), self._state.numel(), mode, corrected, self._cb_async)
+
     def forward_local(self, latents_local: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                       text_embeds: torch.Tensor, time_ids: torch.Tensor) -> torch.Tensor:
         u = self.unet
@@ -164,14 +181,7 @@ class PatchParallelUNet:
             sneed = u._lib.mx_unet_pp_state_bytes(u._handle, b, hl, w, ctx_len, self.world)
             if sneed == 0:
                 raise _lib.MxError("mx_unet_pp_state_bytes: " + u._lib.mx_last_error().decode())
-            if self._state is None or self._state.numel() < sneed:
-                self._state = torch.empty(sneed, dtype=torch.uint8, device=dev)
-                self.counter = 0                     # nothing to be stale about yet
-            self.wait_pending()
-            stale = _lib.PPStale(self._state.data_ptr(), self._state.numel(),
-                                 _lib.PP_WARMUP if self.counter < self.warmup_steps else _lib.PP_STALE,
-                                 int(self.mode == "corrected_async_gn"), self._cb_async)
-            self.last_step_mode = stale.mode
+            stale = self._stale_desc(sneed, ("unet", b, hl, w, ctx_len, self.world), dev, int(self.mode == "corrected_async_gn"))
             rc = u._lib.mx_unet_forward_pp_stale(u._handle, _lib.current_stream(), x.data_ptr(), _lib.torch_dtype_code(x.dtype), ts.data_ptr(),
                                                  ehs.data_ptr(), te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, hl, w, ctx_len,
                                                  C.byref(comm), C.byref(stale), self._ws.data_ptr(), self._ws.numel())
@@ -222,13 +232,7 @@ class PatchParallelSD3(PatchParallelUNet):
             sneed = u._lib.mx_mmdit_pp_state_bytes(u._handle, b, hl, w, lt, self.world)
             if sneed == 0:
                 raise _lib.MxError("mx_mmdit_pp_state_bytes: " + u._lib.mx_last_error().decode())
-            if self._state is None or self._state.numel() < sneed:
-                self._state = torch.empty(sneed, dtype=torch.uint8, device=dev)
-                self.counter = 0
-            self.wait_pending()
-            stale = _lib.PPStale(self._state.data_ptr(), self._state.numel(),
-                                 _lib.PP_WARMUP if self.counter < self.warmup_steps else _lib.PP_STALE, 0, self._cb_async)
-            self.last_step_mode = stale.mode
+            stale = self._stale_desc(sneed, ("mmdit", b, hl, w, lt, self.world), dev, 0)
             stale_ref = C.byref(stale)
             self.counter += 1
         rc = u._lib.mx_mmdit_forward_pp(u._handle, _lib.current_stream(), x.data_ptr(), _lib.torch_dtype_code(x.dtype), ts.data_ptr(),

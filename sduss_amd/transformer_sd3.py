@@ -93,8 +93,11 @@ class MxSD3Transformer:
             desc = cache.bind(self, b, h, w, batch_key, ctx_len=lt, row_ids=row_ids)
             rc = self._lib.mx_mmdit_forward_cached(self._handle, stream, latents.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
                                                    pp.data_ptr(), out.data_ptr(), b, h, w, lt, ws.data_ptr(), ws.numel(), desc)
-            if rc and cache.error is not None:
-                raise cache.error
+            if rc:
+                err = cache.error
+                cache.invalidate()            # see MxUNet.forward_one_cached: a forward that stopped part-way leaves nothing cached behind
+                if err is not None:
+                    raise err
             _lib.check(rc, "mx_mmdit_forward_cached")
             cache.after_forward()
             return out

@@ -148,8 +148,11 @@ class MxUNet:
         rc = self._lib.mx_unet_forward_cached(self._handle, stream, sample.data_ptr(), _lib.torch_dtype_code(sample.dtype),
                                               ts.data_ptr(), ehs.data_ptr(), te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, h, w,
                                               ctx_len, gn_patch, ws.data_ptr(), ws.numel(), desc)
-        if rc and cache.error is not None:
-            raise cache.error                 # the predictor's own exception, not the library's "predictor failed"
+        if rc:
+            err = cache.error
+            cache.invalidate()                # a forward that stopped part-way stored some blocks' rows and not others: nothing cached survives it
+            if err is not None:
+                raise err                     # the predictor's own exception, not the library's "predictor failed"
         _lib.check(rc, "mx_unet_forward_cached")
         cache.after_forward()
         return out

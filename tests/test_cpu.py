@@ -629,9 +629,12 @@ def test_block_cache_slot_table_follows_the_requests(tiny):
             return np.zeros(len(f))
     bc = BlockSkipCache(Zero(), forced_after=3)
 
-    def bind(ids, hw=16):
+    def bind(ids, hw=16, commit=True):
         bc.bind(Model, len(ids), hw, hw, 0, row_ids=ids)
-        return list(bc._slots_arr), list(bc._valid_arr)
+        out = list(bc._slots_arr), list(bc._valid_arr)
+        if commit:
+            bc.after_forward()                                  # the forward succeeded: the staged request -> row table becomes the table
+        return out
     s1, v1 = bind(["a", "b", "c"])
     assert len(set(s1)) == 3 and v1 == [0, 0, 0] and bc.desc.n_slots == 8
     assert bc.state.numel() == l.mx_unet_block_cache_bytes(h, 8, 16, 16)
@@ -647,7 +650,80 @@ def test_block_cache_slot_table_follows_the_requests(tiny):
     assert v5 == [0, 0] and bc.desc.n_slots == 8
     with pytest.raises(AssertionError):
         bind(["x", "x"])
+    # a forward that fails part-way never reaches after_forward(): the requests it introduced must NOT be valid at the next bind (their rows
+    # were not stored for the later blocks), and because some blocks' rows were overwritten and others not, nothing else survives either
+    s6, v6 = bind(["r0", "r1", "n0"], hw=24)
+    assert v6 == [1, 1, 0]
+    s7, v7 = bind(["r0", "r1", "n0", "n1"], hw=24, commit=False)   # the forward of this bind "fails"
+    assert v7 == [1, 1, 1, 0]
+    s8, v8 = bind(["r0", "n1"], hw=24)
+    assert v8 == [0, 0] and bc.previous == {}
+    s9, v9 = bind(["r0", "n1"], hw=24)
+    assert v9 == [1, 1] and s9 == s8
     # without row ids the descriptor goes back to the batch-composition rule
     bc.bind(Model, 2, 16, 16, 5)
     assert not bc.desc.slots and bc.desc.n_slots == 0 and bc.desc.batch_key == 5
     l.mx_unet_destroy(h)
+
+
+def test_oracle_inventories_equal_the_published_checkpoints():
+    """The wiring pin that needs no weights: the oracle's parameter inventory, built from the HF config values alone, must be the published
+    SDXL-base-1.0 UNet (1 680 tensors, 2 567 463 684 parameters: the "2.6 B UNet" of the SDXL report) and the published SD3.5-medium
+    transformer (909 tensors, 2 469 663 936 parameters: "2.5 B").  A mis-wired block (a missing shortcut conv, a wrong transformer depth,
+    a GEGLU of the wrong width, a dual-attention block too many) changes these numbers."""
+    import math
+    from oracle import sd3_mmdit_ref
+    sh = ref.param_shapes(ref.UNetConfig.sdxl_base())
+    assert len(sh) == 1680 and sum(math.prod(v) for v in sh.values()) == 2_567_463_684
+    sh3 = sd3_mmdit_ref.param_shapes(sd3_mmdit_ref.MMDiTConfig.sd35_medium())
+    assert len(sh3) == 909 and sum(math.prod(v) for v in sh3.values()) == 2_469_663_936
+    # per-family sub-totals of the SDXL UNet (they are what the FLOP split of SURVEY 8d is derived from)
+    conv = sum(math.prod(v) for k, v in sh.items() if len(v) == 4)
+    attn = sum(math.prod(v) for k, v in sh.items() if ".attn1." in k or ".attn2." in k)
+    ff = sum(math.prod(v) for k, v in sh.items() if ".ff.net." in k)
+    assert conv + attn + ff > 0.97 * 2_567_463_684 and ff > attn > 0.2 * ff
+
+
+def test_oracle_chain_batched_steps_equal_each_request_alone(tiny):
+    """oracle/chain_ref.denoising_step on a batch of requests at DIFFERENT step indices with DIFFERENT step counts (continuous batching,
+    scheduling_euler_discrete.py:171-175, 213-217) must give every request exactly what it gets when stepped alone: samples are independent,
+    the per-request sigma / timestep rows are the only coupling and they are per-row."""
+    from oracle import chain_ref
+    cfg, P = tiny
+    g = torch.Generator().manual_seed(3)
+
+    def make(rid, steps, hw):
+        ts, sig, init = scheduler_ref.sdxl_euler_tables(steps)
+        pe, ne = torch.randn(1, 77, cfg.cross_attention_dim, generator=g), torch.randn(1, 77, cfg.cross_attention_dim, generator=g)
+        pp, npp = torch.randn(1, cfg.text_embed_dim, generator=g), torch.randn(1, cfg.text_embed_dim, generator=g)
+        tid = torch.tensor([[hw * 8.0, hw * 8.0, 0.0, 0.0, hw * 8.0, hw * 8.0]])
+        lat = torch.randn(1, cfg.in_channels, hw, hw, generator=g) * init
+        return chain_ref.ChainRequest(rid, hw * 8, steps, lat, (pe, pp, tid), (ne, npp, tid), ts, sig)
+
+    import copy
+    model = lambda x, t, e, te, ti: ref.unet_forward(P, cfg, x, t, e, te, ti)
+    a = [make(0, 6, 16), make(1, 9, 16), make(2, 7, 8)]
+    alone = copy.deepcopy(a)
+    joins = [0, 2, 1]
+    with torch.inference_mode():
+        gstep = 0
+        while not all(r.done() for r in a):
+            act = [r for i, r in enumerate(a) if joins[i] <= gstep and not r.done()]
+            d = {}
+            for r in act:
+                d.setdefault(str(r.resolution), []).append(r)
+            chain_ref.denoising_step(d, model, "sdxl", 5.0, store_dtype=None)
+            gstep += 1
+        for r in alone:
+            while not r.done():
+                chain_ref.denoising_step({str(r.resolution): [r]}, model, "sdxl", 5.0, store_dtype=None)
+    assert gstep == 11                       # request 1 joins at 2 and takes 9 steps
+    for x, y in zip(a, alone):
+        assert x.step_index == y.step_index == x.num_inference_steps
+        assert torch.allclose(x.latents, y.latents, atol=2e-3, rtol=0), (x.latents - y.latents).abs().max()   # fp32 throughout (store_dtype None): batching changes only the summation order inside the BLAS calls
+    # the flow-match tables restated for the chain equal the step mirror's
+    from sduss_amd.pipeline_sd3 import flow_match_tables
+    for n in (20, 28, 50):
+        ts, sig = chain_ref.sd3_flow_tables(n)
+        pts, psig = flow_match_tables(n)
+        assert np.array_equal(ts.numpy(), pts) and np.array_equal(sig.numpy(), psig)

@@ -94,7 +94,7 @@ def _stale_worker(rank, world, port, q):
         want0, want1 = sync.forward(x0, *args), sync.forward(x1, *args)
         res = {}
         for mode in ("stale_gn", "corrected_async_gn"):
-            pp = PatchParallelUNet(net, mode=mode, warmup_steps=1)
+            pp = PatchParallelUNet(net, mode=mode, warmup_steps=0)      # distrifuser: synchronous while counter <= warmup_steps -> one warm-up step
             a = pp.forward(x0, *args)                    # warm-up: synchronous, fills the state
             assert pp.last_step_mode == lib.PP_WARMUP
             b = pp.forward(x0, *args)                    # stale step on unchanged inputs: what it reads stale equals what is fresh
@@ -106,6 +106,15 @@ def _stale_worker(rank, world, port, q):
             nrm = float(want1.float().norm())
             l2 = lambda u, v: float((u.float() - v.float()).norm()) / nrm
             res[mode] = (bool(torch.equal(a, want0)), bool(torch.equal(b, want0)), l2(c, want1), l2(c, want0), l2(d, want1), l2(want1, want0))
+        # warm-up length as distrifuser (modules/pp/conv2d.py:97: `counter <= warmup_steps`): warmup_steps + 1 synchronous steps; and a change of
+        # the problem shape -- even to a smaller footprint -- restarts the warm-up on a fresh state layout instead of reading the old one
+        pp = PatchParallelUNet(net, mode="stale_gn", warmup_steps=1)
+        modes = []
+        for _ in range(3):
+            pp.forward(x0, *args); modes.append(pp.last_step_mode)
+        pp.forward(x0[:1], args[0][:1], args[1][:1], args[2][:1], args[3][:1]); modes.append(pp.last_step_mode)
+        pp.reset()
+        res["modes"] = modes
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -127,7 +136,10 @@ def test_stale_async_steps(cuda_device):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    from sduss_amd import lib
     for rank in range(world):
+        # warmup_steps = 1 -> two synchronous steps, then stale; a new problem shape (batch 1, a smaller footprint) restarts the warm-up
+        assert res[rank].pop("modes") == [lib.PP_WARMUP, lib.PP_WARMUP, lib.PP_STALE, lib.PP_WARMUP]
         for mode, (warm_eq, same_eq, lag, old, settled, moved) in res[rank].items():
             print(f"rank {rank} {mode}: relative L2 of the stale step to the synchronous result {lag:.4f} (to the old output {old:.4f}; the inputs "
                   f"moved the synchronous output by {moved:.4f}); one more step on the same inputs {settled:.4f}")
@@ -163,7 +175,7 @@ def _sd3_worker(rank, world, port, q):
         got1 = sync.forward(x1, *args)
         want0, want1 = net.forward_one(x0, *args), net.forward_one(x1, *args)
         oracle = ref.mmdit_forward(P, ocfg, lat, t, e, p)
-        pp = PatchParallelSD3(net, mode="stale_gn", warmup_steps=1)
+        pp = PatchParallelSD3(net, mode="stale_gn", warmup_steps=0)
         a = pp.forward(x0, *args)
         b = pp.forward(x0, *args)
         assert pp.last_step_mode == lib.PP_STALE
