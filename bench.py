@@ -12,8 +12,12 @@ Extra legs (outside the timed region):
   roofline     one more step with every GEMM/conv/attention launch bracketed by hipEvents on its stream
                (mx_profile_enable): achieved = algorithmic FLOPs / summed launch time of the dominant kernel
   stream       the BASELINE.md section 4 procedure: fixed-prompt Poisson streams at the reference's offered loads
-               (1.0 req/s per GPU x 200 requests, short legs at 0.8 and 1.2), p50 / p90 latency and throughput per load
-  cpu_baseline the CPU oracle (torch fp32, all host cores) timed on ONE UNet sample-forward at 1024^2 = 1/100 image
+               (1.0 req/s per GPU x 120 requests, short legs at 0.8 and 1.2), p50 / p90 latency and throughput per load
+  mixed_stream BASELINE configs[4] shape: a mixed-resolution Poisson stream (512 / 768 / 1024 px, 30-50 steps), continuous batching with
+               the resolutions of a step in ONE launch sequence, the reference's metrics (SLO rate, goodput)
+  sd3          BASELINE configs[2]: SD3.5-medium 1024^2 28-step, the same timed-step protocol, with its own roofline
+  cpu_baseline the CPU oracle (torch fp32, all host cores) timed on ONE UNet sample-forward at 1024^2 = 1/100 image -- on the inputs and
+               weights of one row of the bench's own batch, so the same run also checks that row of the HIP forward (parity_check)
 """
 import argparse
 import ctypes as C
@@ -75,11 +79,11 @@ def parse():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--model", choices=["sdxl", "sd3"], default="sdxl", help="sdxl = BASELINE configs[1] (the headline metric); sd3 = configs[2]")
     ap.add_argument("--sliced", action="store_true", help="is_sliced=True, patch_size=256 (the reference's mixed-policy setting)")
-    ap.add_argument("--stream-requests", type=int, default=200, help="requests per GPU of the main Poisson leg (0 = skip the stream legs)")
+    ap.add_argument("--stream-requests", type=int, default=120, help="requests per GPU of the main Poisson leg (0 = skip the stream legs)")
     ap.add_argument("--stream-rates", type=str, default="1.0,0.8,1.2",
                     help="offered loads in requests/s PER GPU (the reference sweeps {0.8..1.2} x N_gpu req/s, scripts/paper/scalibility.sh:12-13); "
                          "the first is the main leg, the others run stream-requests/5 requests each")
-    ap.add_argument("--mix", type=int, default=0, help="configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
+    ap.add_argument("--mix", type=int, default=None, help="(default: 40 on the default SDXL run, else 0) configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
                                                        "reference traces exp/<model>/qps_*.csv) per offered load of --mix-rates; reports the reference's metrics "
                                                        "(scripts/draw/get_metric.py: SLO rate, average latency, goodput, throughput)")
     ap.add_argument("--mix-rates", type=str, default="1.0,2.0")
@@ -87,7 +91,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the informative timing of the stages either side of the loop (text encoders, VAE decode)")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-sd3", action="store_true", help="skip the SD3.5-medium block (configs[2]) of the default SDXL run")
+    ap.add_argument("--no-parity", action="store_true", help="skip the check of one row of the bench batch against the oracle")
+    a = ap.parse_args()
+    if a.mix is None:
+        a.mix = 40 if (a.model == "sdxl" and a.res == 1024) else 0
+    return a
 
 
 def make_batch(den, cfg, n, res, device, shared, base_id=0):
@@ -101,13 +110,16 @@ def make_batch(den, cfg, n, res, device, shared, base_id=0):
 def run_stream(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world):
     """Fixed-prompt Poisson stream: exponential inter-arrivals at `rate_per_gpu` x world requests/s (numpy
     seed 10086), 100 % 1024^2, 50 steps, continuous batching (FCFS, at most --batch requests per step) on every replica,
-    requests placed by the reference's greedy least-outstanding-pixels dispatcher (dp.GreedyPlacer == greedy.py:16-36).
+    requests placed by replaying the arrivals through the reference's dispatcher bookkeeping (dp.replay_placement: GreedyPlacer add on arrival /
+    finish on completion == greedy.py:16-36 + request_pool.py, with a deterministic service model so that every rank derives the same table
+    without a collective; for one resolution and equal loads this is round-robin, what north_star names).
     Returns this rank's per-request latencies (finish - arrival, entrypoints/wrappers.py:31) and its (first arrival, last finish)."""
     n_total = n_per_gpu * world
     rng = np.random.RandomState(10086)                      # reference seed (arg_utils.py:20)
     arrivals = np.cumsum(rng.exponential(1.0 / (rate_per_gpu * world), size=n_total))
     from sduss_amd import dp
-    mine = [(i, arrivals[i]) for i in dp.my_share(n_total, rank, world, [args.res] * n_total)]
+    place = dp.replay_placement(arrivals, [args.res] * n_total, [STEPS_PER_IMAGE] * n_total, world, STEP_SECONDS[args.model], args.batch)
+    mine = [(i, arrivals[i]) for i in range(n_total) if place[i] == rank]
     pending = make_batch(den, cfg, len(mine), args.res, device, shared, base_id=1000)
     for r, (_i, a) in zip(pending, mine):
         r.arrival = float(a)
@@ -136,13 +148,17 @@ def run_stream(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, wo
 REF_DEADLINES_S = {  # SLO = 5 deadlines of the reference's metric script (scripts/draw/get_metric.py:45-57), seconds
     "sdxl": {512: 16.35, 768: 17.5, 1024: 19.31}, "sd3": {512: 11.0, 768: 18.0, 1024: 30.0}}
 REF_STEP_MIX = ((30, 0.054), (35, 0.178), (40, 0.460), (45, 0.228), (50, 0.080))   # step histogram of exp/sdxl/qps_1.0.csv
+STEP_SECONDS = {  # single-request seconds per step on MI355X (profiles/predictor_{sdxl,sd3}_mi355x.txt): the service model of dp.replay_placement
+    "sdxl": {512: 0.0178, 768: 0.0208, 1024: 0.0271}, "sd3": {512: 0.0111, 768: 0.0179, 1024: 0.0286}}
 
 
 def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world, model):
     """configs[4]: a mixed-resolution Poisson stream with the column shape of the reference traces (arrival ms, resolution, steps;
     tests/server/direct_test.py replays them): resolutions uniform over 512 / 768 / 1024, steps by the traces' histogram, exponential
-    inter-arrivals (numpy seed 10086), placed by the greedy least-outstanding-pixels dispatcher, continuous batching FCFS with
-    at most --mix-max-batch requests per step; a mixed step runs its resolutions as concurrent launch sequences (pipeline.py).
+    inter-arrivals (numpy seed 10086), placed by replaying arrivals and completions through the greedy least-outstanding-pixels dispatcher
+    (dp.replay_placement), continuous batching FCFS with at most --mix-max-batch requests per step, is_sliced=True / patch 256 as the
+    reference's mixed policies force (policy/FCFS_Mixed.py:69-70); the resolutions of a step run in ONE launch sequence (pipeline.py
+    _step_mixed; SD3: concurrent per-resolution sequences).
     Metrics as scripts/draw/get_metric.py computes them (deadlines: its SLO = 5 table, measured on H100 by the reference)."""
     from sduss_amd import dp
     n_total = n_per_gpu * world
@@ -150,7 +166,8 @@ def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world
     arrivals = np.cumsum(rng.exponential(1.0 / (rate_per_gpu * world), size=n_total))
     res_all = rng.choice([512, 768, 1024], size=n_total)
     steps_all = rng.choice([s for s, _ in REF_STEP_MIX], size=n_total, p=[p for _, p in REF_STEP_MIX])
-    mine = dp.my_share(n_total, rank, world, [int(r) for r in res_all])
+    place = dp.replay_placement(arrivals, [int(r) for r in res_all], [int(v) for v in steps_all], world, STEP_SECONDS[model], args.mix_max_batch)
+    mine = [i for i in range(n_total) if place[i] == rank]
     pending = []
     for i in mine:
         if hasattr(cfg, "joint_attention_dim"):
@@ -173,7 +190,7 @@ def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world
         by_res = {}
         for r in active:
             by_res.setdefault(str(r.resolution), []).append(r)
-        den.denoising_step(by_res, is_sliced=args.sliced, patch_size=256)
+        den.denoising_step(by_res, is_sliced=True, patch_size=256)
         torch.cuda.synchronize()
         now = time.perf_counter() - t0
         for r in [r for r in active if r.done()]:
@@ -252,10 +269,12 @@ def time_side_stages(device, batch, step_s):
                     "on the host; NOT included in `value`"}
 
 
-def cpu_baseline(res, model):
+def cpu_baseline(res, model, row=None):
     """The CPU baseline on the host cores: one sample-forward of the denoiser at full width.  Probes for stock diffusers + weights
     first (kind 'diffusers'); on this pool the probe has always come back negative (profiles/r02_probe_env_gpubox.json), so the
-    oracle restatement (kind 'port') is timed."""
+    oracle restatement (kind 'port') is timed.  `row` (SDXL): the weights and the inputs of ONE row of the bench's own step batch --
+    (params fp32 on the CPU, sample, timestep, ehs, text_embeds, time_ids) -- so that the oracle's answer for the row also checks the
+    HIP forward of the headline batch (returned as the second value)."""
     usable, probe_note = probe_diffusers()
     threads = torch.get_num_threads()
     if model == "sd3":
@@ -270,8 +289,11 @@ def cpu_baseline(res, model):
     else:
         from oracle import sdxl_unet_ref as ref
         cfg = ref.UNetConfig.sdxl_base()
-        P = ref.fast_params(cfg)      # timing-equivalent weights without 2.6e9 RNG draws
-        sample, t, ehs, text, tids = ref.make_inputs(cfg, 1, res // 8)
+        if row is not None:
+            P, sample, t, ehs, text, tids = row
+        else:
+            P = ref.fast_params(cfg)      # timing-equivalent weights without 2.6e9 RNG draws
+            sample, t, ehs, text, tids = ref.make_inputs(cfg, 1, res // 8)
         with torch.inference_mode():
             t0 = time.perf_counter()
             out = ref.unet_forward(P, cfg, sample, t, ehs, text, tids)
@@ -279,7 +301,106 @@ def cpu_baseline(res, model):
     assert torch.isfinite(out).all()
     return {"value": 1.0 / (dt * 2 * STEPS_PER_IMAGE), "unit": "images/s", "cores": threads, "kind": "port", "diffusers_probe": probe_note,
             "sample": f"1 {MODELS[model]['name']} sample-forward (batch 1, {res}x{res}, fp32 torch oracle) = 1/{2 * STEPS_PER_IMAGE} image, "
-                      f"{dt:.1f} s on {threads} threads of {os.cpu_count()} host CPUs; extrapolated x{2 * STEPS_PER_IMAGE}"}
+                      f"{dt:.1f} s on {threads} threads of {os.cpu_count()} host CPUs; extrapolated x{2 * STEPS_PER_IMAGE}"}, out
+
+
+def build_model(model, device):
+    """(cfg, net, denoiser, params) with random-init weights of the real architecture (no checkpoint on the box)"""
+    mdl = MODELS[model]
+    if model == "sd3":
+        from sduss_amd.config import MMDiTConfig
+        from sduss_amd.pipeline_sd3 import SD3Denoiser
+        from sduss_amd.transformer_sd3 import MxSD3Transformer
+        from sduss_amd.weights import synthetic_mmdit_params
+        cfg = MMDiTConfig.sd35_medium()
+        P = synthetic_mmdit_params(cfg, device=device)
+        net = MxSD3Transformer(cfg, P, device=device)
+        return cfg, net, SD3Denoiser(net, guidance_scale=mdl["cfg"]), P
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.pipeline import SDXLDenoiser
+    from sduss_amd.unet import MxUNet
+    from sduss_amd.weights import synthetic_params
+    cfg = UNetConfig.sdxl_base()
+    P = synthetic_params(cfg, device=device)
+    net = MxUNet(cfg, P, device=device)
+    return cfg, net, SDXLDenoiser(net, guidance_scale=mdl["cfg"]), P
+
+
+def timed_steps(den, reqs, key, args, dist, device, rehearse):
+    """W untimed warm-up steps, then exactly K steps between two fences (barrier + device synchronise), max over ranks: seconds per step"""
+    from sduss_amd import dp
+
+    def step():
+        den.denoising_step({key: reqs}, is_sliced=args.sliced, patch_size=256)
+        for r in reqs:
+            if r.done():
+                r.step_index = 0        # steady state: keep the batch full
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0, dist, None if rehearse else device)
+    return elapsed / args.steps, step
+
+
+def roofline_leg(step, model):
+    """one more step with every GEMM / conv / attention / norm launch bracketed by hipEvents on its stream; returns (kernels, roofline)"""
+    from sduss_amd import lib
+    l = lib.load()
+    l.mx_profile_enable(1)
+    step()
+    torch.cuda.synchronize()
+    buf = (C.c_double * 64)()
+    lib.check(l.mx_profile_collect(buf), "mx_profile_collect")
+    l.mx_profile_enable(0)
+    kinds = []
+    for k, name in enumerate(KIND_NAMES):
+        n, ms, fl, by = buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]
+        if n > 0:
+            kinds.append({"kernel": name, "launches": int(n), "ms_total": ms, "avg_us": 1e3 * ms / n,
+                          "tflops": fl / (ms * 1e-3) / 1e12 if fl else None, "gbps": by / (ms * 1e-3) / 1e9,
+                          "frac_of_mfma_peak": fl / (ms * 1e-3) / MFMA_PEAK_BF16 if fl else None})
+    roof = None
+    mf = [k for k in kinds if k["tflops"]]
+    if mf:
+        dom = max(mf, key=lambda k: k["ms_total"])
+        traffic, src = pmc_traffic_bytes(dom["kernel"], model)
+        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_BF16 / 1e12,
+                "unit": "TFLOP/s", "frac": dom["tflops"] / (MFMA_PEAK_BF16 / 1e12), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE; separate rocprofv3 --pmc passes over the same step, committed "
+                                "under profiles/: counters cannot be collected inside the timed process)", "traffic_source": src,
+                "algorithmic_bytes_per_launch": dom["gbps"] * 1e9 * dom["avg_us"] * 1e-6,
+                "launches_per_step": dom["launches"], "avg_launch_us": dom["avg_us"]}
+    return kinds, roof
+
+
+def parity_row_inputs(net, reqs, P, guidance_rows=True):
+    """The UNet inputs of the headline batch's first step, assembled exactly as SDXLDenoiser does ([uncond..., cond...]), the HIP forward of
+    the WHOLE batch on them, and the last row's inputs for the oracle (the conditional row of the last request)."""
+    from sduss_amd import ops
+    n = len(reqs)
+    lat = torch.cat([r.latents for r in reqs], dim=0)
+    sig = torch.tensor([float(r.sigmas[0]) for r in reqs], device=lat.device)
+    ts = torch.tensor([float(r.timesteps[0]) for r in reqs], device=lat.device)
+    x = ops.euler_scale_input(lat, sig, 2 * n)
+    ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
+    pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+    tids = torch.cat([t for r in reqs for t in (r.negative_add_time_ids, r.add_time_ids)], dim=0)
+    ts2 = torch.cat([ts, ts])
+    got = net.forward_one(x, ts2, ehs, pooled, tids)
+    k = 2 * n - 1
+    f = lambda t: t[k:k + 1].float().cpu()
+    P32 = {name: v.float().cpu() for name, v in P.items()}
+    return got[k:k + 1].float().cpu(), (P32, f(x), f(ts2).reshape(1), f(ehs), f(pooled), f(tids)), k
 
 
 def main():
@@ -307,93 +428,51 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)   # RCCL; used for the barrier + max-over-ranks only: replicas share nothing
 
-    from sduss_amd import lib
-    if args.model == "sd3":
-        from sduss_amd.config import MMDiTConfig
-        from sduss_amd.pipeline_sd3 import SD3Denoiser
-        from sduss_amd.transformer_sd3 import MxSD3Transformer
-        from sduss_amd.weights import synthetic_mmdit_params
-        cfg = MMDiTConfig.sd35_medium()
-        net = MxSD3Transformer(cfg, synthetic_mmdit_params(cfg, device=device), device=device)
-        den = SD3Denoiser(net, guidance_scale=mdl["cfg"])
-    else:
-        from sduss_amd.config import UNetConfig
-        from sduss_amd.pipeline import SDXLDenoiser
-        from sduss_amd.unet import MxUNet
-        from sduss_amd.weights import synthetic_params
-        cfg = UNetConfig.sdxl_base()
-        net = MxUNet(cfg, synthetic_params(cfg, device=device), device=device)
-        den = SDXLDenoiser(net, guidance_scale=mdl["cfg"])
+    from sduss_amd import dp
+    cfg, net, den, P = build_model(args.model, device)
     shared = {}
     reqs = make_batch(den, cfg, args.batch, args.res, device, shared)
     key = str(args.res)
 
-    def step():
-        den.denoising_step({key: reqs}, is_sliced=args.sliced, patch_size=256)
-        for r in reqs:
-            if r.done():
-                r.step_index = 0        # steady state: keep the batch full
+    # ---- parity of the bench's OWN batch, before anything is timed: the HIP forward of the whole headline batch on its first-step inputs;
+    #      the oracle's answer for one row comes from the cpu_baseline leg below (same run, same weights) ----
+    parity_hip = parity_row = None
+    want_parity = rank == 0 and world == 1 and args.model == "sdxl" and not args.no_parity and not args.no_cpu_baseline
+    if want_parity:
+        parity_hip, parity_row, parity_k = parity_row_inputs(net, reqs, P)
+    del P
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    from sduss_amd import dp
-    elapsed = dp.max_over_ranks(elapsed, dist, None if rehearse else device)
-    step_s = elapsed / args.steps
+    step_s, step = timed_steps(den, reqs, key, args, dist, device, rehearse)
     images_per_s = world * args.batch / (STEPS_PER_IMAGE * step_s)
     finite = all(torch.isfinite(r.latents.float()).all().item() for r in reqs)
 
+    def headline(model, m, res, step_seconds, ips, batch, fin):
+        return {
+            "metric": f"images/sec (node), {'SDXL' if model == 'sdxl' else 'SD3.5-medium'} {res}^2 {m['steps']}-step, fixed prompt, CFG",
+            "value": ips, "unit": "images/s", "ms_per_step": 1e3 * step_seconds,
+            "config": {"workload": f"{m['name']} {res}x{res} {m['steps']}-step {m['sched']}, CFG {m['cfg']}, {batch} requests/step "
+                                   f"(denoiser batch {2 * batch}) per GPU, is_sliced={args.sliced}, random-init weights of the "
+                                   f"real architecture ({m['params']} params), one data-parallel replica per GPU, no collective",
+                       "requests_per_step": batch, "resolution": res, "steps_per_image": m["steps"]},
+            "outputs_finite": fin,
+            "achieved_tflops_whole_step": 2 * batch * m["flop"] / step_seconds / 1e12 if res == 1024 else None,
+            "frac_of_mfma_peak_whole_step": 2 * batch * m["flop"] / step_seconds / MFMA_PEAK_BF16 if res == 1024 else None,
+        }
+    h = headline(args.model, mdl, args.res, step_s, images_per_s, args.batch, finite)
     result = {
-        "metric": f"images/sec (node), {'SDXL' if args.model == 'sdxl' else 'SD3.5-medium'} {args.res}^2 {STEPS_PER_IMAGE}-step, fixed prompt, CFG",
-        "value": images_per_s, "unit": "images/s",
+        "metric": h["metric"], "value": h["value"], "unit": "images/s",
         **({"rehearsal": "MX_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- control-flow check only, the numbers mean nothing"} if rehearse else {}),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{mdl['name']} {args.res}x{args.res} {STEPS_PER_IMAGE}-step {mdl['sched']}, CFG {mdl['cfg']}, {args.batch} requests/step "
-                               f"(denoiser batch {2 * args.batch}) per GPU, is_sliced={args.sliced}, random-init weights of the "
-                               f"real architecture ({mdl['params']} params), one data-parallel replica per GPU, no collective",
-                   "requests_per_step": args.batch, "resolution": args.res, "steps_per_image": STEPS_PER_IMAGE},
-        "outputs_finite": finite,
-        "achieved_tflops_whole_step": 2 * args.batch * mdl["flop"] / step_s / 1e12 if args.res == 1024 else None,
-        "frac_of_mfma_peak_whole_step": 2 * args.batch * mdl["flop"] / step_s / MFMA_PEAK_BF16 if args.res == 1024 else None,
+        "config": h["config"], "outputs_finite": finite,
+        "achieved_tflops_whole_step": h["achieved_tflops_whole_step"], "frac_of_mfma_peak_whole_step": h["frac_of_mfma_peak_whole_step"],
     }
 
     # ---- roofline leg: per-launch hipEvents on the launch stream ----
     if not args.no_roofline and rank == 0:
-        l = lib.load()
-        l.mx_profile_enable(1)
-        step()
-        torch.cuda.synchronize()
-        buf = (C.c_double * 64)()
-        lib.check(l.mx_profile_collect(buf), "mx_profile_collect")
-        l.mx_profile_enable(0)
-        kinds = []
-        for k, name in enumerate(KIND_NAMES):
-            n, ms, fl, by = buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]
-            if n > 0:
-                kinds.append({"kernel": name, "launches": int(n), "ms_total": ms, "avg_us": 1e3 * ms / n,
-                              "tflops": fl / (ms * 1e-3) / 1e12 if fl else None, "gbps": by / (ms * 1e-3) / 1e9,
-                              "frac_of_mfma_peak": fl / (ms * 1e-3) / MFMA_PEAK_BF16 if fl else None})
-        result["kernels"] = kinds
-        mf = [k for k in kinds if k["tflops"]]
-        if mf:
-            dom = max(mf, key=lambda k: k["ms_total"])
-            traffic, src = pmc_traffic_bytes(dom["kernel"], args.model)
-            result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_BF16 / 1e12,
-                                  "unit": "TFLOP/s", "frac": dom["tflops"] / (MFMA_PEAK_BF16 / 1e12), "traffic": traffic,
-                                  "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": src,
-                                  "algorithmic_bytes_per_launch": dom["gbps"] * 1e9 * dom["avg_us"] * 1e-6,
-                                  "launches_per_step": dom["launches"], "avg_launch_us": dom["avg_us"]}
+        result["kernels"], roof = roofline_leg(step, args.model)
+        if roof:
+            result["roofline"] = roof
     if dist is not None:
         dist.barrier()
 
@@ -412,8 +491,9 @@ def main():
             if dist is not None:
                 dist.barrier()
         if rank == 0:
-            result["stream"] = {"legs": legs, "arrivals": "exponential inter-arrival, numpy seed 10086, 100% 1024^2 50-step, continuous batching "
-                                                           f"(<= {args.batch} requests/step), greedy least-outstanding-pixels placement over replicas",
+            result["stream"] = {"legs": legs, "arrivals": f"exponential inter-arrival, numpy seed 10086, 100% {args.res}^2 {STEPS_PER_IMAGE}-step, continuous batching "
+                                                           f"(<= {args.batch} requests/step), placement: arrivals and completions replayed through the greedy "
+                                                           "least-outstanding-pixels dispatcher (round-robin at one resolution)",
                                 "latency": "finish - arrival per request; throughput = requests / (last finish - first arrival)"}
             result["p50_latency_s"] = legs[0]["p50_latency_s"]
             result["p90_latency_s"] = legs[0]["p90_latency_s"]
@@ -440,18 +520,54 @@ def main():
         if rank == 0:
             result["mixed_stream"] = {"legs": legs, "trace": "synthetic, shape of exp/<model>/qps_*.csv: resolutions uniform over 512/768/1024, steps 30-50 by the "
                                                               "traces' histogram, exponential arrivals seed 10086", "deadlines_s": REF_DEADLINES_S[args.model],
-                                      "max_batch": args.mix_max_batch, "policy": "FCFS mixed batching; resolutions of a step run as concurrent launch sequences"}
+                                      "max_batch": args.mix_max_batch, "is_sliced": True, "patch_size": 256,
+                                      "policy": "FCFS mixed batching (policy/FCFS_Mixed.py); the resolutions of a step run in ONE launch sequence "
+                                                "(grouped launches)" if args.model == "sdxl" else "FCFS mixed batching; resolutions of a step as concurrent launch sequences"}
 
     # ---- informative: the stages either side of the denoising loop (not part of `value`, which is the loop as BASELINE.json defines it) ----
-    if rank == 0 and not args.no_stages and not args.no_roofline and args.model == "sdxl" and args.res == 1024:
+    if rank == 0 and not args.no_stages and args.model == "sdxl" and args.res == 1024:
         try:
             result["stages_either_side"] = time_side_stages(device, args.batch, step_s)
         except Exception as e:                                  # never fatal for the headline line
             result["stages_either_side"] = {"error": f"{type(e).__name__}: {e}"}
 
-    # ---- CPU baseline leg ----
+    # ---- configs[2]: SD3.5-medium 1024^2 28-step on this GPU, the same timed-step protocol (rank 0 of a one-GPU run only) ----
+    if rank == 0 and world == 1 and args.model == "sdxl" and args.res == 1024 and not args.no_sd3:
+        try:
+            del step, den, net, reqs
+            torch.cuda.empty_cache()
+            m3 = MODELS["sd3"]
+            STEPS_PER_IMAGE = m3["steps"]
+            cfg3, net3, den3, P3 = build_model("sd3", device)
+            del P3
+            reqs3 = make_batch(den3, cfg3, args.batch, 1024, device, {})
+            s3, step3 = timed_steps(den3, reqs3, "1024", args, None, device, False)
+            fin3 = all(torch.isfinite(r.latents.float()).all().item() for r in reqs3)
+            blk = headline("sd3", m3, 1024, s3, args.batch / (m3["steps"] * s3), args.batch, fin3)
+            blk.update({"steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "data": "synthetic", "n_gpus": 1})
+            if not args.no_roofline:
+                blk["kernels"], roof3 = roofline_leg(step3, "sd3")
+                if roof3:
+                    blk["roofline"] = roof3
+            result["sd3"] = blk
+            del step3, den3, net3, reqs3
+            torch.cuda.empty_cache()
+        except Exception as e:                                  # never fatal for the headline line
+            result["sd3"] = {"error": f"{type(e).__name__}: {e}"}
+        STEPS_PER_IMAGE = mdl["steps"]
+
+    # ---- CPU baseline leg (+ the parity check of the headline batch's row) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.res, args.model)
+        result["cpu_baseline"], want = cpu_baseline(args.res, args.model, parity_row)
+        if parity_row is not None:
+            err = (parity_hip - want)
+            l2 = float(err.norm() / want.norm())
+            mx = float(err.abs().max() / want.abs().max())
+            result["parity_check"] = {"what": f"row {parity_k} (conditional row of the last request) of the HIP forward of the bench's own batch of "
+                                              f"{2 * args.batch} at its first step vs the fp32 oracle on the same weights and inputs",
+                                      "rel_l2": l2, "max_err_frac_of_range": mx, "bound_rel_l2": 0.03, "bound_max": 0.05, "ok": bool(l2 <= 0.03 and mx <= 0.05)}
+            if not result["parity_check"]["ok"]:
+                raise SystemExit(f"bench.py: parity check of the headline batch failed: {result['parity_check']}")
 
     if rank == 0:
         print(json.dumps(result))

@@ -215,6 +215,15 @@ int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, c
 #define MX_ATTN_QSCALE(scale) ((scale) * 1.4426950408889634f)
 int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk);
+/* Grouped form: the attention problems of all resolutions present in a mixed batch in ONE launch (see mx_gemm_seg).  The problems share the row
+ * strides and the head count; each has its own batch, sequence lengths and operand bases.  One kernel serves the whole launch (chosen by the
+ * longest query sequence); the arithmetic per problem is that of mx_attention_prescaled with the same kernel. */
+typedef struct mx_attn_problem {
+  const void* q; const void* k; const void* vt; void* o;
+  int64_t vt_batch_stride;
+  int B, Lq, Lk, ldvt;
+} mx_attn_problem;
+int mx_attention_prescaled_grouped(void* stream, const mx_attn_problem* probs, int n, int ldq, int ldk, int ldo, int H);
 /* softmax(q k^T + bias[h]) v: q and the fp32 bias [H][Lq][ldb] both already multiplied by log2(e) (T5: no 1/sqrt(d) scaling, bucketed relative
  * position bias shared by all layers); ldb % 4 == 0, ldb >= Lk rounded up to 64 */
 int mx_attention_prescaled_bias(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
@@ -255,6 +264,13 @@ int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const float* gamma, 
  * norm1 (unet_2d_blocks.py via unet.py:458-462) without materialising the concatenation.  x2 == NULL: mx_groupnorm_nhwc. */
 int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const void* x2, void* y, const float* gamma, const float* beta,
                           int B, int H, int W, int C, int groups, float eps, int silu, int patch, void* workspace);
+
+/* Grouped form (see mx_gemm_seg): the GroupNorms of all resolutions present in a mixed batch as ONE stats / fold / apply launch each.  x2 as in
+ * mx_groupnorm_nhwc_cat (all problems or none); workspace >= mx_groupnorm_nhwc_grouped_workspace_bytes(probs, n, C). */
+typedef struct mx_gn_problem { const void* x; const void* x2; void* y; int B, H, W; } mx_gn_problem;
+size_t mx_groupnorm_nhwc_grouped_workspace_bytes(const mx_gn_problem* probs, int n, int C);
+int mx_groupnorm_nhwc_grouped(void* stream, const mx_gn_problem* probs, int n, int C1, const float* gamma, const float* beta, int C, int groups,
+                              float eps, int silu, int patch, void* workspace);
 
 /* ------------------------------------------------------------------------------------------
  * Outer boundary: the SDXL UNet in the model slot.
@@ -304,6 +320,23 @@ int mx_unet_validate(const mx_unet* u, int batch, int H, int W, int ctx_len);
 int mx_unet_forward(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
                     const void* ehs, const void* text_embeds, const float* time_ids, void* out,
                     int batch, int H, int W, int ctx_len, int gn_patch, void* workspace, size_t workspace_bytes);
+/* Mixed-resolution batch (BASELINE configs[4]): the requests of EVERY resolution present run through ONE launch sequence --
+ * what the reference obtains by cutting the latents of all resolutions into one batch of 256-px patches (modules/unet.py:104-185, split_sample)
+ * and regrouping per latent before attention (attention.py:152-203).  Here nothing is cut: a group = the samples of one resolution, the
+ * activations of a level are the groups' images one after the other, per-token ops are single launches over all rows and the ops with per-image
+ * structure are grouped launches (mx_gemm_seg, mx_attention_prescaled_grouped, mx_groupnorm_nhwc_grouped).  The conditioning rows (timesteps, ehs,
+ * text_embeds, time_ids) are those of all groups concatenated in group order -- the reference's row order, ascending resolution
+ * (pipeline_stable_diffusion_xl_esymred.py:275-276).  Per request the arithmetic is that of mx_unet_forward on its group alone up to the tile
+ * shapes a larger launch selects and the grouping of the fp32 partial sums of the GroupNorm / LayerNorm statistics. */
+typedef struct mx_unet_group { const void* latents; void* out; int batch, H, W; } mx_unet_group;   /* [batch, C, H, W] of io_dtype each */
+size_t mx_unet_workspace_bytes_mixed(const mx_unet* u, const mx_unet_group* groups, int n_groups, int ctx_len);
+int mx_unet_forward_mixed(mx_unet* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                          const void* ehs, const void* text_embeds, const float* time_ids, int ctx_len, int gn_patch, void* workspace,
+                          size_t workspace_bytes);
+/* the same with a stage dump (tests): the NHWC bf16 activation of all groups after `stage`, [sum of the groups' pixels, C] */
+int mx_unet_forward_mixed_trace(mx_unet* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                                const void* ehs, const void* text_embeds, const float* time_ids, int ctx_len, int gn_patch, void* workspace,
+                                size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes);
 /* debugging / parity: copy of the NHWC bf16 activation after the named stage of the LAST forward
  * is not kept; instead a forward can be asked to stop after `stage` and dump it (tests only). */
 int mx_unet_forward_trace(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,

@@ -28,6 +28,7 @@
 //     that tile, O and l are rescaled -- exact, softmax is invariant to the reference; p <= 256 and l >= 1 always hold).
 //     Per 64-key tile and lane this removes 32 v_fma, the alpha exp2 and 16 v_pk_mul for two extra MFMAs on a matrix pipe
 //     that was 41 % busy while the vector ALU was 72 % busy (rocprofv3 SQ_ACTIVE_INST_VALU).
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef MX_AEXP
@@ -55,6 +56,40 @@ struct AttnArgs {
   int ldb;
 };
 
+// Grouped launch (mx_attention_prescaled_grouped): up to MX_MAX_SEGS problems -- the resolutions of a mixed batch, each with its own
+// sequence lengths, batch and operand bases -- in ONE launch.  A workgroup finds its problem from its index with two compares and runs the
+// ordinary kernel body on it: `p` is a wave-uniform reference into the kernel-argument segment (scalar loads).  n == 1: an ordinary launch.
+struct AttnGroup {
+  AttnArgs g[MX_MAX_SEGS];
+  int blk0[MX_MAX_SEGS + 1];           // first workgroup of every problem
+  int n;
+};
+
+// workgroup -> (problem, query block, batch * H + head); ROWS = query rows per workgroup.  Consecutive workgroup ids are dealt round-robin to
+// the 8 XCDs (one L2 each): with the plain order (query block fastest) the query blocks of one head land on all 8 XCDs and each L2 fetches that
+// head's K / V^T (rocprofv3 FETCH_SIZE: 4.4x the algorithmic bytes at Lk = 4429).  When the number of (batch, head) pairs of a problem is a
+// multiple of 8, XCD x instead owns the pairs == x (mod 8) and walks their query blocks consecutively (its workgroup count is then a multiple
+// of 8 as well, so the next problem starts on XCD 0 again).
+template <int ROWS>
+__device__ __forceinline__ const AttnArgs& attn_locate(const AttnGroup& ga, int& qb, int& bh) {
+  int lin = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < MX_MAX_SEGS; ++i) if (i < ga.n && lin >= ga.blk0[i]) s = i;
+  const AttnArgs& p = ga.g[s];
+  lin -= ga.blk0[s];
+  const int gx = (p.Lq + ROWS - 1) / ROWS;
+  if (p.xcd_map) {
+    const int local = lin >> 3;
+    qb = local % gx;
+    bh = ((local / gx) << 3) + (lin & 7);
+  } else {
+    qb = lin % gx;
+    bh = lin / gx;
+  }
+  return p;
+}
+
 constexpr int KT = 64;                 // keys per tile
 constexpr int kBufBytes = 16384;       // one ring buffer: K tile (8 KB) then V^T tile (8 KB)
 
@@ -75,7 +110,7 @@ __device__ __forceinline__ float max_across_halves(float x) {
 // EXTRA: the additive-bias and causal-mask forms of the text encoders, a separate instantiation (as run-time branches they cost the
 // 60 cross-attention launches of a UNet step 3.4 us each: profiles r02_f vs r02_g)
 template <bool PRE, bool EXTRA = false>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnGroup ga) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes];
 
   const int tid = threadIdx.x;
@@ -87,13 +122,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   // with the plain x-fastest order the query blocks of one head land on all 8 XCDs and each L2 fetches that head's K / V^T
   // (rocprofv3 FETCH_SIZE: 4.4x the algorithmic bytes at Lk = 4429).  When the number of (batch, head) pairs is a multiple
   // of 8, XCD x instead owns the pairs == x (mod 8) and walks their query blocks consecutively.
-  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
-  if (p.xcd_map) {
-    const int lin = blockIdx.x + gridDim.x * bh;
-    const int local = lin >> 3;
-    qb = local % (int)gridDim.x;
-    bh = ((local / (int)gridDim.x) << 3) + (lin & 7);
-  }
+  int qb, bh;
+  const AttnArgs& p = attn_locate<128>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
   const int head = bh % p.H;
   const int b = bh / p.H;
   const int q0 = qb * 128 + wave * 32;
@@ -380,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 // s_barrier per tile.  The compute body is attn_fwd_kernel's.
 // ----------------------------------------------------------------------------------------------------------------------
 template <bool PRE>
-__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnGroup ga) {
   #if (MX_AEXP & 32)
   __shared__ __attribute__((aligned(16))) char smem[3 * kBufBytes + 40 * 1024];
 #elif (MX_AEXP & 64)
@@ -398,13 +428,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
   // with the plain x-fastest order the query blocks of one head land on all 8 XCDs and each L2 fetches that head's K / V^T
   // (rocprofv3 FETCH_SIZE: 4.4x the algorithmic bytes at Lk = 4429).  When the number of (batch, head) pairs is a multiple
   // of 8, XCD x instead owns the pairs == x (mod 8) and walks their query blocks consecutively.
-  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
-  if (p.xcd_map) {
-    const int lin = blockIdx.x + gridDim.x * bh;
-    const int local = lin >> 3;
-    qb = local % (int)gridDim.x;
-    bh = ((local / (int)gridDim.x) << 3) + (lin & 7);
-  }
+  int qb, bh;
+  const AttnArgs& p = attn_locate<128>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
   const int head = bh % p.H;
   const int b = bh / p.H;
   const int q0 = qb * 128 + wave * 32;
@@ -704,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnArgs p) 
 // softmax in ONE instruction stream (sched_group_barrier pins the interleave).  A workgroup = 4 waves = 256 query rows, two
 // workgroups per CU; O leaves through the (idle) K / V^T ring as whole 128-byte rows.
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnGroup ga) {
   __shared__ __attribute__((aligned(16))) char smem[3 * kBufBytes];
 
   const int tid = threadIdx.x;
@@ -712,13 +737,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
   const int wave = tid >> 6;
   const int r = lane & 31;   // query column owned by this lane (and fragment row)
   const int hh = lane >> 5;  // half-wave
-  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
-  if (p.xcd_map) {                             // XCD x owns the (batch, head) pairs == x (mod 8) (see attn_fwd_kernel)
-    const int lin = blockIdx.x + gridDim.x * bh;
-    const int local = lin >> 3;
-    qb = local % (int)gridDim.x;
-    bh = ((local / (int)gridDim.x) << 3) + (lin & 7);
-  }
+  int qb, bh;
+  const AttnArgs& p = attn_locate<256>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
   const int head = bh % p.H;
   const int b = bh / p.H;
   const int q0 = qb * 256 + wave * 64;
@@ -1016,20 +1036,15 @@ constexpr int XK_MAXBLK = 3;                   // 32-key blocks (Lk <= 96)
 constexpr int XK_QPW = 64;                     // queries per wave (two 32-query blocks)
 
 template <bool PRE>
-__global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnGroup ga) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 4096];       // one 32 x 64 bf16 patch per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int r = lane & 31;
   const int hh = lane >> 5;
-  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
-  if (p.xcd_map) {                             // XCD x owns the (batch, head) pairs == x (mod 8): their K / V^T stay in one L2
-    const int lin = blockIdx.x + gridDim.x * bh;
-    const int local = lin >> 3;
-    qb = local % (int)gridDim.x;
-    bh = ((local / (int)gridDim.x) << 3) + (lin & 7);
-  }
+  int qb, bh;
+  const AttnArgs& p = attn_locate<4 * XK_QPW>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
   const int head = bh % p.H;
   const int b = bh / p.H;
   const int nblk = (p.Lk + 31) >> 5;           // <= XK_MAXBLK (launcher)
@@ -1166,10 +1181,10 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnArgs p) {
 
 }  // namespace mx
 
-static int launch_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
-                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale, bool pre,
-                            int key_chunk = 0, int64_t k_bstride = 0, int64_t k_cstride = 0, int64_t vt_cstride = 0, bool causal = false,
-                            const float* bias = nullptr, int ldb = 0) {
+// validate one problem and fill its argument block
+static int fill_attention_args(mx::AttnArgs& a, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int64_t vt_batch_stride, void* o,
+                               int ldo, int B, int H, int Lq, int Lk, float scale, bool pre, int key_chunk, int64_t k_bstride, int64_t k_cstride,
+                               int64_t vt_cstride, bool causal, const float* bias, int ldb) {
   using namespace mx;
   MX_CHECK(q && k && vt && o, "attention: null operand");
   MX_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attention: empty problem");
@@ -1183,7 +1198,6 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
     MX_CHECK(ldvt >= MX_VT_LD(Lk), "attention: ldvt must cover MX_VT_LD(Lk) (keys are stored in MX_VT_POS order)");
   }
   MX_CHECK(vt_batch_stride % 8 == 0 && vt_batch_stride >= (int64_t)H * 64 * ldvt, "attention: bad vt_batch_stride");
-  AttnArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.o = (bf16_t*)o;
   a.vt_bstride = (long)vt_batch_stride;
   a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
@@ -1194,38 +1208,88 @@ static int launch_attention(void* stream, const void* q, int ldq, const void* k,
                      "attention: bias form needs prescaled q, ldb a multiple of 4 covering whole 64-key tiles, 16-byte alignment");
   if (causal) MX_CHECK(Lq == Lk && key_chunk == 0 && Lk <= 4096, "attention: causal form is for Lq == Lk <= 4096, one key range");
   a.key_chunk = key_chunk; a.k_bstride = key_chunk > 0 ? (long)k_bstride : (long)Lk * ldk; a.k_cstride = (long)k_cstride; a.vt_cstride = (long)vt_cstride;
-  static const int xcd_env = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
-  a.xcd_map = (xcd_env && ((B * H) % 8 == 0)) ? 1 : 0;
-  static const bool cross_off = [] { const char* e = getenv("MX_ATTN_CROSS"); return e && e[0] == '0'; }();
-  if (Lk <= 32 * XK_MAXBLK && Lq >= 2048 && !cross_off && key_chunk == 0 && !causal && !bias) {   // (at Lq 1024 the general kernel is 7 % faster: both are latency-bound)    // short key sequence: every wave keeps K / V^T in registers (attn_cross_kernel)
-    MX_CHECK(ldo % 8 == 0, "attention: ldo must be a multiple of 8 elements");
-    dim3 xgrid(cdiv(Lq, 4 * XK_QPW), H, B);
-    prof_begin((hipStream_t)stream, PROF_ATTN_CROSS, 4.0 * B * H * (double)Lq * Lk * 64.0, 2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
-    if (pre) hipLaunchKernelGGL(attn_cross_kernel<true>, xgrid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_cross_kernel<false>, xgrid, dim3(256), 0, (hipStream_t)stream, a);
-    prof_end((hipStream_t)stream);
-    MX_LAUNCH_CHECK();
-    return 0;
+  a.xcd_map = ((B * H) % 8 == 0) ? 1 : 0;
+  return 0;
+}
+
+// One launch over ga.n problems (ga.g filled).  The kernel is chosen for the launch as a whole -- by its longest query sequence -- and must
+// be able to serve every problem; otherwise the general register-staged kernel takes them all.
+static int launch_attention_group(void* stream, mx::AttnGroup& ga, bool pre) {
+  using namespace mx;
+  const int n = ga.n;
+  int maxLq = 0;
+  bool all_short = true, all_long_k = true, whole_tiles = true, plain = true, o8 = true;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    const AttnArgs& a = ga.g[i];
+    maxLq = std::max(maxLq, a.Lq);
+    all_short = all_short && a.Lk <= 32 * XK_MAXBLK;
+    all_long_k = all_long_k && a.Lk > 2 * KT;
+    whole_tiles = whole_tiles && a.Lk % KT == 0 && a.Lk >= 3 * KT;
+    plain = plain && a.key_chunk == 0 && !a.causal && !a.bias;
+    o8 = o8 && a.ldo % 8 == 0;
+    flops += 4.0 * a.B * a.H * (double)a.Lq * a.Lk * 64.0;
+    bytes += 2.0 * a.B * a.H * 64.0 * (2.0 * a.Lq + 2.0 * a.Lk);
   }
-  dim3 grid(cdiv(Lq, 128), H, B);
-  prof_begin((hipStream_t)stream, PROF_ATTN, 4.0 * B * H * (double)Lq * Lk * 64.0,
-             2.0 * B * H * 64.0 * (2.0 * Lq + 2.0 * Lk), B * H, Lq, Lk);
-  static const bool dma_off = [] { const char* e = getenv("MX_ATTN_DMA"); return e && e[0] == '0'; }();
-  static const int w64_min = [] { const char* e = getenv("MX_ATTN_W64_MIN_LQ"); return e ? atoi(e) : 2048; }();   // (a tie with the 32-row kernels at Lq 1024)
-  if (causal || bias) {                                // the masked / biased forms live in the register-staged kernel
-    if (pre) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  } else if (pre && Lk > 2 * KT && !dma_off && Lq >= w64_min && ldo % 8 == 0) {   // 64 query rows per wave
-    dim3 grid64(cdiv(Lq, 256), H, B);
-    hipLaunchKernelGGL(attn_fwd64_kernel, grid64, dim3(256), 0, (hipStream_t)stream, a);
-  } else if (Lk % KT == 0 && Lk >= 3 * KT && !dma_off) {      // whole tiles: LDS-DMA staging two tiles ahead
-    if (pre) hipLaunchKernelGGL(attn_fwd_dma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd_dma_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  } else if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  prof_end((hipStream_t)stream);
+  bool extra = false;
+  for (int i = 0; i < n; ++i) extra = extra || ga.g[i].causal || ga.g[i].bias;
+  MX_CHECK(!extra || n == 1, "attention: the causal / bias forms are not grouped");
+  // (at Lq 1024 the general kernel is 7 % faster than the short-key one: both are latency-bound)
+  enum { K_GENERAL, K_CROSS, K_W64, K_DMA } kind = K_GENERAL;
+  if (all_short && maxLq >= 2048 && plain && o8) kind = K_CROSS;          // short key sequence: every wave keeps K / V^T in registers
+  else if (extra) kind = K_GENERAL;                                       // the masked / biased forms live in the register-staged kernel
+  else if (pre && all_long_k && maxLq >= 2048 && o8) kind = K_W64;        // 64 query rows per wave (a tie with the 32-row kernels at Lq 1024)
+  else if (whole_tiles) kind = K_DMA;                                     // whole tiles: LDS-DMA staging two tiles ahead
+  const int rows = kind == K_CROSS ? 4 * XK_QPW : kind == K_W64 ? 256 : 128;
+  long blocks = 0;
+  for (int i = 0; i < n; ++i) { ga.blk0[i] = (int)blocks; blocks += (long)cdiv(ga.g[i].Lq, rows) * ga.g[i].H * ga.g[i].B; }
+  for (int i = n; i <= MX_MAX_SEGS; ++i) ga.blk0[i] = (int)blocks;
+  MX_CHECK(blocks < 2147483647L, "attention: too many workgroups");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)blocks), block(256);
+  const AttnArgs& a0 = ga.g[0];
+  prof_begin(st, kind == K_CROSS ? PROF_ATTN_CROSS : PROF_ATTN, flops, bytes, n == 1 ? a0.B * a0.H : n, maxLq, a0.Lk);
+  switch (kind) {
+    case K_CROSS:
+      if (pre) hipLaunchKernelGGL(attn_cross_kernel<true>, grid, block, 0, st, ga); else hipLaunchKernelGGL(attn_cross_kernel<false>, grid, block, 0, st, ga);
+      break;
+    case K_W64: hipLaunchKernelGGL(attn_fwd64_kernel, grid, block, 0, st, ga); break;
+    case K_DMA:
+      if (pre) hipLaunchKernelGGL(attn_fwd_dma_kernel<true>, grid, block, 0, st, ga); else hipLaunchKernelGGL(attn_fwd_dma_kernel<false>, grid, block, 0, st, ga);
+      break;
+    default:
+      if (extra) { if (pre) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, block, 0, st, ga); else hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, 0, st, ga); }
+      else if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, st, ga);
+      else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, st, ga);
+  }
+  prof_end(st);
   MX_LAUNCH_CHECK();
   return 0;
+}
+
+static int launch_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk, float scale, bool pre,
+                            int key_chunk = 0, int64_t k_bstride = 0, int64_t k_cstride = 0, int64_t vt_cstride = 0, bool causal = false,
+                            const float* bias = nullptr, int ldb = 0) {
+  mx::AttnGroup ga;
+  ga.n = 1;
+  if (fill_attention_args(ga.g[0], q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, scale, pre, key_chunk, k_bstride, k_cstride, vt_cstride,
+                          causal, bias, ldb)) return 1;
+  return launch_attention_group(stream, ga, pre);
+}
+
+/* Grouped form of mx_attention_prescaled: the problems of all resolutions of a mixed batch in ONE launch (the reference regroups the patches of
+ * every latent per resolution and calls the attention once per resolution: modules/attention.py:152-203). */
+extern "C" int mx_attention_prescaled_grouped(void* stream, const mx_attn_problem* probs, int n, int ldq, int ldk, int ldo, int H) {
+  MX_CHECK(probs != nullptr && n >= 1 && n <= MX_MAX_SEGS, "attention: grouped launch needs 1..MX_MAX_SEGS problems");
+  mx::AttnGroup ga;
+  ga.n = n;
+  for (int i = 0; i < n; ++i) {
+    const mx_attn_problem& p = probs[i];
+    if (fill_attention_args(ga.g[i], p.q, ldq, p.k, ldk, p.vt, p.ldvt, p.vt_batch_stride, p.o, ldo, p.B, H, p.Lq, p.Lk, 1.0f, true, 0, 0, 0, 0, false, nullptr, 0))
+      return 1;
+  }
+  return launch_attention_group(stream, ga, true);
 }
 
 extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,

@@ -38,7 +38,12 @@ constexpr int kZeroPageBytes = 16384;
 __device__ __attribute__((aligned(64))) unsigned int g_zero_page[kZeroPageBytes / 4] = {0};
 
 constexpr int BK2 = 64;
-constexpr int NSTAGE = 3;
+// LDS ring depth.  The 256-row tiles fill the 160 KB with three stages (loads two K tiles ahead).  The 128-row tiles, which serve the small
+// launches (one request, mixed batches: M <= ~4k rows), have smaller stages, and a small launch is LATENCY-bound: a CU streams its operands
+// from HBM / a remote L2 at ~2 us per round trip, so with two tiles in flight an iteration cannot be shorter than ~1 us whatever the tile
+// (measured: 22.5 us for M 512, 23.2 us for M 2048 at N 1280, K 1280 = 20 K tiles).  They therefore run four (BN 160: 147 KB) or five
+// (BN 128: 160 KB) stages, loads three / four tiles ahead.
+template <int BN, int MI> struct RingDepth { static constexpr int value = MI == 4 ? 3 : (BN == 160 ? 4 : 5); };
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
@@ -56,6 +61,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
   constexpr int WI = (WCH + 511) / 512;       // W load instructions per thread per tile (3 for BN=160, 2 for 128)
   constexpr int LOADS = XI + WI;              // per-thread DMA instructions per K tile
   constexpr int STAGE_ELEMS = (BM2 + BN) * BK2;
+  constexpr int NSTAGE = RingDepth<BN, MI>::value;
   __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * STAGE_ELEMS];
 
   const int tid = threadIdx.x;
@@ -229,8 +235,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
   constexpr int NF = NI + MI;
 
   setup_tile();
-  issue_next(0);
-  issue_next(1);
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) issue_next(st);
 
   int stage = 0;   // ring stage of the K tile being computed (stream position modulo 3)
   {
@@ -247,12 +253,13 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
     }
 
     for (int kt = 0; kt < nk; ++kt) {
-      // all but the youngest DMA group (and anything younger) of this thread has completed => stream position g landed
-      if constexpr (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      else if constexpr (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if constexpr (LOADS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      static_assert(LOADS >= 4 && LOADS <= 7, "counted wait");
+      // all but the NSTAGE - 2 youngest DMA groups of this thread have completed => the K tile of this iteration has landed
+      constexpr int INFLIGHT = LOADS * (NSTAGE - 2);
+      if constexpr (INFLIGHT == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else if constexpr (INFLIGHT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (INFLIGHT == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if constexpr (INFLIGHT == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else static_assert(INFLIGHT == 6 || INFLIGHT == 7 || INFLIGHT == 10 || INFLIGHT == 12, "counted wait");
       __builtin_amdgcn_s_barrier();
       bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
 #if MX_EXP == 3
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
 #else
       load_frags(stage, 0, wf0, xf0);
 #endif
-      const int st2 = stage >= 1 ? stage - 1 : 2;   // (g + 2) % 3: last read in iteration g-1, which every wave has left
+      const int st2 = stage >= 1 ? stage - 1 : NSTAGE - 1;   // (g + NSTAGE - 1) % NSTAGE: last read in iteration g-1, which every wave has left
 #if MX_EXP != 2
       issue_group(st2);
 #endif
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
 #if MX_EXP != 2
       advance_cursor();
 #endif
-      stage = stage == 2 ? 0 : stage + 1;
+      stage = stage == NSTAGE - 1 ? 0 : stage + 1;
     }
 
     const int m0 = tm * BM2, n0 = tn * BN;

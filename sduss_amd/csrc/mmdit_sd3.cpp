@@ -436,6 +436,14 @@ int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, c
     p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
     p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
     if (pp) p.px.set(comm, stale);
+    if (pp && stale) {      // the state layout (exchanges dealt into chunks, pp_exchange.h) from a host-only recording walk of the same plan
+      std::vector<size_t> sizes;
+      Plan q = p;
+      q.dry = true; q.ar.dry = true; q.ar.base = nullptr; q.ar.cap = 0; q.stage = nullptr; q.lookup = false;
+      q.px.record = &sizes;
+      if (!q.run(nullptr, io_dtype, nullptr, nullptr, nullptr, nullptr)) { err = q.err; return false; }
+      p.px.build_layout(sizes);
+    }
     const bool okr = p.run(latents, io_dtype, timesteps, ehs, pooled, out);
     plan_peak = p.ar.peak;
     if (state_need) *state_need = p.px.state_top;

@@ -33,16 +33,47 @@ struct GnGeom {
   int C1;
 };
 
+// Grouped launch (mx_groupnorm_nhwc_grouped): the GroupNorms of all resolutions present in a mixed batch as ONE stats / fold / apply launch
+// each.  The problems share C, the affine and the thread geometry (both depend on C only); each has its own images, spatial tiles and
+// scratch.  A workgroup finds its problem from its index (blk0 = first workgroup of every problem in that launch); n == 1: an ordinary launch.
+struct GnProb {
+  GnGeom g;
+  const bf16_t* x; bf16_t* y;
+  float* part; float* coef;
+  long y_img;       // elements between the images of y
+  int ppb;          // pixels per workgroup of the apply pass
+  int patch;        // sliced statistics: patch edge in this problem's pixels (0 = exact)
+};
+struct GnGroup {
+  GnProb p[MX_MAX_SEGS];
+  int blk0[MX_MAX_SEGS + 1];
+  int n;
+};
+__device__ __forceinline__ const GnProb& gn_locate(const GnGroup& G, int& local) {
+  local = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < MX_MAX_SEGS; ++i) if (i < G.n && local >= G.blk0[i]) s = i;
+  local -= G.blk0[s];
+  return G.p[s];
+}
+
 __device__ __forceinline__ const bf16_t* gn_src(const bf16_t* x, const GnGeom& g, long pix, int ch) {
   if (g.x2 == nullptr) return x + pix * g.C + ch;
   return ch < g.C1 ? x + pix * g.C1 + ch : g.x2 + pix * (g.C - g.C1) + (ch - g.C1);
 }
 
-__global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, GnGeom g) {
+__global__ void gn_stats_kernel(const GnGroup G) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [L][C][2]
   const int t = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int b = blockIdx.y;
+  int local;
+  const GnProb& P = gn_locate(G, local);
+  const GnGeom& g = P.g;
+  const bf16_t* __restrict__ x = P.x;
+  float* __restrict__ part = P.part;
+  const int ntl = g.tiles_y * g.tiles_x;
+  const int b = local / ntl;
+  const int tile = local - b * ntl;
   const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
   const int cv = t % g.tpr;
   const int pl = t / g.tpr;
@@ -86,11 +117,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // one workgroup (four waves) per (group, image): fp64 fold of tiles x channels-per-group, patch by patch.  Four waves because the fold is a
 // chain of dependent loads: with one wave the 640..1280 items of a 128 x 128 level took 11 us per launch, 46 launches a step.
 constexpr int kFoldThreads = 256;
-__global__ __launch_bounds__(kFoldThreads) void gn_fold_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ coef,
-                                                     GnGeom g, int groups, float eps, int patch) {
-  const int grp = blockIdx.x;
-  const int b = blockIdx.y;
+__global__ __launch_bounds__(kFoldThreads) void gn_fold_kernel(const GnGroup G, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int groups, float eps) {
+  int local;
+  const GnProb& P = gn_locate(G, local);
+  const GnGeom& g = P.g;
+  const float* __restrict__ part = P.part;
+  float* __restrict__ coef = P.coef;
+  const int patch = P.patch;
+  const int b = local / groups;
+  const int grp = local - b * groups;
   const int cpg = g.C / groups;
   const int ntiles = g.tiles_y * g.tiles_x;
   const int lane = threadIdx.x;
@@ -139,10 +175,19 @@ __global__ __launch_bounds__(kFoldThreads) void gn_fold_kernel(const float* __re
 }
 
 template <bool SILU>
-__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                const float* __restrict__ coef, GnGeom g, int pix_per_block, long y_img) {
+__global__ void gn_apply_kernel(const GnGroup G) {
   const int t = threadIdx.x;
-  const int b = blockIdx.y;
+  int local;
+  const GnProb& P = gn_locate(G, local);
+  const GnGeom& g = P.g;
+  const bf16_t* __restrict__ x = P.x;
+  bf16_t* __restrict__ y = P.y;
+  const float* __restrict__ coef = P.coef;
+  const int pix_per_block = P.ppb;
+  const long y_img = P.y_img;
+  const int nblk = (g.H * g.W + pix_per_block - 1) / pix_per_block;
+  const int b = local / nblk;
+  const int pblk = local - b * nblk;
   const int cv = t % g.tpr;
   const int pl = t / g.tpr;
   if (pl >= g.L) return;
@@ -151,7 +196,7 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = cf[2 * e]; sf[e] = cf[2 * e + 1]; }
   const int hw = g.H * g.W;
-  const int p0 = blockIdx.x * pix_per_block;
+  const int p0 = pblk * pix_per_block;
   const int p1 = min(p0 + pix_per_block, hw);
   for (int pi = p0 + pl; pi < p1; pi += g.L) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(gn_src(x, g, (long)b * hw + pi, cv * 8));
@@ -264,57 +309,108 @@ extern "C" int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const flo
   return mx_groupnorm_nhwc_cat(stream, x, C, nullptr, y, gamma, beta, B, H, W, C, groups, eps, silu, patch, workspace);
 }
 
-extern "C" int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const void* x2, void* y, const float* gamma, const float* beta,
-                                     int B, int H, int W, int C, int groups, float eps, int silu, int patch,
-                                     void* workspace) {
-  using namespace mx;
-  MX_CHECK(x && y && gamma && beta && workspace, "groupnorm: null operand");
-  MX_CHECK(x2 == nullptr || (C1 > 0 && C1 < C && C1 % 8 == 0 && (C - C1) % 8 == 0), "groupnorm: bad channel split");
-  MX_CHECK(groups > 0 && C % groups == 0, "groupnorm: C % groups != 0");
+namespace mx {
+// fill problem i of G (geometry, operands, scratch carved from ws) -- returns the scratch bytes used, 0 on error
+static size_t gn_fill(GnGroup& G, int i, const void* x, int C1, const void* x2, void* y, long y_img, int B, int H, int W, int C, int patch, char* ws) {
+  GnProb& P = G.p[i];
   if (patch >= H && patch >= W) patch = 0;  // one patch per image == exact GroupNorm
-  MX_CHECK(patch == 0 || patch >= 2, "groupnorm: patch must be 0 or >= 2");
-  GnGeom g;
-  if (gn_geom(g, B, H, W, C, patch)) return 1;
-  if (x2) { g.x2 = (const bf16_t*)x2; g.C1 = C1; }
-  const int ntiles = g.tiles_y * g.tiles_x;
-  float* part = (float*)workspace;
-  float* coef = part + (size_t)B * ntiles * C * 2;
-  MX_CHECK(((size_t)B * ntiles * C * 2 + (size_t)B * C * 2) * sizeof(float) <= mx_groupnorm_nhwc_workspace_bytes(B, H, W, C),
-           "groupnorm: internal workspace bound exceeded");
-  hipStream_t s = (hipStream_t)stream;
+  if (patch != 0 && patch < 2) { set_error("groupnorm: patch must be 0 or >= 2"); return 0; }
+  if (gn_geom(P.g, B, H, W, C, patch)) return 0;
+  if (x2) { P.g.x2 = (const bf16_t*)x2; P.g.C1 = C1; }
+  const size_t ntiles = (size_t)P.g.tiles_y * P.g.tiles_x;
+  P.x = (const bf16_t*)x; P.y = (bf16_t*)y; P.y_img = y_img; P.patch = patch;
+  P.part = (float*)ws;
+  P.coef = P.part + (size_t)B * ntiles * C * 2;
+  const int hw = H * W;
+  P.ppb = P.g.L * 8 > hw ? hw : P.g.L * 8;
+  return (((size_t)B * ntiles * C * 2 + (size_t)B * C * 2) * sizeof(float) + 255) & ~(size_t)255;
+}
+static void gn_prefix(GnGroup& G, int which, int groups) {      // which: 0 stats, 1 fold, 2 apply
+  long t = 0;
+  for (int i = 0; i < G.n; ++i) {
+    G.blk0[i] = (int)t;
+    const GnGeom& g = G.p[i].g;
+    t += which == 0 ? (long)g.B * g.tiles_y * g.tiles_x : which == 1 ? (long)g.B * groups : (long)g.B * cdiv(g.H * g.W, G.p[i].ppb);
+  }
+  for (int i = G.n; i <= MX_MAX_SEGS; ++i) G.blk0[i] = (int)t;
+}
+static int gn_launch_stats(hipStream_t s, GnGroup& G, int C) {
+  const GnGeom& g = G.p[0].g;
   const int threads = ((g.tpr * g.L + 63) / 64) * 64;
   const size_t smem = (size_t)g.L * C * 2 * sizeof(float);
   MX_CHECK(smem <= 160 * 1024, "groupnorm: LDS budget exceeded");
-  prof_begin(s, PROF_NORM, 0.0, 3.0 * 2.0 * B * H * (double)W * C);  // stats read + apply read + write
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(ntiles, B), dim3(threads), smem, s, (const bf16_t*)x, part, g);
-  MX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_fold_kernel, dim3(groups, B), dim3(kFoldThreads), 0, s, (const float*)part, gamma, beta, coef, g,
-                     groups, eps, patch);
-  MX_LAUNCH_CHECK();
-  const int hw = H * W;
-  int ppb = g.L * 8;  // pixels per block
-  if (ppb > hw) ppb = hw;
-  dim3 grid(cdiv(hw, ppb), B);
-  if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb, (long)hw * C);
-  else hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb, (long)hw * C);
-  prof_end(s);
+  gn_prefix(G, 0, 0);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(G.blk0[MX_MAX_SEGS]), dim3(threads), smem, s, G);
   MX_LAUNCH_CHECK();
   return 0;
+}
+static int gn_launch_apply(hipStream_t s, GnGroup& G, int silu) {
+  const GnGeom& g = G.p[0].g;
+  const int threads = ((g.tpr * g.L + 63) / 64) * 64;
+  gn_prefix(G, 2, 0);
+  if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(G.blk0[MX_MAX_SEGS]), dim3(threads), 0, s, G);
+  else hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(G.blk0[MX_MAX_SEGS]), dim3(threads), 0, s, G);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace mx
+
+extern "C" size_t mx_groupnorm_nhwc_grouped_workspace_bytes(const mx_gn_problem* probs, int n, int C) {
+  size_t t = 0;
+  for (int i = 0; probs && i < n; ++i) t += mx_groupnorm_nhwc_workspace_bytes(probs[i].B, probs[i].H, probs[i].W, C);
+  return t;
+}
+
+/* The GroupNorms of all resolutions present in a mixed batch as ONE stats / fold / apply launch each (see mx_gemm_seg).  The problems share
+ * C, C1, the affine, groups, eps, silu and the sliced-statistics patch edge; each has its own images.  Per problem the arithmetic is
+ * mx_groupnorm_nhwc_cat's. */
+extern "C" int mx_groupnorm_nhwc_grouped(void* stream, const mx_gn_problem* probs, int n, int C1, const float* gamma, const float* beta, int C,
+                                         int groups, float eps, int silu, int patch, void* workspace) {
+  using namespace mx;
+  MX_CHECK(probs && n >= 1 && n <= MX_MAX_SEGS && gamma && beta && workspace, "groupnorm: grouped launch needs 1..MX_MAX_SEGS problems and its operands");
+  MX_CHECK(groups > 0 && C % groups == 0, "groupnorm: C % groups != 0");
+  GnGroup G;
+  G.n = n;
+  char* ws = (char*)workspace;
+  double bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    const mx_gn_problem& q = probs[i];
+    MX_CHECK(q.x && q.y && q.B > 0 && q.H > 0 && q.W > 0, "groupnorm: null operand / empty problem");
+    MX_CHECK(q.x2 == nullptr || (C1 > 0 && C1 < C && C1 % 8 == 0 && (C - C1) % 8 == 0), "groupnorm: bad channel split");
+    MX_CHECK((q.x2 != nullptr) == (probs[0].x2 != nullptr), "groupnorm: grouped launch: either every problem reads a channel concatenation or none");
+    const size_t used = gn_fill(G, i, q.x, C1, q.x2, q.y, (long)q.H * q.W * C, q.B, q.H, q.W, C, patch, ws);
+    if (!used) return 1;
+    MX_CHECK(used <= mx_groupnorm_nhwc_workspace_bytes(q.B, q.H, q.W, C), "groupnorm: internal workspace bound exceeded");
+    ws += mx_groupnorm_nhwc_workspace_bytes(q.B, q.H, q.W, C);
+    bytes += 3.0 * 2.0 * q.B * q.H * (double)q.W * C;     // stats read + apply read + write
+  }
+  hipStream_t s = (hipStream_t)stream;
+  prof_begin(s, PROF_NORM, 0.0, bytes);
+  if (gn_launch_stats(s, G, C)) return 1;
+  gn_prefix(G, 1, groups);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(G.blk0[MX_MAX_SEGS]), dim3(kFoldThreads), 0, s, G, gamma, beta, groups, eps);
+  MX_LAUNCH_CHECK();
+  if (gn_launch_apply(s, G, silu)) return 1;
+  prof_end(s);
+  return 0;
+}
+
+extern "C" int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const void* x2, void* y, const float* gamma, const float* beta,
+                                     int B, int H, int W, int C, int groups, float eps, int silu, int patch,
+                                     void* workspace) {
+  mx_gn_problem q;
+  q.x = x; q.x2 = x2; q.y = y; q.B = B; q.H = H; q.W = W;
+  return mx_groupnorm_nhwc_grouped(stream, &q, 1, C1, gamma, beta, C, groups, eps, silu, patch, workspace);
 }
 
 namespace mx {
 // local part: stats -> per-(image, group) fp64 sums.  workspace: gn_workspace_exact(B, H, W, C, 0) bytes; sums: double [B][groups][2]
 int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, int B, int H, int W, int C, int groups, void* workspace, double* sums) {
-  GnGeom g;
-  if (gn_geom(g, B, H, W, C, 0)) return 1;
-  if (x2) { g.x2 = (const bf16_t*)x2; g.C1 = C1; }
-  const int ntiles = g.tiles_y * g.tiles_x;
-  float* part = (float*)workspace;
-  const int threads = ((g.tpr * g.L + 63) / 64) * 64;
-  const size_t smem = (size_t)g.L * C * 2 * sizeof(float);
-  MX_CHECK(smem <= 160 * 1024, "groupnorm: LDS budget exceeded");
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(ntiles, B), dim3(threads), smem, s, (const bf16_t*)x, part, g);
-  hipLaunchKernelGGL(gn_pp_sums_kernel, dim3(groups, B), dim3(64), 0, s, (const float*)part, sums, g, groups);
+  GnGroup G;
+  G.n = 1;
+  if (!gn_fill(G, 0, x, C1, x2, nullptr, 0, B, H, W, C, 0, (char*)workspace)) return 1;
+  if (gn_launch_stats(s, G, C)) return 1;
+  hipLaunchKernelGGL(gn_pp_sums_kernel, dim3(groups, B), dim3(64), 0, s, (const float*)G.p[0].part, sums, G.p[0].g, groups);
   MX_LAUNCH_CHECK();
   return 0;
 }
@@ -322,21 +418,12 @@ int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, i
 int launch_gn_pp_finish(hipStream_t s, const void* x, int C1, const void* x2, void* y, long y_img_elems, const float* gamma, const float* beta, const double* all_sums,
                         int world, int B, int H, int W, int C, int groups, int H_total, float eps, int silu, void* workspace,
                         const double* fresh_own, int own_rank) {
-  GnGeom g;
-  if (gn_geom(g, B, H, W, C, 0)) return 1;
-  if (x2) { g.x2 = (const bf16_t*)x2; g.C1 = C1; }
-  float* coef = (float*)workspace + (size_t)B * g.tiles_y * g.tiles_x * C * 2;
+  GnGroup G;
+  G.n = 1;
+  if (!gn_fill(G, 0, x, C1, x2, y, y_img_elems, B, H, W, C, 0, (char*)workspace)) return 1;
   const double cnt = (double)H_total * W * (C / groups);
-  hipLaunchKernelGGL(gn_pp_coef_kernel, dim3(groups, B), dim3(64), 0, s, all_sums, gamma, beta, coef, B, C, groups, world, cnt, eps, fresh_own, own_rank);
-  const int threads = ((g.tpr * g.L + 63) / 64) * 64;
-  const int hw = H * W;
-  int ppb = g.L * 8;
-  if (ppb > hw) ppb = hw;
-  dim3 grid(cdiv(hw, ppb), B);
-  if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb, y_img_elems);
-  else hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(threads), 0, s, (const bf16_t*)x, (bf16_t*)y, (const float*)coef, g, ppb, y_img_elems);
-  MX_LAUNCH_CHECK();
-  return 0;
+  hipLaunchKernelGGL(gn_pp_coef_kernel, dim3(groups, B), dim3(64), 0, s, all_sums, gamma, beta, G.p[0].coef, B, C, groups, world, cnt, eps, fresh_own, own_rank);
+  return gn_launch_apply(s, G, silu);
 }
 }  // namespace mx
 

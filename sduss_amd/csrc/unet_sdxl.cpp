@@ -77,7 +77,19 @@ struct Plan {
   mx_unet* u;
   hipStream_t stream;
   Arena ar;
-  int B, H, W, ctx_len, gn_patch;
+  int B, H, W, ctx_len, gn_patch;   // B = samples of ALL groups; H, W = the first group's latent size (the only one unless mixed)
+  // Mixed-resolution batch (mx_unet_forward_mixed): the requests of every resolution present run through ONE launch sequence.  A group = the
+  // samples of one resolution; activations of a level are the groups' token-major images one after the other ([sum_g B_g h_g w_g, C]), so every
+  // per-token op (linear layers, LayerNorm) is one ordinary launch over all rows, and the ops with per-image structure (3x3 convs, GroupNorm,
+  // the QKV epilogue's V^T, attention) are GROUPED launches: one problem per group, no tile straddling two groups (include/mxdenoise.h,
+  // mx_gemm_seg).  The reference reaches the same end by cutting every latent into 256-px patches of one batch (modules/unet.py:104-185).
+  int ng = 1;
+  int gB[MX_MAX_SEGS], gH[MX_MAX_SEGS], gW[MX_MAX_SEGS], gb0[MX_MAX_SEGS];   // per group: samples, latent size, first sample
+  int ch[MX_MAX_SEGS], cw[MX_MAX_SEGS];                                       // per group: image size at the CURRENT level
+  const void* g_lat[MX_MAX_SEGS]; void* g_out[MX_MAX_SEGS];
+  long rows() const { long m = 0; for (int g = 0; g < ng; ++g) m += (long)gB[g] * ch[g] * cw[g]; return m; }
+  long row0(int g) const { long m = 0; for (int k = 0; k < g; ++k) m += (long)gB[k] * ch[k] * cw[k]; return m; }
+  void set_single(int batch, int h, int w, const void* lat, void* out) { ng = 1; gB[0] = batch; gH[0] = h; gW[0] = w; gb0[0] = 0; g_lat[0] = lat; g_out[0] = out; B = batch; H = h; W = w; }
   bool dry;                 // size-only pass: no launches
   bool mute = false;        // block-skip cache: walk a block's plan (allocations, weight / K-V / time-embedding cursors) without launching it
   bool quiet() const { return dry || mute; }
@@ -240,30 +252,55 @@ struct Plan {
     if (stats_out) return gemm_with_stats(d, *stats_out);
     return gemm(d, false);
   }
+  // 3x3 conv over the images of every group at the current level (Hin, Win: the first group's size; the others come from ch / cw).  A mixed
+  // batch is ONE grouped launch: problem g = group g's images, its output grid, its samples' rows of the time-embedding row bias.
   bool conv(const bf16_t* x, int Hin, int Win, int Cin, const std::string& prefix, bf16_t* out, int Cout, int stride, int up,
             int corner_patch, const float* rowbias = nullptr, int ldrb = 0, const void* residual = nullptr, int vhalo = 0) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
     d.vhalo = vhalo;
     const int Hv = Hin << up, Wv = Win << up;
     d.a = x; d.w = wb(prefix + ".weight", (size_t)Cout * 9 * Cin); d.bias = wf(prefix + ".bias", Cout);
-    d.c = out; d.ldc = Cout; d.B = B; d.Hin = Hin; d.Win = Win; d.Cin = Cin;
+    d.c = out; d.ldc = Cout; d.B = gB[0]; d.Hin = Hin; d.Win = Win; d.Cin = Cin;
     d.Hout = (Hv + stride - 1) / stride; d.Wout = (Wv + stride - 1) / stride; d.stride = stride; d.up = up;
     d.corner_patch = corner_patch;
-    d.M = B * d.Hout * d.Wout; d.N = Cout; d.K = 9 * Cin;
+    d.M = gB[0] * d.Hout * d.Wout; d.N = Cout; d.K = 9 * Cin;
     d.rowbias = rowbias; d.ldrb = ldrb; d.rows_per_batch = d.Hout * d.Wout;
     d.residual = residual; d.ldr = Cout;
+    mx_gemm_seg sg[MX_MAX_SEGS];
+    if (ng > 1) {
+      std::memset(sg, 0, sizeof(sg));
+      long in0 = 0, out0 = 0;
+      for (int g = 0; g < ng; ++g) {
+        mx_gemm_seg& q = sg[g];
+        q.B = gB[g]; q.Hin = ch[g]; q.Win = cw[g];
+        q.Hout = ((ch[g] << up) + stride - 1) / stride; q.Wout = ((cw[g] << up) + stride - 1) / stride;
+        q.M = gB[g] * q.Hout * q.Wout; q.rows_per_batch = q.Hout * q.Wout;
+        q.a = x + in0 * Cin; q.c = out + out0 * Cout;
+        q.residual = residual ? (const bf16_t*)residual + out0 * Cout : nullptr;
+        q.rowbias = rowbias ? rowbias + (long)gb0[g] * ldrb : nullptr;
+        in0 += (long)gB[g] * ch[g] * cw[g]; out0 += q.M;
+      }
+      d.segs = sg; d.n_segs = ng;
+    }
     return gemm(d, true);
   }
   bool groupnorm(const bf16_t* x, bf16_t* y, const std::string& prefix, int h, int wd, int C, float eps, bool silu, int patch,
                  const bf16_t* x2 = nullptr, int C1 = 0) {
     if (!ok()) return false;
     const size_t m = ar.mark();
-    const size_t need = mx::gn_workspace_exact(B, h, wd, C, patch);
+    mx_gn_problem pr[MX_MAX_SEGS];
+    long r0 = 0;
+    for (int k = 0; k < ng; ++k) {         // group k's images inside the concatenated activations
+      pr[k].x = x + r0 * (x2 ? C1 : C); pr[k].x2 = x2 ? x2 + r0 * (C - C1) : nullptr; pr[k].y = y + r0 * C;
+      pr[k].B = gB[k]; pr[k].H = ch[k]; pr[k].W = cw[k];
+      r0 += (long)gB[k] * ch[k] * cw[k];
+    }
+    const size_t need = ng > 1 ? mx_groupnorm_nhwc_grouped_workspace_bytes(pr, ng, C) : mx::gn_workspace_exact(gB[0], h, wd, C, patch);
     void* ws = ar.alloc(need);
     if (!ws) return fail("workspace too small");
     const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
     if (ok() && !quiet()) {
-      if (mx_groupnorm_nhwc_cat(stream, x, x2 ? C1 : C, x2, y, g, b, B, h, wd, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, patch, ws))
+      if (mx_groupnorm_nhwc_grouped(stream, pr, ng, x2 ? C1 : C, g, b, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, patch, ws))
         fail(std::string("groupnorm: ") + mx_last_error());
     }
     ar.release(m);
@@ -276,6 +313,13 @@ struct Plan {
     // q carries MX_ATTN_QSCALE(1/8) from the producing GEMM's epilogue (out_scale)
     if (mx_attention_prescaled(stream, q, ldq, k, ldk, vt, ldvt, vt_bstride, o, ldo, B, heads, Lq, Lk))
       return fail(std::string("attention: ") + mx_last_error());
+    return true;
+  }
+  // one launch over the groups' attention problems (mixed batch)
+  bool attention_grouped(const mx_attn_problem* pr, int ldq, int ldk, int ldo, int heads) {
+    if (!ok()) return false;
+    if (quiet()) return true;
+    if (mx_attention_prescaled_grouped(stream, pr, ng, ldq, ldk, ldo, heads)) return fail(std::string("attention: ") + mx_last_error());
     return true;
   }
   void dump(const std::string& name, const bf16_t* t, size_t elems) {
@@ -293,7 +337,7 @@ struct Plan {
   // x2 != nullptr: the block's input is the channel concatenation [x (Cin - C2 channels) | x2 (C2 channels)] of an up block
   // (unet.py:458-462 torch.cat), read in place by norm1 and by the 1x1 shortcut
   bf16_t* resnet(const std::string& p, const bf16_t* x, int h, int wd, int Cin, int Cout, int level, const bf16_t* x2 = nullptr, int C2 = 0) {
-    const int M = B * h * wd;
+    const int M = (int)rows();            // the pixels of every group at this level (h, wd: the first group's image)
     const int C1 = Cin - C2;
     bf16_t* out = alloc<bf16_t>((size_t)M * Cout);
     const size_t m = ar.mark();
@@ -347,9 +391,15 @@ struct Plan {
 
   // modules/transformer.py:32-128 (Transformer2DModel) and :167-290 (BasicTransformerBlock)
   bf16_t* transformer(const std::string& p, const bf16_t* x, int h, int wd, int C, int heads, int layers, int level) {
-    const int L = h * wd;
-    const int M = B * L;
+    const int L = h * wd;                 // tokens per image of the first group (the only one unless the batch is mixed)
+    const int M = (int)rows();
     const int ctx = u->cfg.cross_attention_dim;
+    // per group: tokens per image, first row, its V^T block (rows of MX_VT_LD(tokens) keys)
+    int gL[MX_MAX_SEGS], gldvt[MX_MAX_SEGS]; long gr0[MX_MAX_SEGS], gvt0[MX_MAX_SEGS], vt_elems = 0;
+    for (int g = 0; g < ng; ++g) {
+      gL[g] = ch[g] * cw[g]; gldvt[g] = MX_VT_LD(gL[g]); gr0[g] = row0(g); gvt0[g] = vt_elems;
+      vt_elems += (long)gB[g] * C * gldvt[g];
+    }
     bf16_t* out = alloc<bf16_t>((size_t)M * C);
     const size_t m0 = ar.mark();
     bf16_t* n = alloc<bf16_t>((size_t)M * C);
@@ -366,17 +416,30 @@ struct Plan {
     bf16_t* ln = n;  // the GroupNorm output is dead after proj_in
     const int ldvt = MX_VT_LD(L);
     bf16_t* qk = alloc<bf16_t>((size_t)M * 2 * C);
-    bf16_t* vt = alloc<bf16_t>((size_t)B * C * ldvt);
+    bf16_t* vt = alloc<bf16_t>((size_t)vt_elems);
     bf16_t* ao = alloc<bf16_t>((size_t)M * C);
     bf16_t* q2 = alloc<bf16_t>((size_t)M * C);
     bf16_t* ff = alloc<bf16_t>((size_t)M * 4 * C);
+    mx_gemm_seg qsegs[MX_MAX_SEGS];       // mixed batch: the fused q|k|v projection as a grouped launch (tokens per image and V^T block per group)
     auto qkv_desc = [&](const std::string& b, const bf16_t* a) {
       mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
       d.a = a; d.lda = C; d.w = wb(b + ".attn1.to_qkv.weight", (size_t)3 * C * C); d.bias = wf(b + ".attn1.to_qkv.bias", 3 * C);
       d.c = qk; d.ldc = 2 * C;
       d.M = M; d.N = 3 * C; d.K = C; d.flags = MX_EPI_QKV; d.seg = C; d.period = 3; d.vt = vt; d.ldvt = ldvt;
       d.rows_per_batch = L; d.out_scale = MX_ATTN_QSCALE(0.125f);   // q segment only
+      if (ng > 1) {
+        std::memset(qsegs, 0, sizeof(qsegs));
+        for (int g = 0; g < ng; ++g) {
+          qsegs[g].a = a + gr0[g] * C; qsegs[g].c = qk + gr0[g] * 2 * C; qsegs[g].vt = vt + gvt0[g];
+          qsegs[g].M = gB[g] * gL[g]; qsegs[g].rows_per_batch = gL[g]; qsegs[g].ldvt = gldvt[g];
+        }
+        d.segs = qsegs; d.n_segs = ng;
+      }
       return d;
+    };
+    // the folded LayerNorm's row statistics of a grouped launch: every problem reads its own rows of the one buffer
+    auto use_ln_grouped = [&](mx_gemm_desc& d, const RowStats& st_) {
+      if (d.n_segs > 0) for (int g = 0; g < ng; ++g) qsegs[g].ln_stats = st_.buf + gr0[g] * MX_STATS_PITCH(st_.slabs) * 2;
     };
     auto lin_desc = [&](const bf16_t* a, void* c, int ldc, int N, int flags, float out_scale) {
       mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
@@ -411,7 +474,7 @@ struct Plan {
       {
         if (pass1) normalise();
         mx_gemm_desc d = qkv_desc(b, pass1 ? ln : y);
-        if (!pass1) use_ln(d, st, b + ".attn1.to_qkv.colsum"); else wf(b + ".attn1.to_qkv.colsum", 3 * C);
+        if (!pass1) { use_ln(d, st, b + ".attn1.to_qkv.colsum"); use_ln_grouped(d, st); } else wf(b + ".attn1.to_qkv.colsum", 3 * C);
         gemm(d, false);
       }
       if (is_pp()) {
@@ -423,6 +486,13 @@ struct Plan {
             mx_attention_prescaled_chunked(stream, qk, 2 * C, k_all, C, vt_all, ldvt, (int64_t)C * ldvt, ao, C, B, heads, L, pp_world * L, L,
                                            (int64_t)L * C, (int64_t)M * C, (int64_t)B * C * ldvt))
           fail(std::string("attention: ") + mx_last_error());
+      } else if (ng > 1) {
+        mx_attn_problem pr[MX_MAX_SEGS];
+        for (int g = 0; g < ng; ++g) {
+          pr[g].q = qk + gr0[g] * 2 * C; pr[g].k = qk + gr0[g] * 2 * C + C; pr[g].vt = vt + gvt0[g]; pr[g].o = ao + gr0[g] * C;
+          pr[g].vt_batch_stride = (int64_t)C * gldvt[g]; pr[g].B = gB[g]; pr[g].Lq = gL[g]; pr[g].Lk = gL[g]; pr[g].ldvt = gldvt[g];
+        }
+        attention_grouped(pr, 2 * C, 2 * C, C, heads);
       } else {
         attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
       }
@@ -433,6 +503,15 @@ struct Plan {
              pass2 ? nullptr : &st);
       if (ok()) {
         const int li = kvp->next++;
+        if (ng > 1) {                       // the hoisted K / V^T are per sample: group g reads the rows of its samples
+          mx_attn_problem pr[MX_MAX_SEGS];
+          for (int g = 0; g < ng; ++g) {
+            pr[g].q = q2 + gr0[g] * C; pr[g].k = kvp->k + (size_t)li * C + (size_t)gb0[g] * ctx_len * kvp->ldk;
+            pr[g].vt = kvp->vt + (size_t)li * C * kvp->ldvt + (size_t)gb0[g] * kvp->vt_bstride; pr[g].o = ao + gr0[g] * C;
+            pr[g].vt_batch_stride = kvp->vt_bstride; pr[g].B = gB[g]; pr[g].Lq = gL[g]; pr[g].Lk = ctx_len; pr[g].ldvt = kvp->ldvt;
+          }
+          attention_grouped(pr, C, kvp->ldk, C, heads);
+        } else
         attention(q2, C, kvp->k + (size_t)li * C, kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, kvp->ldvt, kvp->vt_bstride,
                   ao, C, heads, L, ctx_len);
       }
@@ -513,10 +592,13 @@ struct Plan {
     }
 
     // ---- conv_in (unet.py:344) ----
-    int h = H, wd = W;
-    bf16_t* x0 = alloc<bf16_t>((size_t)B * h * wd * kConvInPad);
-    if (ok() && !dry && mx::launch_prep_latent(stream, latents, io_dtype, x0, B, c.in_channels, h * wd, kConvInPad)) fail(mx_last_error());
-    bf16_t* x = alloc<bf16_t>((size_t)B * h * wd * C0);
+    int h = H, wd = W;                    // the first group's image at the current level; ch / cw hold every group's
+    for (int g = 0; g < ng; ++g) { ch[g] = gH[g]; cw[g] = gW[g]; }
+    if (ng > 1 && (is_pp() || bc)) fail("a mixed-resolution batch runs neither patch-parallel nor through the block cache");
+    bf16_t* x0 = alloc<bf16_t>((size_t)rows() * kConvInPad);
+    for (int g = 0; g < ng && ok() && !dry; ++g)
+      if (mx::launch_prep_latent(stream, g_lat[g], io_dtype, x0 + row0(g) * kConvInPad, gB[g], c.in_channels, ch[g] * cw[g], kConvInPad)) fail(mx_last_error());
+    bf16_t* x = alloc<bf16_t>((size_t)rows() * C0);
     if (is_pp()) {
       bf16_t* x0p = alloc_padded(h, wd, kConvInPad);
       copy_to_padded(x0, x0p, h, wd, kConvInPad);
@@ -524,7 +606,7 @@ struct Plan {
       conv(x0p, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0, nullptr, 0, nullptr, 1);
     } else
     conv(x0, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0);  // patches are cut from the true latent: no corner rule (unet.py:123-158)
-    dump("conv_in", x, (size_t)B * h * wd * C0);
+    dump("conv_in", x, (size_t)rows() * C0);
 
     struct Skip { bf16_t* t; int C; int h, wd; };
     std::vector<Skip> skips;
@@ -545,7 +627,9 @@ struct Plan {
       }
       if (i != nlev - 1) {
         const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0";
-        bf16_t* d = alloc<bf16_t>((size_t)B * (h / 2) * (wd / 2) * Cout);
+        size_t drows = 0;
+        for (int g = 0; g < ng; ++g) drows += (size_t)gB[g] * ((ch[g] + 1) / 2) * ((cw[g] + 1) / 2);
+        bf16_t* d = alloc<bf16_t>(drows * Cout);
         if (is_pp()) {
           if (h % 2) fail("patch-parallel: local rows must stay even down to the last level");
           const size_t mk = ar.mark();
@@ -557,8 +641,9 @@ struct Plan {
         } else
         conv(x, h, wd, Cout, dp + ".conv", d, Cout, 2, 0, level_patch(i));   // resnet.py:364-371
         h /= 2; wd /= 2;
+        for (int g = 0; g < ng; ++g) { ch[g] = (ch[g] + 1) / 2; cw[g] = (cw[g] + 1) / 2; }
         x = d;
-        dump(dp, x, (size_t)B * h * wd * Cout);
+        dump(dp, x, (size_t)rows() * Cout);
         skips.push_back({x, Cout, h, wd});
       }
     };
@@ -583,7 +668,7 @@ struct Plan {
       }
       if (i != nlev - 1) {
         const std::string upn = "up_blocks." + std::to_string(i) + ".upsamplers.0";
-        bf16_t* d = alloc<bf16_t>((size_t)B * (2 * h) * (2 * wd) * Cout);
+        bf16_t* d = alloc<bf16_t>((size_t)rows() * 4 * Cout);
         if (is_pp()) {
           const size_t mk = ar.mark();
           bf16_t* xp = alloc_padded(h, wd, Cout);
@@ -594,8 +679,9 @@ struct Plan {
         } else
         conv(x, h, wd, Cout, upn + ".conv", d, Cout, 1, 1, level_patch(level - 1));  // resnet.py:316, 327-333
         h *= 2; wd *= 2;
+        for (int g = 0; g < ng; ++g) { ch[g] *= 2; cw[g] *= 2; }
         x = d;
-        dump(upn, x, (size_t)B * h * wd * Cout);
+        dump(upn, x, (size_t)rows() * Cout);
       }
     };
 
@@ -687,14 +773,14 @@ struct Plan {
     int block = 0;
     if (bc) {
       if (bc_rows < B) bc_rows = B;
-      bc_top = (dry ? (char*)nullptr : (char*)bc->state) + bc_scratch_bytes(c.layers_per_block, bc_rows);
+      bc_top = (dry ? (char*)(uintptr_t)0x1000 : (char*)bc->state) + bc_scratch_bytes(c.layers_per_block, bc_rows);
     }
     for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, false, {{x, (size_t)h * wd * Ccur}}, [&] { down_block(i); });
     if (ok()) { run_block(block, false, {{x, (size_t)h * wd * Ccur}}, [&] { mid_block(); }); ++block; }
     for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, true, up_inputs(c.layers_per_block + 1), [&] { up_block(i); });
     // ---- out (unet.py:508-517) ----
     {
-      const size_t M = (size_t)B * h * wd;
+      const size_t M = (size_t)rows();
       const int Co = c.out_channels;
       const int ldo = (Co + 3) / 4 * 4;
       bf16_t* o = alloc<bf16_t>(M * ldo);
@@ -709,7 +795,8 @@ struct Plan {
       conv(n, h, wd, C0, "conv_out", o, ldo, 1, 0, level_patch(0));
       }
       dump("conv_out", o, M * ldo);
-      if (ok() && !dry && mx::launch_nhwc_to_nchw(stream, o, outp, io_dtype, B, Co, h * wd, ldo)) fail(mx_last_error());
+      for (int g = 0; g < ng && ok() && !dry; ++g)
+        if (mx::launch_nhwc_to_nchw(stream, o + row0(g) * ldo, g_out[g], io_dtype, gB[g], Co, ch[g] * cw[g], ldo)) fail(mx_last_error());
     }
     if (stage && !dry && ok() && !stage_hit) fail(std::string("unknown stage '") + stage + "'");
     return ok();
@@ -737,8 +824,20 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
                  const void* text_embeds, const float* time_ids, void* out, int batch, int H, int W, int ctx_len, int gn_patch,
                  void* workspace, size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_bytes, bool dry,
                  size_t* peak, bool lookup = false, const mx_pp_comm* comm = nullptr, const mx_pp_stale* stale = nullptr,
-                 size_t* state_need = nullptr) {
+                 size_t* state_need = nullptr, const mx_unet_group* groups = nullptr, int n_groups = 0) {
   MX_CHECK(u != nullptr, "unet: null handle");
+  if (groups) {        // mixed-resolution batch: `batch`, H, W describe the first group; every group is validated below
+    MX_CHECK(n_groups >= 1 && n_groups <= MX_MAX_SEGS && comm == nullptr, "unet: a mixed batch has 1..MX_MAX_SEGS resolution groups and does not run patch-parallel");
+    batch = groups[0].batch; H = groups[0].H; W = groups[0].W; latents = groups[0].latents; out = groups[0].out;
+    const int dv = 1 << (u->cfg.n_levels - 1);
+    for (int g = 0; g < n_groups; ++g) {
+      MX_CHECK(groups[g].batch > 0 && groups[g].H > 0 && groups[g].W > 0 && groups[g].H % dv == 0 && groups[g].W % dv == 0, "unet: bad group shape");
+      MX_CHECK(dry || (groups[g].latents && groups[g].out), "unet: null group operand");
+      if (gn_patch > 0)
+        MX_CHECK((groups[g].H % gn_patch == 0 && groups[g].W % gn_patch == 0) || (gn_patch >= groups[g].H && gn_patch >= groups[g].W),
+                 "unet: every group's H, W must be multiples of gn_patch");
+    }
+  }
   const bool pp = comm != nullptr && comm->world > 1;
   if (pp) {
     MX_CHECK(comm->rank >= 0 && comm->rank < comm->world && (dry || comm->all_gather != nullptr), "unet pp: bad communicator");
@@ -762,12 +861,30 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
   size_t plan_peak = 0;
   auto enqueue = [&](hipStream_t s) {
     Plan p;
-    p.u = u; p.stream = s; p.B = batch; p.H = H; p.W = W; p.ctx_len = ctx_len;
-    p.gn_patch = (gn_patch >= H && gn_patch >= W) ? 0 : gn_patch;
+    p.u = u; p.stream = s; p.ctx_len = ctx_len;
+    p.set_single(batch, H, W, latents, out);
+    bool patch_covers_all = gn_patch >= H && gn_patch >= W;
+    if (groups) {
+      p.ng = n_groups; p.B = 0;
+      for (int g = 0; g < n_groups; ++g) {
+        p.gB[g] = groups[g].batch; p.gH[g] = groups[g].H; p.gW[g] = groups[g].W; p.gb0[g] = p.B; p.g_lat[g] = groups[g].latents; p.g_out[g] = groups[g].out;
+        p.B += groups[g].batch;
+        patch_covers_all = patch_covers_all && gn_patch >= groups[g].H && gn_patch >= groups[g].W;
+      }
+    }
+    p.gn_patch = patch_covers_all ? 0 : gn_patch;
     p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
     p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
     if (pp) { p.pp_rank = comm->rank; p.pp_world = comm->world; p.Htot = H * comm->world; }
     if (pp) p.px.set(comm, stale);
+    if (pp && stale) {      // the state layout (exchanges dealt into chunks, pp_exchange.h) from a host-only recording walk of the same plan
+      std::vector<size_t> sizes;
+      Plan q = p;
+      q.dry = true; q.ar.dry = true; q.ar.base = nullptr; q.ar.cap = 0; q.stage = nullptr; q.lookup = false;
+      q.px.record = &sizes;
+      if (!q.run(nullptr, io_dtype, nullptr, nullptr, nullptr, nullptr, nullptr)) { err = q.err; return false; }
+      p.px.build_layout(sizes);
+    }
     const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
     plan_peak = p.ar.peak;
     if (state_need) *state_need = p.px.state_top;
@@ -778,10 +895,13 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
   if (dry || stage || pp) {     // (the all-gather callbacks of a patch-parallel forward cannot be captured)
     okr = enqueue((hipStream_t)stream);
   } else {
-    const std::vector<uint64_t> key = {(uint64_t)batch, (uint64_t)H, (uint64_t)W, (uint64_t)ctx_len, (uint64_t)gn_patch, (uint64_t)io_dtype,
-                                       (uint64_t)(uintptr_t)latents, (uint64_t)(uintptr_t)timesteps, (uint64_t)(uintptr_t)ehs,
-                                       (uint64_t)(uintptr_t)text_embeds, (uint64_t)(uintptr_t)time_ids, (uint64_t)(uintptr_t)out,
-                                       (uint64_t)(uintptr_t)workspace, (uint64_t)workspace_bytes, (uint64_t)(uintptr_t)u->blob};
+    std::vector<uint64_t> key = {(uint64_t)batch, (uint64_t)H, (uint64_t)W, (uint64_t)ctx_len, (uint64_t)gn_patch, (uint64_t)io_dtype,
+                                 (uint64_t)(uintptr_t)latents, (uint64_t)(uintptr_t)timesteps, (uint64_t)(uintptr_t)ehs,
+                                 (uint64_t)(uintptr_t)text_embeds, (uint64_t)(uintptr_t)time_ids, (uint64_t)(uintptr_t)out,
+                                 (uint64_t)(uintptr_t)workspace, (uint64_t)workspace_bytes, (uint64_t)(uintptr_t)u->blob};
+    for (int g = 1; g < n_groups; ++g)
+      for (uint64_t v : {(uint64_t)groups[g].batch, (uint64_t)groups[g].H, (uint64_t)groups[g].W, (uint64_t)(uintptr_t)groups[g].latents, (uint64_t)(uintptr_t)groups[g].out})
+        key.push_back(v);
     okr = u->graphs.run((hipStream_t)stream, key, enqueue);
   }
   if (peak) *peak = plan_peak;
@@ -846,6 +966,41 @@ extern "C" int mx_unet_forward(mx_unet* u, void* stream, const void* latents, in
                       workspace, workspace_bytes, nullptr, nullptr, 0, false, nullptr);
 }
 
+/* ---- mixed-resolution batch: ONE launch sequence over the requests of every resolution present (the reference batches
+ * 512 / 768 / 1024 px requests by cutting all of them into 256-px patches, modules/unet.py:104-185) ---- */
+extern "C" size_t mx_unet_workspace_bytes_mixed(const mx_unet* u, const mx_unet_group* groups, int n_groups, int ctx_len) {
+  if (!u || !groups || n_groups < 1 || n_groups > MX_MAX_SEGS) return 0;
+  size_t best = 0;
+  const int div = 1 << (u->cfg.n_levels - 1);
+  for (int gp : {0, 2 * div}) {                 // (the sliced GroupNorm needs the larger scratch: size for the smallest legal patch)
+    bool legal = true;
+    for (int g = 0; g < n_groups; ++g) legal = legal && (gp == 0 || (groups[g].H % gp == 0 && groups[g].W % gp == 0));
+    if (!legal) continue;
+    size_t peak = 0;
+    if (forward_impl(const_cast<mx_unet*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, ctx_len, gp, nullptr, 0,
+                     nullptr, nullptr, 0, true, &peak, false, nullptr, nullptr, nullptr, groups, n_groups))
+      return 0;
+    best = std::max(best, peak);
+  }
+  return best + 4096;
+}
+
+extern "C" int mx_unet_forward_mixed(mx_unet* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                                     const void* ehs, const void* text_embeds, const float* time_ids, int ctx_len, int gn_patch, void* workspace,
+                                     size_t workspace_bytes) {
+  MX_CHECK(groups != nullptr, "unet_forward_mixed: null groups");
+  return forward_impl(u, stream, nullptr, io_dtype, timesteps, ehs, text_embeds, time_ids, nullptr, 0, 0, 0, ctx_len, gn_patch, workspace, workspace_bytes,
+                      nullptr, nullptr, 0, false, nullptr, false, nullptr, nullptr, nullptr, groups, n_groups);
+}
+
+extern "C" int mx_unet_forward_mixed_trace(mx_unet* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                                           const void* ehs, const void* text_embeds, const float* time_ids, int ctx_len, int gn_patch, void* workspace,
+                                           size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes) {
+  MX_CHECK(groups != nullptr && stage && stage_out, "unet_forward_mixed_trace: groups, stage and stage_out required");
+  return forward_impl(u, stream, nullptr, io_dtype, timesteps, ehs, text_embeds, time_ids, nullptr, 0, 0, 0, ctx_len, gn_patch, workspace, workspace_bytes,
+                      stage, stage_out, stage_out_bytes, false, nullptr, false, nullptr, nullptr, nullptr, groups, n_groups);
+}
+
 /* ---- block-skip cache (include/mxdenoise.h; the reference's CacheManager, modules/cache_manager.py:101-161) ---- */
 extern "C" size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, int W) {
   if (!u || batch <= 0 || H <= 0 || W <= 0) return 0;
@@ -853,11 +1008,11 @@ extern "C" size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, 
   if (H % div || W % div) return 0;
   Plan p;
   mx_block_cache sizing{};
-  p.u = const_cast<mx_unet*>(u); p.stream = nullptr; p.B = batch; p.H = H; p.W = W; p.ctx_len = 64; p.gn_patch = 0;
+  p.u = const_cast<mx_unet*>(u); p.stream = nullptr; p.set_single(batch, H, W, nullptr, nullptr); p.ctx_len = 64; p.gn_patch = 0;
   p.dry = true; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
   p.bc = &sizing; p.bc_rows = batch;
   if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
-  return (size_t)(p.bc_top - (char*)nullptr) + 256;
+  return (size_t)(p.bc_top - (char*)(uintptr_t)0x1000) + 256;     // (dry walk: the bump pointer starts at a placeholder base, as the arena does)
 }
 
 extern "C" int mx_unet_forward_cached(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
@@ -898,7 +1053,7 @@ extern "C" int mx_unet_forward_cached(mx_unet* u, void* stream, const void* late
   }
   p.bc_all_valid = true; p.bc_any_valid = false;
   for (int b = 0; b < batch; ++b) { p.bc_all_valid = p.bc_all_valid && p.bc_valid[b]; p.bc_any_valid = p.bc_any_valid || p.bc_valid[b]; }
-  p.u = u; p.stream = (hipStream_t)stream; p.B = batch; p.H = H; p.W = W; p.ctx_len = ctx_len;
+  p.u = u; p.stream = (hipStream_t)stream; p.set_single(batch, H, W, latents, out); p.ctx_len = ctx_len;
   p.gn_patch = (gn_patch >= H && gn_patch >= W) ? 0 : gn_patch;
   p.dry = false;
   p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = false;

@@ -51,6 +51,22 @@ class GemmDesc(C.Structure):
     ]
 
 
+class AttnProblem(C.Structure):
+    """mx_attn_problem"""
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p), ("vt_batch_stride", C.c_int64),
+                ("B", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int), ("ldvt", C.c_int)]
+
+
+class GnProblem(C.Structure):
+    """mx_gn_problem"""
+    _fields_ = [("x", C.c_void_p), ("x2", C.c_void_p), ("y", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
+class UNetGroup(C.Structure):
+    """mx_unet_group: the samples of one resolution of a mixed batch"""
+    _fields_ = [("latents", C.c_void_p), ("out", C.c_void_p), ("batch", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
 class UNetConfigC(C.Structure):
     _fields_ = [
         ("in_channels", C.c_int), ("out_channels", C.c_int), ("n_levels", C.c_int),
@@ -143,6 +159,12 @@ SYMBOLS = {
     "mx_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mx_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "mx_groupnorm_nhwc_cat": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "mx_attention_prescaled_grouped": (_i, [_vp, C.POINTER(AttnProblem), _i, _i, _i, _i, _i]),
+    "mx_groupnorm_nhwc_grouped_workspace_bytes": (_sz, [C.POINTER(GnProblem), _i, _i]),
+    "mx_groupnorm_nhwc_grouped": (_i, [_vp, C.POINTER(GnProblem), _i, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp]),
+    "mx_unet_workspace_bytes_mixed": (_sz, [_vp, C.POINTER(UNetGroup), _i, _i]),
+    "mx_unet_forward_mixed": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
+    "mx_unet_forward_mixed_trace": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, C.c_char_p, _vp, _sz]),
     "mx_unet_create": (_vp, [C.POINTER(UNetConfigC)]),
     "mx_unet_destroy": (None, [_vp]),
     "mx_unet_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),

@@ -67,6 +67,7 @@ class SDXLDenoiser:
         self.concurrent_resolutions = True
         self._streams: List[torch.cuda.Stream] = []
         self._cache = StepCache(unet.device)      # per batch composition: conditioning cats, sigma/timestep tables (step_state.py)
+        self._mixed_cond: Dict[tuple, tuple] = {}  # per mixed composition: the conditioning of all resolutions concatenated
 
     def set_timesteps(self, req: Request) -> None:
         if req.num_inference_steps not in self._tables:
@@ -89,6 +90,9 @@ class SDXLDenoiser:
         (one 512-1024 px request fills about a quarter of the CUs) leaves room for the other sequences to run beside it.
         The caller's stream waits for all of them; ``self.concurrent_resolutions = False`` serialises them."""
         res_list = [r for r in sorted(worker_reqs.keys(), key=lambda r: int(r)) if worker_reqs[r]]       # :275-276
+        if (1 < len(res_list) <= self.unet.max_mixed_groups and self.unet.mixed_one_sequence and getattr(self.unet, "_block_caches", None) is None):
+            self._step_mixed(res_list, worker_reqs, do_classifier_free_guidance, is_sliced, patch_size)
+            return
         if len(res_list) <= 1 or not self.concurrent_resolutions:
             for res in res_list:
                 self._step_resolution(res, worker_reqs[res], do_classifier_free_guidance, is_sliced, patch_size)
@@ -109,6 +113,55 @@ class SDXLDenoiser:
         for res in res_list:                       # the new latents were allocated on side streams: consumers on `cur`
             for r in worker_reqs[res]:             # (post_inference / VAE) are now known to the allocator
                 r.latents.record_stream(cur)
+
+    def _gather(self, res: str, reqs: List[Request], do_classifier_free_guidance: bool):
+        """the per-resolution gather of :287-339 through the per-composition cache: (entry, latents [n, ...], sigma, sigma_next, timesteps)"""
+        def build_cond():
+            if do_classifier_free_guidance:                              # :322-339 row order [uncond..., cond...]
+                ehs = torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0)
+                tids = torch.cat([t for r in reqs for t in (r.negative_add_time_ids, r.add_time_ids)], dim=0)    # interleaved neg/pos per request (:302-305)
+            else:
+                ehs = torch.cat([r.prompt_embeds for r in reqs], dim=0)
+                pooled = torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
+                tids = torch.cat([r.add_time_ids for r in reqs], dim=0)
+            return ehs, pooled, tids
+        e = self._cache.entry((res, do_classifier_free_guidance, tuple(r.request_id for r in reqs), tuple(id(r) for r in reqs)), reqs, build_cond)
+        lat = self._cache.latents(e, reqs)
+        sig, sig_next, ts = self._cache.step_scalars(e, reqs)
+        return e, lat, sig, sig_next, ts
+
+    def _step_mixed(self, res_list: List[str], worker_reqs: Dict[str, List[Request]], do_classifier_free_guidance: bool, is_sliced: bool,
+                    patch_size: int) -> None:
+        """All resolutions of the batch in ONE launch sequence (MxUNet.forward_mixed): the reference runs them as one patch batch
+        (:369-380 with the dict of all resolutions; modules/unet.py:242-260).  Conditioning rows: ascending resolution, [uncond..., cond...]
+        inside each (:275-276, 327-339)."""
+        here = torch.cuda.current_stream()
+        parts = []
+        for res in res_list:
+            reqs = worker_reqs[res]
+            for r in reqs:
+                r.latents.record_stream(here)
+            e, lat, sig, sig_next, ts = self._gather(res, reqs, do_classifier_free_guidance)
+            rows = 2 * len(reqs) if do_classifier_free_guidance else len(reqs)
+            parts.append((res, reqs, e, lat, sig, sig_next, torch.cat([ts, ts]) if do_classifier_free_guidance else ts,
+                          ops.euler_scale_input(lat, sig, rows)))
+        key = tuple(id(p[2]) for p in parts)                 # the concatenated conditioning lives as long as its per-resolution entries
+        hit = self._mixed_cond.get(key)
+        if hit is None or any(a is not b for a, b in zip(hit[0], [p[2] for p in parts])):
+            cat = tuple(torch.cat([p[2].cond[k] for p in parts], dim=0) for k in range(3))
+            if len(self._mixed_cond) > 32:
+                self._mixed_cond.clear()
+            hit = self._mixed_cond[key] = ([p[2] for p in parts], cat)
+        ehs, pooled, tids = hit[1]
+        noise = self.unet.forward_mixed([p[7] for p in parts], torch.cat([p[6] for p in parts]), ehs, pooled, tids,
+                                        gn_patch=(patch_size // 8 if is_sliced else 0))
+        g = self.guidance_scale if do_classifier_free_guidance else 0.0
+        for (res, reqs, _e, lat, sig, sig_next, _ts, _x), nz in zip(parts, noise):
+            ops.cfg_euler_step_(nz, lat, sig, sig_next, g)              # :382-397
+            for i, r in enumerate(reqs):                                 # :399-403
+                r.step_index += 1
+                r.latents = lat[i:i + 1]
 
     def _step_resolution(self, res: str, reqs: List[Request], do_classifier_free_guidance: bool, is_sliced: bool,
                          patch_size: int) -> None:

@@ -60,6 +60,8 @@ class MxUNet:
         self.weights = PackedWeights(pack(cfg, params), self.device)
         _lib.check(self._lib.mx_unet_set_weights(self._handle, self.weights.blob.data_ptr(), self.weights.blob.numel(),
                                                  self.weights.table, len(self.weights.names)), "mx_unet_set_weights")
+        self.mixed_one_sequence = True     # False: one launch sequence per resolution (the round-2 form; A/B and tests)
+        self.max_mixed_groups = _lib.MAX_SEGS
         self._ws_by_stream: Dict[int, Optional[torch.Tensor]] = {}
         self._ws_need = {}
         self.config = _Config(in_channels=cfg.in_channels, time_cond_proj_dim=None,
@@ -125,6 +127,56 @@ class MxUNet:
                                                    st.numel() * 2), "mx_unet_forward_trace")
         return st
 
+    def forward_mixed(self, samples: List[torch.Tensor], timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                      text_embeds: torch.Tensor, time_ids: torch.Tensor, gn_patch: int = 0, stage: Optional[str] = None) -> List[torch.Tensor]:
+        """ONE launch sequence over the latents of several resolutions (mx_unet_forward_mixed): ``samples[g]`` is [B_g, C, H_g, W_g]; the
+        conditioning rows are those of all groups concatenated in list order.  What the reference's sliced branch does by cutting every latent
+        into one patch batch (unet.py:104-185, 242-260).  With ``stage`` returns that stage's NHWC activation of all groups instead
+        ([sum of pixels, C], tests)."""
+        assert 1 <= len(samples) <= _lib.MAX_SEGS, f"a mixed batch holds up to {_lib.MAX_SEGS} resolutions"
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([float(timestep)], device=self.device)
+        samples = [x.contiguous() for x in samples]
+        dt = samples[0].dtype
+        assert all(x.is_cuda and x.ndim == 4 and x.dtype == dt for x in samples)
+        btot = sum(x.shape[0] for x in samples)
+        ctx_len = encoder_hidden_states.shape[1]
+        ts = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+        if ts.numel() == 1:
+            ts = ts.expand(btot)
+        ts = ts.contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        te = text_embeds.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        ti = time_ids.to(device=self.device, dtype=torch.float32).contiguous()
+        assert ts.shape[0] == btot and ehs.shape[0] == btot and te.shape[0] == btot and ti.shape == (btot, 6)
+        outs = [torch.empty((x.shape[0], self.cfg.out_channels, x.shape[2], x.shape[3]), dtype=dt, device=self.device) for x in samples]
+        groups = (_lib.UNetGroup * len(samples))()
+        for g, (x, o) in enumerate(zip(samples, outs)):
+            groups[g].latents, groups[g].out = x.data_ptr(), o.data_ptr()
+            groups[g].batch, groups[g].H, groups[g].W = x.shape[0], x.shape[2], x.shape[3]
+        key = ("mixed", tuple((x.shape[0], x.shape[2], x.shape[3]) for x in samples), ctx_len)
+        need = self._ws_need.get(key)
+        if need is None:
+            need = self._ws_need[key] = self._lib.mx_unet_workspace_bytes_mixed(self._handle, groups, len(samples), ctx_len)
+        if need == 0:
+            raise _lib.MxError("mx_unet_workspace_bytes_mixed: " + self._lib.mx_last_error().decode())
+        stream = _lib.current_stream()
+        sk = int(stream or 0)
+        ws = self._ws_by_stream.get(sk)
+        if ws is None or ws.numel() < need:
+            self._ws_by_stream[sk] = None
+            ws = self._ws_by_stream[sk] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        code = _lib.torch_dtype_code(dt)
+        if stage is None:
+            _lib.check(self._lib.mx_unet_forward_mixed(self._handle, stream, groups, len(samples), code, ts.data_ptr(), ehs.data_ptr(), te.data_ptr(),
+                                                       ti.data_ptr(), ctx_len, gn_patch, ws.data_ptr(), ws.numel()), "mx_unet_forward_mixed")
+            return outs
+        st = torch.empty(64 << 20, dtype=torch.bfloat16, device=self.device)        # large enough for any stage of the test shapes
+        _lib.check(self._lib.mx_unet_forward_mixed_trace(self._handle, stream, groups, len(samples), code, ts.data_ptr(), ehs.data_ptr(), te.data_ptr(),
+                                                         ti.data_ptr(), ctx_len, gn_patch, ws.data_ptr(), ws.numel(), stage.encode(), st.data_ptr(),
+                                                         st.numel() * 2), "mx_unet_forward_mixed_trace")
+        return [st]
+
     def forward_one_cached(self, cache, sample: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                            text_embeds: torch.Tensor, time_ids: torch.Tensor, batch_key: int = 0, gn_patch: int = 0, row_ids=None) -> torch.Tensor:
         """forward_one through the block-skip cache (sduss_amd/block_cache.py BlockSkipCache; the reference's ESYMRED_USE_CACHE=TRUE
@@ -175,6 +227,11 @@ class MxUNet:
         keys = [k for k in sample if sample[k] is not None and sample[k].shape[0] > 0]
         if not is_sliced:
             keys = keys[:1]  # the reference's unsliced branch runs the first resolution only (unet.py:268-272)
+        if is_sliced and len(keys) > 1 and len(keys) <= _lib.MAX_SEGS and getattr(self, "_block_caches", None) is None and self.mixed_one_sequence:
+            # the resolutions of a mixed batch as ONE launch sequence (the reference: one patch batch, unet.py:242-260)
+            assert patch_size is not None and all(int(k) % patch_size == 0 for k in keys)
+            res = self.forward_mixed([sample[k] for k in keys], timestep, encoder_hidden_states, text_embeds, time_ids, gn_patch=patch_size // 8)
+            return (dict(zip(keys, res)),)
         for key in keys:
             x = sample[key]
             n = x.shape[0]

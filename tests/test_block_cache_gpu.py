@@ -299,8 +299,10 @@ def test_model_slot_forward_with_the_cache_enabled(tiny):
         return {"256": [synthetic_request(i, 256, 10, cfg, den, torch.device("cuda:0"), shared=shared) for i in range(2)],
                 "128": [synthetic_request(10 + i, 128, 10, cfg, den, torch.device("cuda:0"), shared=shared) for i in range(1)]}
     exact = fresh()
+    net.mixed_one_sequence = False          # the cache entry runs one launch sequence per resolution (one cache state each): compare like with like
     for _ in range(3):
         den.denoising_step(exact)
+    net.mixed_one_sequence = True
     pred = Always(1)
     net.enable_block_cache(pred)
     try:

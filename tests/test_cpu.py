@@ -727,3 +727,17 @@ def test_oracle_chain_batched_steps_equal_each_request_alone(tiny):
         ts, sig = chain_ref.sd3_flow_tables(n)
         pts, psig = flow_match_tables(n)
         assert np.array_equal(ts.numpy(), pts) and np.array_equal(sig.numpy(), psig)
+
+
+def test_host_side_plans_under_address_and_ub_sanitizers():
+    """SURVEY.md section 5 (race detection / sanitizers): GPU sanitizers are not available on this pool, so the sanitizer covers what runs on
+    the host -- the step plans' arena / cursor / offset arithmetic.  `make asan` compiles every source --cuda-host-only with AddressSanitizer +
+    UBSan and links tests/asan_walk.cpp, which walks the dry-run entry points (workspace / state sizing at the benchmark's sizes, mixed
+    groups, patch-parallel comm plans at world 2 / 4 / 8, block-cache state, grouped-GEMM tile bookkeeping) without launching a kernel."""
+    import subprocess
+    csrc = os.path.join(ROOT, "sduss_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j4", "asan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    exe = os.path.join(ROOT, "build", "asan", "asan_walk")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert r.returncode == 0 and "ASAN_WALK_OK" in r.stdout, (r.stdout[-2000:] + r.stderr[-4000:])

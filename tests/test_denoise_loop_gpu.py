@@ -61,6 +61,19 @@ def _mirror_sd3(r) -> chain_ref.ChainRequest:
                                   (f(r.negative_prompt_embeds), f(r.negative_pooled_prompt_embeds)), ts, sig)
 
 
+@pytest.fixture(autouse=True)
+def few_host_threads(request):
+    """the tiny-config oracle forwards are ~100 small torch ops each: on the GPU box's 128 default threads they spend their time in thread
+    wake-ups (the 59-step continuous-batching schedule took 95 s).  The full-width chain keeps the default."""
+    if "base_width" in request.node.name:
+        yield
+        return
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(n, 8))
+    yield
+    torch.set_num_threads(n)
+
+
 @pytest.fixture(scope="module")
 def tiny_sdxl(cuda_device):
     from sduss_amd.config import UNetConfig

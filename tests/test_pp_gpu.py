@@ -74,6 +74,26 @@ def test_two_ranks_equal_one_rank(cuda_device):
     assert ncalls > 40
 
 
+@pytest.mark.timeout(300)
+def test_four_ranks_equal_one_rank(cuda_device):
+    """the same with the latent rows over FOUR ranks sharing the test box's GPU (16 latent rows each: 4 x 16 = 64 tokens per image at the
+    deepest attention level, the smallest legal split)"""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dmax, scale, frac, oerr, oscale, ncalls = res[0]
+    print(f"patch-parallel x4 vs single rank: max diff {dmax:.5f} ({dmax / scale:.5f} of range); vs oracle {oerr / oscale:.4f} of range; {ncalls} exchanges")
+    assert dmax <= 0.03 * scale and oerr <= 0.04 * oscale and ncalls > 40
+
+
 def _stale_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -94,11 +114,18 @@ def _stale_worker(rank, world, port, q):
         want0, want1 = sync.forward(x0, *args), sync.forward(x1, *args)
         res = {}
         for mode in ("stale_gn", "corrected_async_gn"):
-            pp = PatchParallelUNet(net, mode=mode, warmup_steps=0)      # distrifuser: synchronous while counter <= warmup_steps -> one warm-up step
+            from sduss_amd.patch_parallel import CommLog
+            slog = CommLog()
+            pp = PatchParallelUNet(net, mode=mode, warmup_steps=0, log=slog)      # distrifuser: synchronous while counter <= warmup_steps -> one warm-up step
             a = pp.forward(x0, *args)                    # warm-up: synchronous, fills the state
             assert pp.last_step_mode == lib.PP_WARMUP
+            n_sync = len(slog.calls)
             b = pp.forward(x0, *args)                    # stale step on unchanged inputs: what it reads stale equals what is fresh
             assert pp.last_step_mode == lib.PP_STALE
+            stale_calls = slog.calls[n_sync:]
+            # a stale step coalesces its exchanges: <= 8 in-place asynchronous all-gathers over chunks of the state (pp_exchange.h; distrifuser
+            # flushes <= 60 tensors per all_gather, utils.py:184-205), no synchronous one
+            assert all(so == -1 for so, _ro, _nb in stale_calls) and 1 <= len(stale_calls) <= 8 < n_sync, (len(stale_calls), n_sync)
             c = pp.forward(x1, *args)                    # stale step on moved inputs: the other rank's rows lag one step
             d = pp.forward(x1, *args)                    # the inputs stop moving: the lag is gone one step later
             pp.reset()

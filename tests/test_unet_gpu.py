@@ -216,7 +216,8 @@ def test_denoising_step_mixed_resolutions_concurrent_equals_serial(tiny):
     ocfg, P, net = tiny
     cfg = UNetConfig.tiny()
     outs = []
-    for concurrent in (False, True):
+    net.mixed_one_sequence = False              # this test is about the per-resolution sequences on side streams (the single mixed sequence:
+    for concurrent in (False, True):            # tests/test_grouped_gpu.py)
         den = SDXLDenoiser(net, guidance_scale=5.0)
         den.concurrent_resolutions = concurrent
         reqs = {"128": [synthetic_request(0, 128, 6, cfg, den, "cuda:0")],
@@ -228,6 +229,7 @@ def test_denoising_step_mixed_resolutions_concurrent_equals_serial(tiny):
             den.denoising_step(reqs, is_sliced=True, patch_size=128)
         torch.cuda.synchronize()
         outs.append({k: torch.cat([r.latents for r in v]).float().cpu() for k, v in reqs.items()})
+    net.mixed_one_sequence = True
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), f"concurrent != serial at {k}"
 

@@ -19,19 +19,30 @@ KINDS = ["gemm128", "gemm64", "conv128", "conv64", "attn", "gnorm", "gemm_v2_160
 
 
 def main():
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    """argv[1]: requests at 1024 px (default 4), or a mix "a/b/c" of 512 / 768 / 1024 px requests; argv[2] = "serial": the mix as one launch
+    sequence per resolution, back to back (default: ONE mixed sequence)"""
+    arg = sys.argv[1] if len(sys.argv) > 1 else "4"
+    mix = tuple(int(v) for v in arg.split("/")) if "/" in arg else (0, 0, int(arg))
     dev = torch.device("cuda:0")
     cfg = UNetConfig.sdxl_base()
     net = MxUNet(cfg, synthetic_params(cfg, device=dev), device=dev)
     den = SDXLDenoiser(net)
+    if len(sys.argv) > 2 and sys.argv[2] == "serial":
+        net.mixed_one_sequence = False
+        den.concurrent_resolutions = False
     shared = {}
-    reqs = [synthetic_request(i, 1024, 50, cfg, den, dev, shared=shared) for i in range(batch)]
+    rid = 0
+    batch = {}
+    for res, n in zip((512, 768, 1024), mix):
+        if n:
+            batch[str(res)] = [synthetic_request(rid + i, res, 50, cfg, den, dev, shared=shared) for i in range(n)]
+            rid += n
     for _ in range(2):
-        den.denoising_step({"1024": reqs})
+        den.denoising_step(batch)
     torch.cuda.synchronize()
     l = lib.load()
     l.mx_profile_enable(1)
-    den.denoising_step({"1024": reqs})
+    den.denoising_step(batch)
     torch.cuda.synchronize()
     buf = (C.c_double * 64)()
     lib.check(l.mx_profile_collect(buf))
@@ -50,6 +61,10 @@ def main():
         tf = fl / (ms * 1e-3) / 1e12 if fl else 0.0
         print(f"{kind:11s} {m:7d} {nn:6d} {k:6d} {cnt:4d} {ms:8.3f} {100 * ms / tot:6.2f} {1e3 * ms / cnt:10.1f} {tf:8.1f}")
     print(f"total profiled {tot:.2f} ms")
+    per_kind = collections.OrderedDict()
+    for (kind, _m, _n, _k), (cnt, ms, _fl) in agg.items():
+        a = per_kind.setdefault(kind, [0, 0.0]); a[0] += cnt; a[1] += ms
+    print("per kind: " + ", ".join(f"{k} {v[0]} launches {v[1]:.2f} ms" for k, v in per_kind.items()))
 
 
 if __name__ == "__main__":
