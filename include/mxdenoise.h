@@ -244,6 +244,10 @@ int mx_rmsnorm(void* stream, const void* x, void* y, const float* w, int M, int 
  * (scale2, shift2) sharing the normalisation; x,y bf16 [M, C]; scale/shift fp32 rows with stride ldmod, b = row / rows_per_batch */
 int mx_layernorm_mod(void* stream, const void* x, void* y, void* y2, const float* scale, const float* shift,
                      const float* scale2, const float* shift2, int ldmod, int M, int C, int rows_per_batch, float eps);
+/* the same over a mixed batch: n groups of rows one after the other, group g = batches[g] samples of rows_per_batch[g] rows each; scale / shift
+ * rows are per sample in group order (one launch for the image stream of all resolutions, see mx_gemm_seg) */
+int mx_layernorm_mod_grouped(void* stream, const void* x, void* y, void* y2, const float* scale, const float* shift, const float* scale2,
+                             const float* shift2, int ldmod, int C, float eps, const int* batches, const int* rows_per_batch, int n);
 /* in-place RMSNorm over every 64-wide head of rows (b*batch_rows + row_off + i), i < rows_per_batch, of a bf16 [*, ld] matrix;
  * heads [0, heads_q) use weight wq[64], heads [heads_q, heads_total) use wk[64] (fp32) */
 int mx_rmsnorm_heads(void* stream, void* x, int ld, int nbatch, int rows_per_batch, int batch_rows, int row_off,
@@ -425,6 +429,13 @@ int mx_mmdit_forward_trace(mx_mmdit* u, void* stream, const void* latents, int i
                            const void* pooled, void* out, int batch, int H, int W, int ctx_len, void* workspace,
                            size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_out_bytes);
 
+/* Mixed-resolution batch for the SD3 / SD3.5 transformer, as mx_unet_forward_mixed: group g = the samples of one resolution ([batch, C, H, W]
+ * latents in, the same shape out); timesteps / encoder_hidden_states / pooled_projections are the rows of all groups in group order.  The
+ * reference re-chunks the tokens of all resolutions into one batch (modules/utils.py:86-122) and regroups them per latent before attention. */
+size_t mx_mmdit_workspace_bytes_mixed(const mx_mmdit* u, const mx_unet_group* groups, int n_groups, int ctx_len);
+int mx_mmdit_forward_mixed(mx_mmdit* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                           const void* encoder_hidden_states, const void* pooled_projections, int ctx_len, void* workspace, size_t workspace_bytes);
+
 /* Patch parallelism for the SD3 / SD3.5 transformer (distrifuser models/distri_sd3_transformer_pp.py:87-97: the positional embedding is taken
  * for the whole grid, then the image tokens are sliced by rank; modules/pp/attn.py:202-277: the joint attention keeps its local queries -- this
  * rank's image tokens and the text tokens -- and gathers the other ranks' image K / V; the text stream is computed by every rank).
@@ -518,10 +529,16 @@ int mx_t5_encode(mx_t5* t, void* stream, const int32_t* ids, void* out, int batc
  * first, the first-consumed one last, as res_hidden_states_tuple is ordered: cache_manager.py:110-121)] and answers
  * run / reuse per sample; a reused block's outputs (hidden state and, for the down blocks, the skip tensors) come from the cache.
  * Approximate by design and OFF on the exact path (mx_unet_forward never consults it).
- * Granularity: the step batch, as the reference's block-level caches -- a block's outputs come from the cache only when NO sample asks to run
- * it (save_and_get_block_states: mask.sum() == 0, cache_manager.py:60-67).  When a block runs here it runs for every sample; the reference
- * additionally drops the not-asking samples inside the block's attention layers (attention.py:104,224,415), a further approximation that is
- * not reproduced.  The cached state belongs to one batch composition: a different
+ * Granularity: the SAMPLE (a request's CFG row) -- the reference's unit when each latent is one patch (is_sliced False, unet.py:261-272: the
+ * caches are keyed by request id).  A block is skipped as a whole only when NO sample asks to run it (save_and_get_block_states:
+ * mask.sum() == 0, cache_manager.py:60-67).  When it runs, the samples that did not ask keep their cached outputs (UNet; round 3): the
+ * reference computes every op of a running block for the asking rows only and returns each op's cached output for the others
+ * (update_and_return, cache_manager.py:84-99; resnet.py:157-172, 414-454; attention.py:73-76, 104, 224), which for non-interacting samples is
+ * exactly "the block's outputs of a not-asking sample are its cached ones".  Here the block is evaluated for the whole batch and those rows
+ * are restored from the state, so the RESULT is the reference's; the arithmetic of the not-asking rows is not saved.  Not reproduced: with
+ * several patches per latent (is_sliced True) the reference's unit is the 256-px patch, and a stale patch also feeds its neighbours' halos,
+ * GroupNorm statistics and attention keys; the MMDiT entry keeps whole-block reuse (its text stream attends over partly stale image keys in
+ * the reference).  The cached state belongs to one batch composition: a different
  * batch_key, batch size or latent size invalidates it (every block runs once and refills it).  Not combined with patch parallelism.
  *   predict(ctx, block, is_up, n_samples, n_feat, timesteps[n], mse[n * n_feat], run_out[n]): mse = MX_MSE_UNCACHED when the block has no
  *   cached input; return non-zero to abort the forward.  The reference's predictors are cuML random forests that are not loadable here:

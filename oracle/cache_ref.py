@@ -38,3 +38,137 @@ class CacheManagerRef:
         self.previous_mask = {k: (0 if mask[i] == 1 or self.previous_mask[k] == self.forced_after else self.previous_mask[k] + 1)
                               for i, k in enumerate(new_indices)}             # :135 / :158
         return mask > 0.5, feature                        # :159
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The cached FORWARD: the seven block wrappers of modules/unet_2d_blocks.py around the oracle's blocks, with real tensors.
+# Restates, for the case of one patch per latent (is_sliced False: unet.py:261-272 keys every cache by request id, so a "patch" is a sample):
+#   * PatchCrossAttnDownBlock2D / PatchDownBlock2D (unet_2d_blocks.py:66-170): mask = input.get_mask(...); the body runs when mask.sum() != 0;
+#     output = save_and_get_block_states / _tupple (hidden state and the skip tensors the block emits);
+#   * PatchUNetMidBlock2DCrossAttn (:9-62);
+#   * PatchCrossAttnUpBlock2D / PatchUpBlock2D (:180-382): get_mask(..., is_upsample=True, res_tuple = the skips the block consumes);
+#   * inside a running block every Split* / Patch* op computes the asking rows and returns its own cached output for the others
+#     (cache_manager.py:84-99 update_and_return; resnet.py:157-172, 414-454; attention.py:73-76, 104, 224).  Samples do not interact inside a
+#     block (GroupNorm, attention and convolution are per sample), so op by op this gives, for a sample that did not ask, exactly the
+#     outputs the block produced for it at its last run -- restated here at block granularity, row by row.
+# The mse features are the reference's: nn.MSELoss(reduction='none')(cached, new).mean(dim=(-1, -2, -3)) per sample.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class CachedUNetRef:
+    """State across steps: per block the cached inputs / outputs per request id, and the decision managers."""
+
+    def __init__(self, P, cfg, down_predictor, up_predictor=None, forced_after=4):
+        import torch
+        from . import sdxl_unet_ref as ref
+        self.torch, self.ref = torch, ref
+        self.P = {k: v.to(torch.float32) for k, v in P.items()}
+        self.cfg = cfg
+        nlev = len(cfg.block_out_channels)
+        self.n_blocks = 2 * nlev + 1
+        up = up_predictor if up_predictor is not None else down_predictor
+        self.mgr = [CacheManagerRef(up if b > nlev else down_predictor, forced_after) for b in range(self.n_blocks)]
+        self.cin = [dict() for _ in range(self.n_blocks)]         # id -> cached input tensors (list: hidden state [, skips])
+        self.cout = [dict() for _ in range(self.n_blocks)]        # id -> cached output tensors (list: [skips..., ] hidden state)
+        self.blocks_run = []
+        self.features = []
+
+    def _gate(self, b, ids, timestep, ins):
+        """get_mask of block b on its input tensors `ins` ([B, ...] each); returns the run mask"""
+        torch = self.torch
+        n = len(ids)
+        mse = [[0.0] * len(ins) for _ in range(n)]
+        for i, k in enumerate(ids):
+            if k in self.cin[b]:
+                for j, t in enumerate(ins):
+                    mse[i][j] = float(((t[i] - self.cin[b][k][j]) ** 2).mean())
+        is_up = len(ins) > 1
+        mask, feat = self.mgr[b].get_mask(ids, [m[0] for m in mse], b, timestep, [m[1:] for m in mse] if is_up else None)
+        self.cin[b] = {k: [t[i].clone() for t in ins] for i, k in enumerate(ids)}        # the cached input is always the latest one (:133,153)
+        self.features.append(feat)
+        return mask
+
+    def _merge(self, b, ids, mask, outs):
+        """outputs of block b after a run with `mask`: rows that did not ask come from the cache; the cache then holds the merged rows
+        (update_and_return per op == per block for non-interacting samples; save_and_get_block_states :60-67)"""
+        torch = self.torch
+        merged = []
+        for j, t in enumerate(outs):
+            t = t.clone()
+            for i, k in enumerate(ids):
+                if not mask[i] and k in self.cout[b]:
+                    t[i] = self.cout[b][k][j]
+            merged.append(t)
+        self.cout[b] = {k: [t[i].clone() for t in merged] for i, k in enumerate(ids)}
+        return merged
+
+    def forward(self, ids, sample, timestep, encoder_hidden_states, text_embeds, time_ids):
+        torch, ref, P, cfg = self.torch, self.ref, self.P, self.cfg
+        import torch.nn.functional as F
+        x = sample.to(torch.float32)
+        ctx = encoder_hidden_states.to(torch.float32)
+        emb = ref.time_and_aug_embedding(P, cfg, timestep, text_embeds, time_ids)
+        ch = cfg.block_out_channels
+        nlev = len(ch)
+        x = F.conv2d(x, P["conv_in.weight"], P["conv_in.bias"], padding=1)
+        skips = [x]
+        ran = 0
+        tl = [float(t) for t in timestep]
+
+        def cached_outputs(b, n_out):
+            return [torch.stack([self.cout[b][k][j] for k in ids]) for j in range(n_out)]
+
+        for i in range(nlev):                                                # down blocks: unet_2d_blocks.py:66-170
+            b = i
+            mask = self._gate(b, ids, tl, [x])
+            n_out = cfg.layers_per_block + (1 if i != nlev - 1 else 0)
+            if mask.sum() != 0:
+                outs = []
+                for j in range(cfg.layers_per_block):
+                    x = ref.resnet_block(P, f"down_blocks.{i}.resnets.{j}", x, emb, cfg, None)
+                    if cfg.down_has_attn[i]:
+                        x = ref.transformer_2d(P, f"down_blocks.{i}.attentions.{j}", x, ctx, cfg.num_heads[i], cfg.transformer_layers_per_block[i], cfg, None)
+                    outs.append(x)
+                if i != nlev - 1:
+                    x = F.conv2d(x, P[f"down_blocks.{i}.downsamplers.0.conv.weight"], P[f"down_blocks.{i}.downsamplers.0.conv.bias"], stride=2, padding=1)
+                    outs.append(x)
+                outs = self._merge(b, ids, mask, outs)
+                ran |= 1 << b
+            else:
+                outs = cached_outputs(b, n_out)
+            skips.extend(outs)
+            x = outs[-1]
+        b = nlev                                                             # mid block: :9-62
+        mask = self._gate(b, ids, tl, [x])
+        if mask.sum() != 0:
+            top = nlev - 1
+            x = ref.resnet_block(P, "mid_block.resnets.0", x, emb, cfg, None)
+            x = ref.transformer_2d(P, "mid_block.attentions.0", x, ctx, cfg.num_heads[-1], cfg.transformer_layers_per_block[-1], cfg, None)
+            x = ref.resnet_block(P, "mid_block.resnets.1", x, emb, cfg, None)
+            x = self._merge(b, ids, mask, [x])[0]
+            ran |= 1 << b
+        else:
+            x = cached_outputs(b, 1)[0]
+        rev_attn, rev_layers, rev_heads = list(reversed(cfg.down_has_attn)), list(reversed(cfg.transformer_layers_per_block)), list(reversed(cfg.num_heads))
+        for i in range(nlev):                                                # up blocks: :180-382
+            b = nlev + 1 + i
+            n_res = cfg.layers_per_block + 1
+            res_tuple = skips[-n_res:]                                       # oldest first; the block consumes res_tuple[-1] first (:250-257)
+            skips = skips[:-n_res]
+            mask = self._gate(b, ids, tl, [x] + list(res_tuple))
+            if mask.sum() != 0:
+                res = list(res_tuple)
+                for j in range(n_res):
+                    x = torch.cat([x, res.pop()], dim=1)
+                    x = ref.resnet_block(P, f"up_blocks.{i}.resnets.{j}", x, emb, cfg, None)
+                    if rev_attn[i]:
+                        x = ref.transformer_2d(P, f"up_blocks.{i}.attentions.{j}", x, ctx, rev_heads[i], rev_layers[i], cfg, None)
+                if i != nlev - 1:
+                    x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+                    x = F.conv2d(x, P[f"up_blocks.{i}.upsamplers.0.conv.weight"], P[f"up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
+                x = self._merge(b, ids, mask, [x])[0]
+                ran |= 1 << b
+            else:
+                x = cached_outputs(b, 1)[0]
+        x = F.silu(F.group_norm(x, cfg.norm_num_groups, P["conv_norm_out.weight"], P["conv_norm_out.bias"], cfg.norm_eps))
+        x = F.conv2d(x, P["conv_out.weight"], P["conv_out.bias"], padding=1)
+        self.blocks_run.append(ran)
+        return x

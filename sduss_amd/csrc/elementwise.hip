@@ -500,6 +500,7 @@ int launch_sq_diff_partial(hipStream_t s, const void* a, const void* b, long ele
 // slotted[slot[i]]
 __global__ __launch_bounds__(256) void copy_rows_kernel(char* __restrict__ batch, char* __restrict__ slotted, long vecs, const int* __restrict__ slot, int scatter) {
   const int smp = blockIdx.y;
+  if (slot[smp] < 0) return;                   // a sample the copy does not concern (block cache: partial reuse inside a running block)
   u32x4* pb = reinterpret_cast<u32x4*>(batch) + (long)smp * vecs;
   u32x4* ps = reinterpret_cast<u32x4*>(slotted) + (long)slot[smp] * vecs;
   for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < vecs; v += (long)gridDim.x * 256) {

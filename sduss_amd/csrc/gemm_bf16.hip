@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs pk) {
 }
 
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
+int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn);
 int launch_v4(hipStream_t s, const GemmArgs& a);
 
 // Tile choice for the pipelined kernels.  Candidates (token rows x features): 256x256 (gemm_bf16_v3.hip), 256x160, 256x128,
@@ -421,7 +422,9 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   if (v2bn == 256) {
     launch_v4(s, a);                                           // 256 x 256 ping-pong (gemm_bf16_v4.hip)
   } else if (v2bn) {
-    launch_v2(s, a, conv, v2bn, tc.rows);
+    static const bool pingpong = [] { const char* e = getenv("MX_GEMM_V5"); return !(e && e[0] == '0'); }();   // A/B: 0 = the lock-step 256-row loop of gemm_v2
+    if (tc.rows == 256 && pingpong) launch_v5(s, a, conv, v2bn);        // 256-row tiles: ping-pong schedule (gemm_bf16_v5.hip)
+    else launch_v2(s, a, conv, v2bn, tc.rows);
   } else if (use128) {
     dim3 grid(mt128, d->N / 128);
     if (conv) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, block, 0, s, a);

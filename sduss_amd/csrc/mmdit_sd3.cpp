@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -62,7 +63,26 @@ struct Plan {
   mx_mmdit* u;
   hipStream_t stream;
   Arena ar;
-  int B, H, W, Lt;
+  int B, H, W, Lt;                 // B = samples of ALL groups; H, W = the first group's latent size (the only one unless mixed)
+  // Mixed-resolution batch (mx_mmdit_forward_mixed): the requests of every resolution present in ONE launch sequence.  A group = the samples of
+  // one resolution.  The image stream is the groups' token rows one after the other, the text stream is per sample (same length everywhere);
+  // the joint q|k / V^T / O buffers hold each group's [image ; text] sequences at its own length.  Per-token ops are single launches; the ops
+  // with per-sample structure -- AdaLN modulation, the q|k|v projections into the joint buffers, attention, the gated projections reading the
+  // joint sequence back -- are GROUPED launches (mx_gemm_seg, mx_attention_prescaled_grouped, mx_layernorm_mod_grouped).  The reference
+  // re-chunks the tokens of all resolutions into one batch (modules/utils.py:86-122) and regroups them per latent before attention
+  // (attention.py:300-372).
+  int ng = 1;
+  int gB[MX_MAX_SEGS], gH[MX_MAX_SEGS], gW[MX_MAX_SEGS], gb0[MX_MAX_SEGS];
+  const void* g_lat[MX_MAX_SEGS]; void* g_out[MX_MAX_SEGS];
+  void set_single(int batch, int h, int w, const void* lat, void* out) { ng = 1; gB[0] = batch; gH[0] = h; gW[0] = w; gb0[0] = 0; g_lat[0] = lat; g_out[0] = out; B = batch; H = h; W = w; }
+  typedef std::function<void(int, mx_gemm_seg&)> SegFill;      // fills problem g of a grouped GEMM
+  mx_gemm_seg seg_buf[MX_MAX_SEGS];
+  void attach(mx_gemm_desc& d, const SegFill& fill) {
+    if (ng <= 1 || !fill) return;
+    std::memset(seg_buf, 0, sizeof(seg_buf));
+    for (int g = 0; g < ng; ++g) fill(g, seg_buf[g]);
+    d.segs = seg_buf; d.n_segs = ng;
+  }
   bool dry, lookup = false;
   bool mute = false;               // block-skip cache: the block is reused, nothing of it is launched
   bool quiet() const { return dry || mute; }
@@ -131,28 +151,39 @@ struct Plan {
   // C = A W^T + bias with the optional fused pieces
   bool linear(const void* a, int lda, const std::string& name, void* c, int ldc, int M, int N, int K, int flags = 0,
               const void* residual = nullptr, int ldr = 0, const float* gate = nullptr, int ldg = 0, int rows_per_batch = 0,
-              int a_batch_rows = 0, int a_row_off = 0) {
+              int a_batch_rows = 0, int a_row_off = 0, const SegFill& fill = nullptr) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
     d.a = a; d.lda = lda; d.w = wb(name + ".weight", (size_t)N * K); d.bias = wf(name + ".bias", N);
     d.c = c; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.flags = flags; d.residual = residual; d.ldr = ldr;
     d.gate = gate; d.ldg = ldg; d.rows_per_batch = rows_per_batch; d.a_batch_rows = a_batch_rows; d.a_row_off = a_row_off;
+    attach(d, fill);
     return gemm(d);
   }
   // fused q|k|v projection of `rows_per_batch` tokens per sample into the joint buffers at row offset `row_off`; the epilogue
   // RMS-normalises every q / k head (norm_q / norm_k, attention.py:332-346, 377-388) and scales q for mx_attention_prescaled
   bool qkv(const void* a, const std::string& name, const std::string& qnorm, const std::string& knorm, bf16_t* qk, bf16_t* vt, int ldvt,
-           int M, int d_model, int rows_per_batch, int joint_rows, int row_off) {
+           int M, int d_model, int rows_per_batch, int joint_rows, int row_off, const SegFill& fill = nullptr) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
     d.a = a; d.lda = d_model; d.w = wb(name + ".weight", (size_t)3 * d_model * d_model); d.bias = wf(name + ".bias", 3 * d_model);
     d.c = qk; d.ldc = 2 * d_model; d.M = M; d.N = 3 * d_model; d.K = d_model; d.flags = MX_EPI_QKV | MX_EPI_RMSNORM; d.seg = d_model; d.period = 3;
     d.vt = vt; d.ldvt = ldvt; d.rows_per_batch = rows_per_batch; d.c_batch_rows = joint_rows; d.c_row_off = row_off;
     d.rms_wq = wf(qnorm, 64); d.rms_wk = wf(knorm, 64); d.rms_eps = u->cfg.norm_eps; d.out_scale = MX_ATTN_QSCALE(0.125f);
+    attach(d, fill);
     return gemm(d);
   }
+  // image: the rows are the image stream (per-group tokens per sample in a mixed batch); otherwise the text stream (Lt rows per sample)
   bool lnmod(const bf16_t* x, bf16_t* y, bf16_t* y2, const float* scale, const float* shift, const float* scale2,
-             const float* shift2, int ldmod, int M, int C, int rows_per_batch) {
+             const float* shift2, int ldmod, int M, int C, int rows_per_batch, bool image = false) {
     if (!ok()) return false;
     if (quiet()) return true;
+    if (image && ng > 1) {
+      int rpb[MX_MAX_SEGS];
+      const int ps = u->cfg.patch_size;
+      for (int g = 0; g < ng; ++g) rpb[g] = (gH[g] / ps) * (gW[g] / ps);
+      if (mx_layernorm_mod_grouped(stream, x, y, y2, scale, shift, scale2, shift2, ldmod, C, u->cfg.norm_eps, gB, rpb, ng))
+        return fail(std::string("layernorm_mod: ") + mx_last_error());
+      return true;
+    }
     if (mx_layernorm_mod(stream, x, y, y2, scale, shift, scale2, shift2, ldmod, M, C, rows_per_batch, u->cfg.norm_eps))
       return fail(std::string("layernorm_mod: ") + mx_last_error());
     return true;
@@ -194,7 +225,19 @@ struct Plan {
     const int ldvt_j = (MX_VT_LD(Lj) + 63) / 64 * 64;
     const int ldvt_i = (MX_VT_LD(L) + 63) / 64 * 64;
     const int Kp = ps * ps * c.in_channels;
-    const int MI = B * L, MT = B * Lt;
+    // per group (one unless the batch is mixed): image tokens per sample, joint sequence, V^T row lengths, first rows / elements of the group
+    // in the image stream, in the joint q|k / O buffers and in the two V^T buffers
+    int gL[MX_MAX_SEGS], gLj[MX_MAX_SEGS], gldj[MX_MAX_SEGS], gldi[MX_MAX_SEGS];
+    long r0[MX_MAX_SEGS], jr0[MX_MAX_SEGS], vj0[MX_MAX_SEGS], vi0[MX_MAX_SEGS];
+    long rows_i = 0, rows_j = 0, el_vj = 0, el_vi = 0;
+    for (int g = 0; g < ng; ++g) {
+      gL[g] = (gH[g] / ps) * (gW[g] / ps); gLj[g] = gL[g] + Lt;
+      gldj[g] = (MX_VT_LD(gLj[g]) + 63) / 64 * 64; gldi[g] = (MX_VT_LD(gL[g]) + 63) / 64 * 64;
+      r0[g] = rows_i; jr0[g] = rows_j; vj0[g] = el_vj; vi0[g] = el_vi;
+      rows_i += (long)gB[g] * gL[g]; rows_j += (long)gB[g] * gLj[g]; el_vj += (long)gB[g] * d * gldj[g]; el_vi += (long)gB[g] * d * gldi[g];
+    }
+    if (ng > 1 && (is_pp() || bc)) return fail("mmdit: a mixed-resolution batch runs neither patch-parallel nor through the block cache");
+    const int MI = (int)rows_i, MT = B * Lt;
     // patch-parallel: L counts this rank's image tokens; the keys of the joint attention are all ranks' image tokens, then the text tokens
     const int world = px.world;
     const int Ltot = L * world, Ljt = Ltot + Lt;
@@ -227,9 +270,16 @@ struct Plan {
 
     // ---- PatchEmbed + positional table (:82-83), context_embedder (:115) ----
     bf16_t* patches = alloc<bf16_t>((size_t)MI * Kp);
-    if (ok() && !dry && mx::launch_patchify(stream, latents, io_dtype, patches, B, c.in_channels, H, W, ps)) fail(mx_last_error());
-    bf16_t* pos = alloc<bf16_t>((size_t)Ltot * d);
-    {
+    for (int g = 0; g < ng && ok() && !dry; ++g)
+      if (mx::launch_patchify(stream, g_lat[g], io_dtype, patches + r0[g] * Kp, gB[g], c.in_channels, gH[g], gW[g], ps)) fail(mx_last_error());
+    bf16_t* pos = alloc<bf16_t>(ng > 1 ? (size_t)MI * d : (size_t)Ltot * d);      // (mixed: one cropped table per group, [L_g, d] at the group's first row)
+    if (ng > 1) {
+      const bf16_t* table = wb("pos_embed.table", (size_t)c.pos_embed_max_size * c.pos_embed_max_size * d);
+      for (int g = 0; g < ng && ok(); ++g) {
+        if (gH[g] / ps > c.pos_embed_max_size || gW[g] / ps > c.pos_embed_max_size) return fail("mmdit: latent larger than the positional table");
+        if (!dry && mx::launch_crop_pos(stream, table, pos + r0[g] * d, c.pos_embed_max_size, gH[g] / ps, gW[g] / ps, d)) fail(mx_last_error());
+      }
+    } else {
       // the centre crop is taken for the WHOLE grid (distri_sd3_transformer_pp.py:87 embeds before it slices); this rank reads its rows
       const bf16_t* table = wb("pos_embed.table", (size_t)c.pos_embed_max_size * c.pos_embed_max_size * d);
       if (h * world > c.pos_embed_max_size) return fail("mmdit: latent larger than the positional table");
@@ -237,7 +287,8 @@ struct Plan {
       if (pos) pos += (size_t)px.rank * L * d;
     }
     bf16_t* x = alloc<bf16_t>((size_t)MI * d);
-    linear(patches, Kp, "pos_embed.proj", x, d, MI, d, Kp, MX_EPI_RES_BCAST, pos, d, nullptr, 0, L);
+    linear(patches, Kp, "pos_embed.proj", x, d, MI, d, Kp, MX_EPI_RES_BCAST, pos, d, nullptr, 0, L, 0, 0, [&](int g, mx_gemm_seg& q) {
+      q.a = patches + r0[g] * Kp; q.c = x + r0[g] * d; q.residual = pos + r0[g] * d; q.M = gB[g] * gL[g]; q.rows_per_batch = gL[g]; });
     bf16_t* ctx = alloc<bf16_t>((size_t)MT * d);
     linear(ehs, c.joint_attention_dim, "context_embedder", ctx, d, MT, d, c.joint_attention_dim);
     dump("embed", x, (size_t)MI * d);
@@ -247,11 +298,11 @@ struct Plan {
     bf16_t* xin = alloc<bf16_t>((size_t)MI * d);
     bf16_t* x2in = alloc<bf16_t>((size_t)MI * d);
     bf16_t* cin = alloc<bf16_t>((size_t)MT * d);
-    bf16_t* qk_j = alloc<bf16_t>((size_t)B * Lj * 2 * d);
-    bf16_t* vt_j = alloc<bf16_t>((size_t)B * d * ldvt_j);
-    bf16_t* o_j = alloc<bf16_t>((size_t)B * Lj * d);
+    bf16_t* qk_j = alloc<bf16_t>((size_t)rows_j * 2 * d);
+    bf16_t* vt_j = alloc<bf16_t>((size_t)el_vj);
+    bf16_t* o_j = alloc<bf16_t>((size_t)rows_j * d);
     bf16_t* qk_i = alloc<bf16_t>((size_t)MI * 2 * d);
-    bf16_t* vt_i = alloc<bf16_t>((size_t)B * d * ldvt_i);
+    bf16_t* vt_i = alloc<bf16_t>((size_t)el_vi);
     bf16_t* o_i = alloc<bf16_t>((size_t)MI * d);
     bf16_t* ff = alloc<bf16_t>((size_t)MI * 4 * d);
     bf16_t* ffc = alloc<bf16_t>((size_t)MT * 4 * d);
@@ -353,34 +404,62 @@ struct Plan {
       const float* mi = mod + off_img[i];   // chunks: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp[, shift2, scale2, gate2]
       const float* mc = mod + off_ctx[i];
       // AdaLN-Zero(-X) on the image stream, AdaLN-Zero / -continuous on the context stream (transformer.py:316-328)
-      lnmod(x, xin, dual ? x2in : nullptr, mi + d, mi, dual ? mi + 7 * d : nullptr, dual ? mi + 6 * d : nullptr, ntot, MI, d, L);
+      lnmod(x, xin, dual ? x2in : nullptr, mi + d, mi, dual ? mi + 7 * d : nullptr, dual ? mi + 6 * d : nullptr, ntot, MI, d, L, true);
       if (last) lnmod(ctx, cin, nullptr, mc, mc + d, nullptr, nullptr, ntot, MT, d, Lt);        // continuous: (scale, shift)
       else lnmod(ctx, cin, nullptr, mc + d, mc, nullptr, nullptr, ntot, MT, d, Lt);
       // joint attention (attention.py:256-372): image rows first, then text rows
-      qkv(xin, b + ".attn.to_qkv", b + ".attn.norm_q.weight", b + ".attn.norm_k.weight", qk_j, vt_j, ldvt_j, MI, d, L, Lj, 0);
-      qkv(cin, b + ".attn.add_qkv", b + ".attn.norm_added_q.weight", b + ".attn.norm_added_k.weight", qk_j, vt_j, ldvt_j, MT, d, Lt, Lj, L);
+      // (mixed batch: group g's image rows go to rows [0, L_g) of its samples' joint sequences, the text rows behind them)
+      qkv(xin, b + ".attn.to_qkv", b + ".attn.norm_q.weight", b + ".attn.norm_k.weight", qk_j, vt_j, ldvt_j, MI, d, L, Lj, 0, [&](int g, mx_gemm_seg& q) {
+        q.a = xin + r0[g] * d; q.c = qk_j + jr0[g] * 2 * d; q.vt = vt_j + vj0[g]; q.M = gB[g] * gL[g]; q.rows_per_batch = gL[g]; q.ldvt = gldj[g];
+        q.c_batch_rows = gLj[g]; q.c_row_off = 0; });
+      qkv(cin, b + ".attn.add_qkv", b + ".attn.norm_added_q.weight", b + ".attn.norm_added_k.weight", qk_j, vt_j, ldvt_j, MT, d, Lt, Lj, L, [&](int g, mx_gemm_seg& q) {
+        q.a = cin + (long)gb0[g] * Lt * d; q.c = qk_j + jr0[g] * 2 * d; q.vt = vt_j + vj0[g]; q.M = gB[g] * Lt; q.rows_per_batch = Lt; q.ldvt = gldj[g];
+        q.c_batch_rows = gLj[g]; q.c_row_off = gL[g]; });
       if (is_pp()) {
         gather_kv(qk_j, vt_j, ldvt_j, Lt, ldvt_jt);
         attention_qk(qk_j, k_all, d, vt_all, ldvt_jt, o_j, heads, Lj, Ljt);
+      } else if (ng > 1) {
+        mx_attn_problem pr[MX_MAX_SEGS];
+        for (int g = 0; g < ng; ++g) {
+          pr[g].q = qk_j + jr0[g] * 2 * d; pr[g].k = qk_j + jr0[g] * 2 * d + d; pr[g].vt = vt_j + vj0[g]; pr[g].o = o_j + jr0[g] * d;
+          pr[g].vt_batch_stride = (int64_t)d * gldj[g]; pr[g].B = gB[g]; pr[g].Lq = gLj[g]; pr[g].Lk = gLj[g]; pr[g].ldvt = gldj[g];
+        }
+        if (ok() && !quiet() && mx_attention_prescaled_grouped(stream, pr, ng, 2 * d, 2 * d, d, heads)) fail(std::string("attention: ") + mx_last_error());
       } else
       attention(qk_j, d, vt_j, ldvt_j, o_j, heads, Lj);
       // x += gate_msa * to_out(attn[:, :L])                                   (transformer.py:344-345)
-      linear(o_j, d, b + ".attn.to_out.0", x, d, MI, d, d, 0, x, d, mi + 2 * d, ntot, L, Lj, 0);
+      linear(o_j, d, b + ".attn.to_out.0", x, d, MI, d, d, 0, x, d, mi + 2 * d, ntot, L, Lj, 0, [&](int g, mx_gemm_seg& q) {
+        q.a = o_j + jr0[g] * d; q.c = x + r0[g] * d; q.residual = x + r0[g] * d; q.gate = mi + 2 * d + (long)gb0[g] * ntot; q.M = gB[g] * gL[g];
+        q.rows_per_batch = gL[g]; q.a_batch_rows = gLj[g]; q.a_row_off = 0; });
       if (dual) {                                                             // attn2: image-only self-attention (:347-357)
-        qkv(x2in, b + ".attn2.to_qkv", b + ".attn2.norm_q.weight", b + ".attn2.norm_k.weight", qk_i, vt_i, ldvt_i, MI, d, L, 0, 0);
+        qkv(x2in, b + ".attn2.to_qkv", b + ".attn2.norm_q.weight", b + ".attn2.norm_k.weight", qk_i, vt_i, ldvt_i, MI, d, L, 0, 0, [&](int g, mx_gemm_seg& q) {
+          q.a = x2in + r0[g] * d; q.c = qk_i + r0[g] * 2 * d; q.vt = vt_i + vi0[g]; q.M = gB[g] * gL[g]; q.rows_per_batch = gL[g]; q.ldvt = gldi[g]; });
         if (is_pp()) {
           gather_kv(qk_i, vt_i, ldvt_i, 0, ldvt_it);
           attention_qk(qk_i, k_all, d, vt_all, ldvt_it, o_i, heads, L, Ltot);
+        } else if (ng > 1) {
+          mx_attn_problem pr[MX_MAX_SEGS];
+          for (int g = 0; g < ng; ++g) {
+            pr[g].q = qk_i + r0[g] * 2 * d; pr[g].k = qk_i + r0[g] * 2 * d + d; pr[g].vt = vt_i + vi0[g]; pr[g].o = o_i + r0[g] * d;
+            pr[g].vt_batch_stride = (int64_t)d * gldi[g]; pr[g].B = gB[g]; pr[g].Lq = gL[g]; pr[g].Lk = gL[g]; pr[g].ldvt = gldi[g];
+          }
+          if (ok() && !quiet() && mx_attention_prescaled_grouped(stream, pr, ng, 2 * d, 2 * d, d, heads)) fail(std::string("attention: ") + mx_last_error());
         } else
         attention(qk_i, d, vt_i, ldvt_i, o_i, heads, L);
-        linear(o_i, d, b + ".attn2.to_out.0", x, d, MI, d, d, 0, x, d, mi + 8 * d, ntot, L);
+        linear(o_i, d, b + ".attn2.to_out.0", x, d, MI, d, d, 0, x, d, mi + 8 * d, ntot, L, 0, 0, [&](int g, mx_gemm_seg& q) {
+          q.a = o_i + r0[g] * d; q.c = x + r0[g] * d; q.residual = x + r0[g] * d; q.gate = mi + 8 * d + (long)gb0[g] * ntot; q.M = gB[g] * gL[g];
+          q.rows_per_batch = gL[g]; });
       }
       // x += gate_mlp * ff(LN(x) * (1 + scale_mlp) + shift_mlp)               (:359-366)
-      lnmod(x, xin, nullptr, mi + 4 * d, mi + 3 * d, nullptr, nullptr, ntot, MI, d, L);
+      lnmod(x, xin, nullptr, mi + 4 * d, mi + 3 * d, nullptr, nullptr, ntot, MI, d, L, true);
       linear(xin, d, b + ".ff.net.0.proj", ff, 4 * d, MI, 4 * d, d, MX_EPI_GELU_TANH);
-      linear(ff, 4 * d, b + ".ff.net.2", x, d, MI, d, 4 * d, 0, x, d, mi + 5 * d, ntot, L);
+      linear(ff, 4 * d, b + ".ff.net.2", x, d, MI, d, 4 * d, 0, x, d, mi + 5 * d, ntot, L, 0, 0, [&](int g, mx_gemm_seg& q) {
+        q.a = ff + r0[g] * 4 * d; q.c = x + r0[g] * d; q.residual = x + r0[g] * d; q.gate = mi + 5 * d + (long)gb0[g] * ntot; q.M = gB[g] * gL[g];
+        q.rows_per_batch = gL[g]; });
       if (!last) {                                                            // context stream (:371-386)
-        linear(o_j, d, b + ".attn.to_add_out", ctx, d, MT, d, d, 0, ctx, d, mc + 2 * d, ntot, Lt, Lj, L);
+        linear(o_j, d, b + ".attn.to_add_out", ctx, d, MT, d, d, 0, ctx, d, mc + 2 * d, ntot, Lt, Lj, L, [&](int g, mx_gemm_seg& q) {
+          q.a = o_j + jr0[g] * d; q.c = ctx + (long)gb0[g] * Lt * d; q.residual = ctx + (long)gb0[g] * Lt * d; q.gate = mc + 2 * d + (long)gb0[g] * ntot;
+          q.M = gB[g] * Lt; q.rows_per_batch = Lt; q.a_batch_rows = gLj[g]; q.a_row_off = gL[g]; });
         lnmod(ctx, cin, nullptr, mc + 4 * d, mc + 3 * d, nullptr, nullptr, ntot, MT, d, Lt);
         linear(cin, d, b + ".ff_context.net.0.proj", ffc, 4 * d, MT, 4 * d, d, MX_EPI_GELU_TANH);
         linear(ffc, 4 * d, b + ".ff_context.net.2", ctx, d, MT, d, 4 * d, 0, ctx, d, mc + 5 * d, ntot, Lt);
@@ -391,12 +470,13 @@ struct Plan {
       if (cached && ok()) after(i, ran, last);
     }
     // ---- norm_out (AdaLN-continuous) + proj_out + unpatchify (SD3Transformer.py:238-259) ----
-    lnmod(x, xin, nullptr, mod + off_out, mod + off_out + d, nullptr, nullptr, ntot, MI, d, L);
+    lnmod(x, xin, nullptr, mod + off_out, mod + off_out + d, nullptr, nullptr, ntot, MI, d, L, true);
     const int No = ps * ps * c.out_channels;
     bf16_t* o = alloc<bf16_t>((size_t)MI * No);
     linear(xin, d, "proj_out", o, No, MI, No, d);
     dump("proj_out", o, (size_t)MI * No);
-    if (ok() && !dry && mx::launch_unpatchify(stream, o, outp, io_dtype, B, c.out_channels, H, W, ps, No)) fail(mx_last_error());
+    for (int g = 0; g < ng && ok() && !dry; ++g)
+      if (mx::launch_unpatchify(stream, o + r0[g] * No, g_out[g], io_dtype, gB[g], c.out_channels, gH[g], gW[g], ps, No)) fail(mx_last_error());
     if (stage && !dry && ok() && !stage_hit) fail(std::string("unknown stage '") + stage + "'");
     return ok();
   }
@@ -416,8 +496,18 @@ int check_cfg(const mx_mmdit_config* c) {
 int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
                  const void* pooled, void* out, int batch, int H, int W, int ctx_len, void* workspace, size_t workspace_bytes,
                  const char* stage, void* stage_out, size_t stage_bytes, bool dry, size_t* peak, bool lookup = false,
-                 const mx_pp_comm* comm = nullptr, const mx_pp_stale* stale = nullptr, size_t* state_need = nullptr) {
+                 const mx_pp_comm* comm = nullptr, const mx_pp_stale* stale = nullptr, size_t* state_need = nullptr,
+                 const mx_unet_group* groups = nullptr, int n_groups = 0) {
   MX_CHECK(u != nullptr, "mmdit: null handle");
+  if (groups) {        // mixed-resolution batch: `batch`, H, W describe the first group; every group is validated here
+    MX_CHECK(n_groups >= 1 && n_groups <= MX_MAX_SEGS && comm == nullptr, "mmdit: a mixed batch has 1..MX_MAX_SEGS resolution groups and does not run patch-parallel");
+    batch = groups[0].batch; H = groups[0].H; W = groups[0].W; latents = groups[0].latents; out = groups[0].out;
+    for (int g = 0; g < n_groups; ++g) {
+      MX_CHECK(groups[g].batch > 0 && groups[g].H > 0 && groups[g].W > 0 && groups[g].H % u->cfg.patch_size == 0 && groups[g].W % u->cfg.patch_size == 0 &&
+               groups[g].H / u->cfg.patch_size <= u->cfg.pos_embed_max_size && groups[g].W / u->cfg.patch_size <= u->cfg.pos_embed_max_size, "mmdit: bad group shape");
+      MX_CHECK(dry || (groups[g].latents && groups[g].out), "mmdit: null group operand");
+    }
+  }
   MX_CHECK(batch > 0 && H > 0 && W > 0 && ctx_len > 0, "mmdit: bad shape");
   MX_CHECK(H % u->cfg.patch_size == 0 && W % u->cfg.patch_size == 0, "mmdit: H, W must be multiples of patch_size");
   MX_CHECK(H / u->cfg.patch_size <= u->cfg.pos_embed_max_size && W / u->cfg.patch_size <= u->cfg.pos_embed_max_size, "mmdit: latent larger than the positional table");
@@ -432,7 +522,15 @@ int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, c
   size_t plan_peak = 0;
   auto enqueue = [&](hipStream_t s) {
     Plan p;
-    p.u = u; p.stream = s; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
+    p.u = u; p.stream = s; p.Lt = ctx_len;
+    p.set_single(batch, H, W, latents, out);
+    if (groups) {
+      p.ng = n_groups; p.B = 0;
+      for (int g = 0; g < n_groups; ++g) {
+        p.gB[g] = groups[g].batch; p.gH[g] = groups[g].H; p.gW[g] = groups[g].W; p.gb0[g] = p.B; p.g_lat[g] = groups[g].latents; p.g_out[g] = groups[g].out;
+        p.B += groups[g].batch;
+      }
+    }
     p.dry = dry; p.lookup = lookup; p.stage = stage; p.stage_out = stage_out; p.stage_bytes = stage_bytes;
     p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
     if (pp) p.px.set(comm, stale);
@@ -454,10 +552,13 @@ int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, c
   if (dry || stage || pp) {     // (the all-gather callbacks of a patch-parallel forward cannot be captured)
     okr = enqueue((hipStream_t)stream);
   } else {
-    const std::vector<uint64_t> key = {(uint64_t)batch, (uint64_t)H, (uint64_t)W, (uint64_t)ctx_len, (uint64_t)io_dtype,
-                                       (uint64_t)(uintptr_t)latents, (uint64_t)(uintptr_t)timesteps, (uint64_t)(uintptr_t)ehs,
-                                       (uint64_t)(uintptr_t)pooled, (uint64_t)(uintptr_t)out, (uint64_t)(uintptr_t)workspace,
-                                       (uint64_t)workspace_bytes, (uint64_t)(uintptr_t)u->blob};
+    std::vector<uint64_t> key = {(uint64_t)batch, (uint64_t)H, (uint64_t)W, (uint64_t)ctx_len, (uint64_t)io_dtype,
+                                 (uint64_t)(uintptr_t)latents, (uint64_t)(uintptr_t)timesteps, (uint64_t)(uintptr_t)ehs,
+                                 (uint64_t)(uintptr_t)pooled, (uint64_t)(uintptr_t)out, (uint64_t)(uintptr_t)workspace,
+                                 (uint64_t)workspace_bytes, (uint64_t)(uintptr_t)u->blob};
+    for (int g = 1; g < n_groups; ++g)
+      for (uint64_t v : {(uint64_t)groups[g].batch, (uint64_t)groups[g].H, (uint64_t)groups[g].W, (uint64_t)(uintptr_t)groups[g].latents, (uint64_t)(uintptr_t)groups[g].out})
+        key.push_back(v);
     okr = u->graphs.run((hipStream_t)stream, key, enqueue);
   }
   if (peak) *peak = plan_peak;
@@ -512,6 +613,24 @@ extern "C" int mx_mmdit_forward(mx_mmdit* u, void* stream, const void* latents, 
                       nullptr, nullptr, 0, false, nullptr);
 }
 
+/* ---- mixed-resolution batch: ONE launch sequence over the requests of every resolution present (see mx_unet_forward_mixed) ---- */
+extern "C" size_t mx_mmdit_workspace_bytes_mixed(const mx_mmdit* u, const mx_unet_group* groups, int n_groups, int ctx_len) {
+  if (!u || !groups || n_groups < 1 || n_groups > MX_MAX_SEGS) return 0;
+  size_t peak = 0;
+  if (forward_impl(const_cast<mx_mmdit*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, ctx_len, nullptr, 0, nullptr, nullptr, 0,
+                   true, &peak, false, nullptr, nullptr, nullptr, groups, n_groups))
+    return 0;
+  return peak + 4096;
+}
+
+extern "C" int mx_mmdit_forward_mixed(mx_mmdit* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                                      const void* encoder_hidden_states, const void* pooled_projections, int ctx_len, void* workspace,
+                                      size_t workspace_bytes) {
+  MX_CHECK(groups != nullptr, "mmdit_forward_mixed: null groups");
+  return forward_impl(u, stream, nullptr, io_dtype, timesteps, encoder_hidden_states, pooled_projections, nullptr, 0, 0, 0, ctx_len, workspace,
+                      workspace_bytes, nullptr, nullptr, 0, false, nullptr, false, nullptr, nullptr, nullptr, groups, n_groups);
+}
+
 /* ---- patch parallelism (distrifuser models/distri_sd3_transformer_pp.py, modules/pp/attn.py:202-277) ---- */
 extern "C" size_t mx_mmdit_workspace_bytes_pp(const mx_mmdit* u, int batch, int H_local, int W, int ctx_len, int world) {
   if (!u) return 0;
@@ -558,7 +677,7 @@ extern "C" size_t mx_mmdit_block_cache_bytes(const mx_mmdit* u, int batch, int H
   if (!u || batch <= 0 || H <= 0 || W <= 0 || ctx_len <= 0 || H % u->cfg.patch_size || W % u->cfg.patch_size) return 0;
   Plan p;
   mx_block_cache sizing{};
-  p.u = const_cast<mx_mmdit*>(u); p.stream = nullptr; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
+  p.u = const_cast<mx_mmdit*>(u); p.stream = nullptr; p.set_single(batch, H, W, nullptr, nullptr); p.Lt = ctx_len;
   p.dry = true; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
   p.bc = &sizing; p.bc_rows = batch;
   if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
@@ -597,7 +716,7 @@ extern "C" int mx_mmdit_forward_cached(mx_mmdit* u, void* stream, const void* la
   }
   p.bc_all_valid = true; p.bc_any_valid = false;
   for (int b = 0; b < batch; ++b) { p.bc_all_valid = p.bc_all_valid && p.bc_valid[b]; p.bc_any_valid = p.bc_any_valid || p.bc_valid[b]; }
-  p.u = u; p.stream = (hipStream_t)stream; p.B = batch; p.H = H; p.W = W; p.Lt = ctx_len;
+  p.u = u; p.stream = (hipStream_t)stream; p.set_single(batch, H, W, latents, out); p.Lt = ctx_len;
   p.dry = false;
   p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = false;
   p.bc = cache;

@@ -580,12 +580,15 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict
   if (lane == 0) *reinterpret_cast<f32x2*>(stats + (long)row * 8) = f32x2{s1, s2};     // one slab, row pitch 4 (mxdenoise.h)
 }
 
+// rows of a mixed batch: group g holds rows [r0[g], r0[g + 1]) with rpb[g] rows per sample, its first sample is b0[g] (n == 0: one group)
+struct RowGroups { int n; int r0[MX_MAX_SEGS + 1]; int rpb[MX_MAX_SEGS]; int b0[MX_MAX_SEGS]; };
+
 template <int VPL>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                             bf16_t* __restrict__ y2, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ scale2,
                                                             const float* __restrict__ shift2, int ldmod, int M, int C,
-                                                            int rows_per_batch, float eps) {
+                                                            int rows_per_batch, float eps, const RowGroups rg) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -620,7 +623,14 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const bf16_t* __rest
     }
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-  const long mrow = (long)(row / rows_per_batch) * ldmod;
+  int sample = row / rows_per_batch;
+  if (rg.n > 0) {                              // mixed batch: the row's group, then its sample inside the group
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < MX_MAX_SEGS; ++k) if (k < rg.n && row >= rg.r0[k]) g = k;
+    sample = rg.b0[g] + (row - rg.r0[g]) / rg.rpb[g];
+  }
+  const long mrow = (long)sample * ldmod;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int ch = lane + 64 * i;
@@ -694,22 +704,46 @@ __global__ __launch_bounds__(256) void rmsnorm_heads_kernel(bf16_t* __restrict__
 
 }  // namespace mx
 
-extern "C" int mx_layernorm_mod(void* stream, const void* x, void* y, void* y2, const float* scale, const float* shift,
-                                const float* scale2, const float* shift2, int ldmod, int M, int C, int rows_per_batch, float eps) {
+static int launch_layernorm_mod(void* stream, const void* x, void* y, void* y2, const float* scale, const float* shift, const float* scale2,
+                                const float* shift2, int ldmod, int M, int C, int rows_per_batch, float eps, const mx::RowGroups& rg) {
   using namespace mx;
   MX_CHECK(x && y && scale && shift, "layernorm_mod: null operand");
   MX_CHECK(!y2 || (scale2 && shift2), "layernorm_mod: second output needs scale2/shift2");
   MX_CHECK(C % 8 == 0 && C <= 64 * 8 * 8, "layernorm_mod: C must be a multiple of 8 and <= 4096");
-  MX_CHECK(rows_per_batch > 0 && M % rows_per_batch == 0 && ldmod % 4 == 0, "layernorm_mod: bad batch geometry");
+  MX_CHECK(rows_per_batch > 0 && (rg.n > 0 || M % rows_per_batch == 0) && ldmod % 4 == 0, "layernorm_mod: bad batch geometry");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(M, 4)), block(256);
   const int vpl = cdiv(C / 8, 64);
   const bf16_t* xp = (const bf16_t*)x; bf16_t* yp = (bf16_t*)y; bf16_t* y2p = (bf16_t*)y2;
-#define MX_LNMOD(V) hipLaunchKernelGGL((layernorm_mod_kernel<V>), grid, block, 0, s, xp, yp, y2p, scale, shift, scale2, shift2, ldmod, M, C, rows_per_batch, eps)
+#define MX_LNMOD(V) hipLaunchKernelGGL((layernorm_mod_kernel<V>), grid, block, 0, s, xp, yp, y2p, scale, shift, scale2, shift2, ldmod, M, C, rows_per_batch, eps, rg)
   if (vpl <= 1) MX_LNMOD(1); else if (vpl <= 2) MX_LNMOD(2); else if (vpl <= 3) MX_LNMOD(3); else if (vpl <= 4) MX_LNMOD(4); else MX_LNMOD(8);
 #undef MX_LNMOD
   MX_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mx_layernorm_mod(void* stream, const void* x, void* y, void* y2, const float* scale, const float* shift,
+                                const float* scale2, const float* shift2, int ldmod, int M, int C, int rows_per_batch, float eps) {
+  mx::RowGroups rg; rg.n = 0;
+  return launch_layernorm_mod(stream, x, y, y2, scale, shift, scale2, shift2, ldmod, M, C, rows_per_batch, eps, rg);
+}
+
+/* Mixed batch: the rows are n groups one after the other, group g = batches[g] samples of rows_per_batch[g] rows; the modulation rows
+ * (scale / shift, stride ldmod) are per sample in group order. */
+extern "C" int mx_layernorm_mod_grouped(void* stream, const void* x, void* y, void* y2, const float* scale, const float* shift,
+                                        const float* scale2, const float* shift2, int ldmod, int C, float eps, const int* batches,
+                                        const int* rows_per_batch, int n) {
+  MX_CHECK(batches && rows_per_batch && n >= 1 && n <= MX_MAX_SEGS, "layernorm_mod: grouped launch needs 1..MX_MAX_SEGS groups");
+  mx::RowGroups rg; rg.n = n;
+  int r = 0, b = 0;
+  for (int g = 0; g < n; ++g) {
+    MX_CHECK(batches[g] > 0 && rows_per_batch[g] > 0, "layernorm_mod: empty group");
+    rg.r0[g] = r; rg.rpb[g] = rows_per_batch[g]; rg.b0[g] = b;
+    r += batches[g] * rows_per_batch[g]; b += batches[g];
+  }
+  for (int g = n; g <= MX_MAX_SEGS; ++g) rg.r0[g] = r;
+  for (int g = n; g < MX_MAX_SEGS; ++g) { rg.rpb[g] = 1; rg.b0[g] = 0; }
+  return launch_layernorm_mod(stream, x, y, y2, scale, shift, scale2, shift2, ldmod, r, C, 1, eps, rg);
 }
 
 extern "C" int mx_rmsnorm_heads(void* stream, void* x, int ld, int nbatch, int rows_per_batch, int batch_rows, int row_off,

@@ -100,7 +100,9 @@ struct Plan {
   const int* bc_dslot = nullptr;  // device copy of bc->slots (null: sample i lives in row i)
   std::vector<unsigned char> bc_valid;   // per sample: the state holds its tensors of an earlier step
   bool bc_all_valid = false, bc_any_valid = false;
-  static size_t bc_scratch_bytes(int lpb, int rows) { return (((size_t)(lpb + 2) * rows * 64 * sizeof(double) + (size_t)rows * sizeof(int)) + 255) & ~(size_t)255; }
+  // head of the state: comparison partial sums, the slot table, the selection table of a partially reused block
+  static size_t bc_scratch_bytes(int lpb, int rows) { return (((size_t)(lpb + 2) * rows * 64 * sizeof(double) + 2 * (size_t)rows * sizeof(int)) + 255) & ~(size_t)255; }
+  int* bc_dsel() const { return (int*)((char*)bc->state + (size_t)(u->cfg.layers_per_block + 2) * bc_rows * 64 * sizeof(double) + (size_t)bc_rows * sizeof(int)); }
   // batch-ordered tensor <-> its rows in the state
   bool bc_store(char* region, const void* t, size_t per_sample_bytes) {
     if (bc_dslot) { if (mx::launch_copy_rows(stream, (void*)t, region, per_sample_bytes, B, bc_dslot, 1)) return fail(mx_last_error()); return true; }
@@ -730,6 +732,18 @@ struct Plan {
       if (bc->predict(bc->ctx, idx, is_up ? 1 : 0, B, nf, h_timesteps.data(), mse.data(), run.data())) { fail("block cache: the predictor failed"); return; }
       bool any = !bc_all_valid;                                  // a sample without cached tensors has nothing to reuse
       for (int b = 0; b < B; ++b) any = any || run[b] != 0;
+      // Partial reuse INSIDE a running block: a sample that did not ask keeps, for every op of the block, the output that op produced at the
+      // sample's last run (every Split* / Patch* module holds its own output cache and computes the asking rows only: resnet.py:157-172,
+      // 414-419, 449-454; attention.py:73-76, 104, 224; cache_manager.py:84-99 update_and_return).  Samples do not interact inside a block
+      // when each is one patch (is_sliced False: unet.py:261-272 keys the caches by request), so for them this is exactly "the block's
+      // outputs of a not-asking sample are the cached ones": the block runs for the batch and those rows are then restored from the state.
+      // (With several patches per latent the reference also feeds the stale patches' values into their neighbours' halos, GroupNorm
+      // statistics and attention keys: not reproduced -- the unit here is the sample.)
+      std::vector<int> sel(B, -1);
+      bool partial = false;
+      if (any) for (int b = 0; b < B; ++b) if (!run[b] && bc_valid[b]) { sel[b] = bc->slots ? bc->slots[b] : b; partial = true; }
+      if (partial && ok() && hipMemcpyAsync(bc_dsel(), sel.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess)
+        fail("block cache: sending the selection table failed");
       for (int f = 0; f < nf && ok(); ++f)                       // the cached input is always the latest one (cache_manager.py:133,153)
         bc_store(in_cache[f], ins[f].p, ins[f].per_sample * 2);
       const size_t n_skips0 = skips.size();
@@ -758,6 +772,7 @@ struct Plan {
           }
           bc->observe(bc->ctx, idx, B, om.data());
         }
+        if (any && partial && mx::launch_copy_rows(stream, o.p, oc, o.per_sample * 2, B, bc_dsel(), 0)) { fail(mx_last_error()); return; }
         if (any ? !bc_store(oc, o.p, o.per_sample * 2) : !bc_load(o.p, oc, o.per_sample * 2)) return;
       }
       if (any) blocks_run |= 1u << idx;

@@ -165,6 +165,8 @@ SYMBOLS = {
     "mx_unet_workspace_bytes_mixed": (_sz, [_vp, C.POINTER(UNetGroup), _i, _i]),
     "mx_unet_forward_mixed": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
     "mx_unet_forward_mixed_trace": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, C.c_char_p, _vp, _sz]),
+    "mx_mmdit_workspace_bytes_mixed": (_sz, [_vp, C.POINTER(UNetGroup), _i, _i]),
+    "mx_mmdit_forward_mixed": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _i, _vp, _sz]),
     "mx_unet_create": (_vp, [C.POINTER(UNetConfigC)]),
     "mx_unet_destroy": (None, [_vp]),
     "mx_unet_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),
@@ -189,6 +191,7 @@ SYMBOLS = {
     "mx_unet_pp_comm_plan": (_i, [_vp, _i, _i, _i, _i, C.POINTER(PPComm)]),
     "mx_attention_prescaled_chunked": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64]),
     "mx_layernorm_mod": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f]),
+    "mx_layernorm_mod_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _i]),
     "mx_rmsnorm_heads": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _f]),
     "mx_mmdit_create": (_vp, [C.POINTER(MMDiTConfigC)]),
     "mx_mmdit_destroy": (None, [_vp]),

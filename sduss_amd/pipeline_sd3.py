@@ -57,6 +57,7 @@ class SD3Denoiser:
         self.concurrent_resolutions = True
         self._streams: List[torch.cuda.Stream] = []
         self._cache = StepCache(transformer.device)
+        self._mixed_cond: Dict[tuple, tuple] = {}   # per mixed composition: the conditioning of all resolutions concatenated
 
     def set_timesteps(self, req: SD3Request) -> None:
         if req.num_inference_steps not in self._tables:
@@ -70,6 +71,10 @@ class SD3Denoiser:
         """One timestep for every request, in place; the resolutions of a mixed batch run on separate streams (see
         SDXLDenoiser.denoising_step)."""
         res_list = [r for r in sorted(runner_reqs.keys(), key=lambda r: int(r)) if runner_reqs[r]]           # :240-241
+        tr = self.transformer
+        if 1 < len(res_list) <= tr.max_mixed_groups and tr.mixed_one_sequence and getattr(tr, "_block_caches", None) is None:
+            self._step_mixed(res_list, runner_reqs, do_classifier_free_guidance)
+            return
         if len(res_list) <= 1 or not self.concurrent_resolutions:
             for res in res_list:
                 self._step_resolution(res, runner_reqs[res], do_classifier_free_guidance, is_sliced, patch_size)
@@ -90,6 +95,45 @@ class SD3Denoiser:
         for res in res_list:
             for r in runner_reqs[res]:
                 r.latents.record_stream(cur)
+
+    def _step_mixed(self, res_list: List[str], runner_reqs: Dict[str, List[SD3Request]], do_classifier_free_guidance: bool) -> None:
+        """All resolutions of the batch in ONE launch sequence (MxSD3Transformer.forward_mixed): the reference hands the transformer the dict
+        of all resolutions (:312-322) and re-chunks their tokens into one batch (SD3Transformer.py:86).  Rows: ascending resolution,
+        [uncond..., cond...] inside each (:240-241, 281-292)."""
+        here = torch.cuda.current_stream()
+        parts = []
+        for res in res_list:
+            reqs = runner_reqs[res]
+            for r in reqs:
+                r.latents.record_stream(here)
+
+            def build_cond(reqs=reqs):
+                if do_classifier_free_guidance:
+                    return (torch.cat([r.negative_prompt_embeds for r in reqs] + [r.prompt_embeds for r in reqs], dim=0),
+                            torch.cat([r.negative_pooled_prompt_embeds for r in reqs] + [r.pooled_prompt_embeds for r in reqs], dim=0))
+                return torch.cat([r.prompt_embeds for r in reqs], dim=0), torch.cat([r.pooled_prompt_embeds for r in reqs], dim=0)
+            e = self._cache.entry((res, do_classifier_free_guidance, tuple(r.request_id for r in reqs), tuple(id(r) for r in reqs)), reqs, build_cond)
+            lat = self._cache.latents(e, reqs)
+            sig, sig_next, ts = self._cache.step_scalars(e, reqs)
+            if do_classifier_free_guidance:
+                x_in, ts2 = ops.euler_scale_input(lat, torch.zeros_like(sig), 2 * len(reqs)), torch.cat([ts, ts], dim=0)
+            else:
+                x_in, ts2 = lat, ts
+            parts.append((reqs, e, lat, sig, sig_next, ts2, x_in))
+        key = tuple(id(p[1]) for p in parts)
+        hit = self._mixed_cond.get(key)
+        if hit is None or any(a is not b for a, b in zip(hit[0], [p[1] for p in parts])):
+            if len(self._mixed_cond) > 32:
+                self._mixed_cond.clear()
+            hit = self._mixed_cond[key] = ([p[1] for p in parts], tuple(torch.cat([p[1].cond[k] for p in parts], dim=0) for k in range(2)))
+        ehs, pooled = hit[1]
+        noise = self.transformer.forward_mixed([p[6] for p in parts], torch.cat([p[5] for p in parts]), ehs, pooled)
+        g = self.guidance_scale if do_classifier_free_guidance else 0.0
+        for (reqs, _e, lat, sig, sig_next, _ts, _x), nz in zip(parts, noise):
+            ops.cfg_flow_step_(nz, lat, sig, sig_next, g)
+            for i, r in enumerate(reqs):
+                r.step_index += 1
+                r.latents = lat[i:i + 1]
 
     def _step_resolution(self, res: str, reqs: List[SD3Request], do_classifier_free_guidance: bool, is_sliced: bool,
                          patch_size: int) -> None:

@@ -46,6 +46,8 @@ class MxSD3Transformer:
                                                   self.weights.table, len(self.weights.names)), "mx_mmdit_set_weights")
         self._ws_by_stream = {}
         self._ws_need = {}
+        self.mixed_one_sequence = True     # False: one launch sequence per resolution (the round-2 form; A/B and tests)
+        self.max_mixed_groups = _lib.MAX_SEGS
         self.config = _Config(in_channels=cfg.in_channels, patch_size=cfg.patch_size, sample_size=cfg.sample_size,
                               joint_attention_dim=cfg.joint_attention_dim, pooled_projection_dim=cfg.pooled_projection_dim)
 
@@ -113,6 +115,43 @@ class MxSD3Transformer:
                    "mx_mmdit_forward_trace")
         return st
 
+    def forward_mixed(self, latents, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor, pooled: torch.Tensor):
+        """ONE launch sequence over the latents of several resolutions (mx_mmdit_forward_mixed): ``latents[g]`` is [B_g, C, H_g, W_g]; the
+        conditioning rows are those of all groups concatenated in list order (SD3Transformer.py:86 re-chunks all resolutions into one batch)."""
+        assert 1 <= len(latents) <= _lib.MAX_SEGS
+        latents = [x.contiguous() for x in latents]
+        dt = latents[0].dtype
+        assert all(x.is_cuda and x.ndim == 4 and x.dtype == dt for x in latents)
+        btot = sum(x.shape[0] for x in latents)
+        lt = encoder_hidden_states.shape[1]
+        ts = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+        if ts.numel() == 1:
+            ts = ts.expand(btot)
+        ts = ts.contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        pp = pooled.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        assert ts.shape[0] == btot and ehs.shape[0] == btot and pp.shape == (btot, self.cfg.pooled_projection_dim)
+        outs = [torch.empty((x.shape[0], self.cfg.out_channels, x.shape[2], x.shape[3]), dtype=dt, device=self.device) for x in latents]
+        groups = (_lib.UNetGroup * len(latents))()
+        for g, (x, o) in enumerate(zip(latents, outs)):
+            groups[g].latents, groups[g].out = x.data_ptr(), o.data_ptr()
+            groups[g].batch, groups[g].H, groups[g].W = x.shape[0], x.shape[2], x.shape[3]
+        key = ("mixed", tuple((x.shape[0], x.shape[2], x.shape[3]) for x in latents), lt)
+        need = self._ws_need.get(key)
+        if need is None:
+            need = self._ws_need[key] = self._lib.mx_mmdit_workspace_bytes_mixed(self._handle, groups, len(latents), lt)
+        if need == 0:
+            raise _lib.MxError("mx_mmdit_workspace_bytes_mixed: " + self._lib.mx_last_error().decode())
+        stream = _lib.current_stream()
+        skey = int(stream or 0)
+        ws = self._ws_by_stream.get(skey)
+        if ws is None or ws.numel() < need:
+            self._ws_by_stream[skey] = None
+            ws = self._ws_by_stream[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.mx_mmdit_forward_mixed(self._handle, stream, groups, len(latents), _lib.torch_dtype_code(dt), ts.data_ptr(), ehs.data_ptr(),
+                                                    pp.data_ptr(), lt, ws.data_ptr(), ws.numel()), "mx_mmdit_forward_mixed")
+        return outs
+
     def forward(self, hidden_states: Dict[str, torch.Tensor], encoder_hidden_states: torch.Tensor = None,
                 pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None, block_controlnet_hidden_states=None,
                 joint_attention_kwargs=None, return_dict: bool = True, skip_layers=None, patch_size: int = None,
@@ -123,6 +162,9 @@ class MxSD3Transformer:
         keys = [k for k in hidden_states if hidden_states[k] is not None and hidden_states[k].shape[0] > 0]
         if not is_sliced:
             keys = keys[:1]   # the reference's unsliced branch runs the first resolution only (SD3Transformer.py:105-109)
+        if is_sliced and 1 < len(keys) <= _lib.MAX_SEGS and getattr(self, "_block_caches", None) is None and self.mixed_one_sequence:
+            res = self.forward_mixed([hidden_states[k] for k in keys], timestep, encoder_hidden_states, pooled_projections)
+            return (dict(zip(keys, res)),)
         for key in keys:
             x = hidden_states[key]
             n = x.shape[0]

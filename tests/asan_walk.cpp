@@ -93,6 +93,9 @@ int main() {
     REQUIRE(mx_mmdit_pp_state_bytes(m, 2, 128 / world, 128, 333, world) > 0);
   }
   REQUIRE(mx_mmdit_block_cache_bytes(m, 8, 128, 128, 333) > 0);
+  for (int i = 0; i < 3; ++i) { g[i].batch = 2 * (i + 1); g[i].H = g[i].W = res[i]; }
+  REQUIRE(mx_mmdit_workspace_bytes_mixed(m, g, 3, 333) > 0);
+  REQUIRE(mx_mmdit_workspace_bytes_mixed(m, g, 2, 333) > 0);
   mx_mmdit_destroy(m);
 
   // ---- VAE decoder, CLIP, T5 ----

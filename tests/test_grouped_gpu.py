@@ -367,3 +367,66 @@ def test_mixed_denoising_step_equals_per_resolution_steps(tiny):
         l2 = ((outs[0][k] - outs[1][k]).norm() / outs[1][k].norm()).item()
         print(f"mixed step {k}: rel L2 to the per-resolution steps {l2:.5f}")
         assert l2 <= 0.03
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# SD3 / SD3.5: the MMDiT step plan on a mixed batch (mx_mmdit_forward_mixed)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny_sd3(cuda_device):
+    from oracle import sd3_mmdit_ref as ref
+    from sduss_amd.config import MMDiTConfig
+    from sduss_amd.transformer_sd3 import MxSD3Transformer
+    ocfg = ref.MMDiTConfig.tiny()
+    P = ref.init_params(ocfg)
+    return ocfg, P, MxSD3Transformer(MMDiTConfig.tiny(), P, device="cuda:0")
+
+
+def test_mmdit_mixed_forward(tiny_sd3):
+    """{128, 256, 384} px in one launch sequence: AdaLN modulation, the q|k|v projections into per-group joint sequences, joint and dual
+    attention, the gated projections reading the joint sequence back and the positional tables are all per group.  Every request within the
+    single-forward tolerance of the oracle and close to the per-resolution sequence; one group alone is the ordinary forward bit for bit."""
+    from oracle import sd3_mmdit_ref as ref
+    ocfg, P, net = tiny_sd3
+    spec = [(1, 16), (2, 32), (1, 48)]
+    ins = [ref.make_inputs(ocfg, b, hw, seed=20 + i, ctx_len=21) for i, (b, hw) in enumerate(spec)]
+    for i, x in enumerate(ins):
+        x[1].fill_(701.0 - 200.0 * i)
+    cat = lambda k: torch.cat([x[k] for x in ins])
+    xs = [x[0].cuda().to(torch.bfloat16) for x in ins]
+    got = net.forward_mixed(xs, cat(1).cuda(), cat(2).cuda(), cat(3).cuda())
+    for i, (b, hw) in enumerate(spec):
+        lat, t, e, p = ins[i]
+        with torch.inference_mode():
+            want = ref.mmdit_forward(P, ocfg, lat, t, e, p)
+        alone = net.forward_one(xs[i], t.cuda(), e.cuda(), p.cuda()).float().cpu()
+        g_ = got[i].float().cpu()
+        l2 = ((g_ - want).norm() / want.norm()).item()
+        l2a = ((g_ - alone).norm() / want.norm()).item()
+        print(f"mmdit mixed forward: group {i} ({b} x {hw * 8} px): rel L2 to the oracle {l2:.4f}, to the per-resolution sequence {l2a:.4f}")
+        assert torch.isfinite(g_).all() and l2 <= 0.02 and (g_ - want).abs().max() <= 0.04 * want.abs().max() and l2a <= 0.02
+    one = net.forward_mixed([xs[1]], ins[1][1].cuda(), ins[1][2].cuda(), ins[1][3].cuda())[0]
+    assert torch.equal(one, net.forward_one(xs[1], ins[1][1].cuda(), ins[1][2].cuda(), ins[1][3].cuda()))
+
+
+def test_mmdit_mixed_denoising_step(tiny_sd3):
+    from sduss_amd.config import MMDiTConfig
+    from sduss_amd.pipeline_sd3 import SD3Denoiser, synthetic_sd3_request
+    ocfg, P, net = tiny_sd3
+    cfg = MMDiTConfig.tiny()
+    outs = []
+    for one in (True, False):
+        net.mixed_one_sequence = one
+        den = SD3Denoiser(net, guidance_scale=7.0)
+        reqs = {"128": [synthetic_sd3_request(0, 128, 6, cfg, den, "cuda:0", ctx_len=21)],
+                "256": [synthetic_sd3_request(1, 256, 6, cfg, den, "cuda:0", ctx_len=21), synthetic_sd3_request(2, 256, 8, cfg, den, "cuda:0", ctx_len=21)],
+                "384": [synthetic_sd3_request(3, 384, 6, cfg, den, "cuda:0", ctx_len=21)]}
+        for _ in range(3):
+            den.denoising_step(reqs, is_sliced=True, patch_size=128)
+        torch.cuda.synchronize()
+        outs.append({k: torch.cat([r.latents for r in v]).float().cpu() for k, v in reqs.items()})
+    net.mixed_one_sequence = True
+    for k in outs[0]:
+        l2 = ((outs[0][k] - outs[1][k]).norm() / outs[1][k].norm()).item()
+        print(f"sd3 mixed step {k}: rel L2 to the per-resolution steps {l2:.5f}")
+        assert l2 <= 0.03

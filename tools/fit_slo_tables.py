@@ -10,7 +10,8 @@
 
 Everything is measured through the HIP library on random-init weights of the real architectures, with the step counts of the reference's
 profiles (50 steps; the tables are per-stage totals, not per-step).  Outputs (profiles/): esymred_mi355x.json (the reference's file with its
-STANDALONE block replaced; Hyper_Parameter / DISCARD_SLACK copied from the values the reference ships), sm_util_<model>_<res>_mi355x.csv.
+STANDALONE block replaced; Hyper_Parameter / DISCARD_SLACK copied from the values the reference ships) and exec_time_mi355x/sm_util_<model>_<res>.csv
+-- the reference's file names, so that ESYMRED_EXEC_TIME_DIR can point at the directory (policy/ESyMReD.py:81, 105-118 reads the LAST column).
 
 Usage (GPU box): python tools/fit_slo_tables.py --out-dir gpurun_out/slo [--models sdxl,sd3] [--steps 10] [--max-batch 8]
 """
@@ -82,12 +83,14 @@ def main():
                 reqs = bench.make_batch(den, cfg, n, res, device, {}, base_id=res * 100 + n * 10)
                 step_s = timed(lambda: den.denoising_step({str(res): reqs}, is_sliced=False), args.steps)
                 lat = torch.randn(n, vcfg.latent_channels, res // 8, res // 8, device=device, dtype=torch.bfloat16)
-                post_s = timed(lambda: vae.decode(lat), 3)
+                # (the decoder's 128-channel full-resolution level indexes its activations with 32 bits: images go through it four at a time)
+                post_s = timed(lambda: [vae.decode(lat[k:k + 4]) for k in range(0, n, 4)], 3)
                 rows.append((10, STEPS_PER_LOOP * step_s, post_s))
                 print(f"{model} {res} px batch {n}: {1e3 * step_s:.2f} ms/step -> {STEPS_PER_LOOP * step_s:.3f} s per {STEPS_PER_LOOP}-step loop, "
                       f"VAE decode {1e3 * post_s:.1f} ms", flush=True)
                 del reqs, lat
-            with open(os.path.join(args.out_dir, f"sm_util_{model}_{res}_mi355x.csv"), "w") as f:
+            os.makedirs(os.path.join(args.out_dir, "exec_time_mi355x"), exist_ok=True)
+            with open(os.path.join(args.out_dir, "exec_time_mi355x", f"sm_util_{model}_{res}.csv"), "w") as f:
                 f.write("sm util, unet time, post time\n")          # header of exp/profile/sm_util_sdxl_1024.csv
                 for u, a, b in rows:
                     f.write(f"{u},{a},{b}\n")
