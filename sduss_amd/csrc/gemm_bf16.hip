@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs pk) {
 }
 
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
-int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn);
+int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
 int launch_v4(hipStream_t s, const GemmArgs& a);
 
 // Tile choice for the pipelined kernels.  Candidates (token rows x features): 256x256 (gemm_bf16_v3.hip), 256x160, 256x128,
@@ -209,13 +209,10 @@ static long rows_of(const mx_gemm_desc* d) {
   return m;
 }
 static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
-  static const bool disabled = [] { const char* e = getenv("MX_GEMM_V2"); return e && e[0] == '0'; }();
-  static const bool v3_disabled = [] { const char* e = getenv("MX_GEMM_256"); return e && e[0] == '0'; }();     // A/B: keep launches off the 256 x 256 kernel
-  static const bool small_disabled = [] { const char* e = getenv("MX_GEMM_ROWS128"); return e && e[0] == '0'; }();
-  static const double v3_discount = [] { const char* e = getenv("MX_V3_DISCOUNT"); return e ? atof(e) : 0.87; }();
+  constexpr double v3_discount = 0.87;          // measured advantage of the 256 x 256 ping-pong kernel per byte fetched (round 1 A/B sweeps)
   const TileChoice none = {0, 0};
   const long Mtot = rows_of(d);
-  if (disabled || Mtot < 128 || d->K < 128) return none;
+  if (Mtot < 128 || d->K < 128) return none;
   if (d->flags & MX_EPI_OUT_F32) return none;     // the register-exchange epilogue of the 256-row kernels writes bf16 only
   // their LDS-staged epilogue moves 16-byte pieces of C and of the residual
   if (d->ldc % 8 != 0 || ((uintptr_t)d->c & 15) != 0) return none;
@@ -241,8 +238,7 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   for (int c = 0; c < 5; ++c) {
     const int bn = cands[c].bn, rows = cands[c].rows;
     if (d->N % bn != 0 || Mtot < rows) continue;
-    if (bn == 256 && (conv || v3_disabled || !fits32 || d->a2 || d->ln_stats || d->stats_out)) continue;   // (built without those hooks)
-    if (rows == 128 && small_disabled) continue;
+    if (bn == 256 && (conv || !fits32 || d->a2 || d->ln_stats || d->stats_out)) continue;   // (built without those hooks)
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;
     if ((d->flags & MX_EPI_RMSNORM) && bn == 160) continue;   // a 64-wide head must lie inside one wave panel (gemm_epilogue_regs)
@@ -317,8 +313,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(!(d->flags & MX_EPI_RMSNORM) && d->a_batch_rows <= 0 && d->c_batch_rows <= 0 && !d->a2, "gemm: folded LayerNorm excludes RMSNORM, the row remaps and the split A operand");
     MX_CHECK((((uintptr_t)d->ln_stats & 15) | ((uintptr_t)d->ln_colsum & 15)) == 0, "gemm: ln_stats / ln_colsum must be 16-byte aligned");
   }
-  static const int xcd_map = [] { const char* e = getenv("MX_XCD_MAP"); return e ? atoi(e) : 1; }();
-  a.xcd_map = xcd_map;
+  a.xcd_map = 1;
 
   if (!conv && d->a2) {
     MX_CHECK(d->k_split > 0 && d->k_split < d->K && d->k_split % BK == 0, "gemm: k_split must be a multiple of 64 inside (0, K)");
@@ -422,8 +417,10 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   if (v2bn == 256) {
     launch_v4(s, a);                                           // 256 x 256 ping-pong (gemm_bf16_v4.hip)
   } else if (v2bn) {
-    static const bool pingpong = [] { const char* e = getenv("MX_GEMM_V5"); return !(e && e[0] == '0'); }();   // A/B: 0 = the lock-step 256-row loop of gemm_v2
-    if (tc.rows == 256 && pingpong) launch_v5(s, a, conv, v2bn);        // 256-row tiles: ping-pong schedule (gemm_bf16_v5.hip)
+    // 256-row tiles: ping-pong schedule (gemm_bf16_v5.hip).  128-row tiles (small M) stay on the lock-step loop of gemm_bf16_v2.hip: the
+    // ping-pong form is a tie there (same-box A/B, profiles/r03_d_gemm_bench_small_*: M2048 N1280 K1280 19.3 vs 19.2 us, conv B2 1280@32 98.9 vs
+    // 108.5 us) -- with half the MFMAs per K tile its L phase (5 LDS-DMA issues + 14 fragment reads) outlasts the M phase
+    if (tc.rows == 256) launch_v5(s, a, conv, v2bn, tc.rows);
     else launch_v2(s, a, conv, v2bn, tc.rows);
   } else if (use128) {
     dim3 grid(mt128, d->N / 128);

@@ -24,12 +24,6 @@
 #include "../../include/mxdenoise.h"
 #include "gemm_args.h"
 
-#ifndef MX_CONV_CMAJOR
-#define MX_CONV_CMAJOR 0   // 1: conv K tiles in channel-major order (experiment, see advance_cursor)
-#endif
-#ifndef MX_EXP
-#define MX_EXP 0   // tools/exp_build.sh: 1 = no MFMA, 2 = no LDS-DMA in the K loop, 3 = no fragment reads (diagnostics only)
-#endif
 
 namespace mx {
 
@@ -178,22 +172,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
       park_on_zero_page();
       return;
     }
-#if MX_CONV_CMAJOR
-    if constexpr (CONV) {
-      // K tiles in channel-major order (64-channel slice outermost, the nine taps inside): the nine shifted reads of one slice of the
-      // input follow each other, so they hit the XCD's L2 instead of being re-fetched per tap (tap-major: FETCH 4.9x algorithmic)
-      if (++tap_next == 9) {
-        tap_next = 0; ++in_tap;                 // in_tap counts channel slices here
-#pragma unroll
-        for (int i = 0; i < WI; ++i) wsrc[i] += BK2 * 2 - 8 * p.Cin * 2;
-      } else {
-#pragma unroll
-        for (int i = 0; i < WI; ++i) wsrc[i] += p.Cin * 2;
-      }
-      conv_set_tap(tap_next, in_tap * BK2 * 2);
-      return;
-    }
-#endif
 #pragma unroll
     for (int i = 0; i < WI; ++i) wsrc[i] += BK2 * 2;
     if constexpr (!CONV) {
@@ -262,20 +240,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
       else static_assert(INFLIGHT == 6 || INFLIGHT == 7 || INFLIGHT == 10 || INFLIGHT == 12, "counted wait");
       __builtin_amdgcn_s_barrier();
       bf16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
-#if MX_EXP == 3
-      for (int i = 0; i < NI; ++i) { wf0[i] = __builtin_bit_cast(bf16x8, acc[i][0]); wf1[i] = __builtin_bit_cast(bf16x8, acc[i][1]); }
-      for (int j = 0; j < MI; ++j) { xf0[j] = __builtin_bit_cast(bf16x8, acc[0][j]); xf1[j] = __builtin_bit_cast(bf16x8, acc[1][j]); }
-#else
       load_frags(stage, 0, wf0, xf0);
-#endif
       const int st2 = stage >= 1 ? stage - 1 : NSTAGE - 1;   // (g + NSTAGE - 1) % NSTAGE: last read in iteration g-1, which every wave has left
-#if MX_EXP != 2
       issue_group(st2);
-#endif
-#if MX_EXP != 3
       load_frags(stage, 1, wf1, xf1);
-#endif
-#if MX_EXP != 1
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -286,7 +254,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
-#endif
       __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);                 // fragment reads of k-step 0
 #pragma unroll
       for (int s = 0; s < LOADS; ++s) {
@@ -299,20 +266,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // fragment reads of k-step 1
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - LOADS - (NF + 1) / 2, 0);
-#if MX_EXP != 2
       advance_cursor();
-#endif
       stage = stage == NSTAGE - 1 ? 0 : stage + 1;
     }
 
     const int m0 = tm * BM2, n0 = tn * BN;
-#if MX_EXP == 4   // no epilogue: keep the accumulators alive with a store that never executes on real data
-    {
-      float t = 0.f;
-      for (int i = 0; i < NI; ++i) for (int j = 0; j < MI; ++j) for (int q = 0; q < 4; ++q) t += acc[i][j][q];
-      if (t == 12345.678f) reinterpret_cast<bf16_t*>(p.c)[m0 + n0] = f32_to_bf16(t);
-    }
-#else
     // register-exchange epilogue (gemm_args.h): no LDS, no barrier; the past-the-end DMAs are drained before the workgroup retires
     if (p.flags & MX_EPI_GEGLU) {
       if constexpr (NI % 4 == 0 && !CONV) gemm_epilogue_regs<NI, MI, true>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
@@ -320,22 +278,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
       gemm_epilogue_regs<NI, MI, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
   }
 }
 
-// bn: 160 or 128 features per tile; rows: 256, or 128 when the 256-row tiling would leave most CUs idle (small M)
+// bn: 160 or 128 features per tile.  This file serves the 128-row tiles (small M: one request, mixed batches); the 256-row tiles run the
+// ping-pong schedule of gemm_bf16_v5.hip (the lock-step 256-row instantiation it replaced: git history, A/B in profiles/r03_*gemm_bench*).
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows) {
-  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, rows)) * (a.N / bn);
+  (void)rows;
+  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, 128)) * (a.N / bn);
   dim3 grid(tiles), block(512);
-#define MX_V2(BN_, MI_) \
-  do { \
-    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<BN_, MI_, true>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((gemm_v2_kernel<BN_, MI_, false>), grid, block, 0, s, a); \
-  } while (0)
-  if (bn == 160) { if (rows == 256) MX_V2(160, 4); else MX_V2(160, 2); }
-  else { if (rows == 256) MX_V2(128, 4); else MX_V2(128, 2); }
-#undef MX_V2
+  if (bn == 160) {
+    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<160, 2, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_v2_kernel<160, 2, false>), grid, block, 0, s, a);
+  } else {
+    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<128, 2, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_v2_kernel<128, 2, false>), grid, block, 0, s, a);
+  }
   return 0;
 }
 

@@ -48,13 +48,12 @@ __device__ __forceinline__ void glds16_5(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_sched_barrier(0);            \
   } while (0)
 
-template <int BN, bool CONV>
+template <int BN, int MI, bool CONV>       // MI: 16-wide token blocks per wave; tile rows BM5 = 64 * MI (256, or 128 for small M)
 __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
-  constexpr int MI = 4;                       // 16-wide token blocks per wave (64 tokens)
-  constexpr int BM5 = 256;
+  constexpr int BM5 = 64 * MI;
   constexpr int NI = BN / 32;                 // 16-wide feature blocks per wave (BN / 2 features)
   constexpr int WCH = BN * 8;                 // 16-byte chunks of the W tile
-  constexpr int XI = BM5 * 8 / 512;           // X load instructions per thread per tile (4)
+  constexpr int XI = BM5 * 8 / 512;           // X load instructions per thread per tile (4, or 2 for the 128-row tile)
   constexpr int WI = (WCH + 511) / 512;       // W load instructions per thread per tile (3 for BN 160, 2 for 128)
   constexpr int LOADS = XI + WI;
   constexpr int STAGE_ELEMS = (BM5 + BN) * BK5;
@@ -63,7 +62,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1;                   // 0..3: token quarter; groups: wm 0-1 = A, wm 2-3 = B
+  const int wm = wave >> 1;                   // 0..3: token quarter of the tile; groups: wm 0-1 = A, wm 2-3 = B
   const int wn = wave & 1;
   const bool group_b = wave >= 4;
   GemmArgs p = pk;
@@ -191,8 +190,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   setup_tile();
   issue_group(0); advance_cursor();
   issue_group(1); advance_cursor();
-  if constexpr (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own part of K tile 0 landed
-  static_assert(LOADS == 6 || LOADS == 7, "counted wait");
+  auto wait_all_but_newest = [&]() __attribute__((always_inline)) {       // all of this thread's DMA groups but the youngest have landed
+    if constexpr (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (LOADS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    static_assert(LOADS >= 4 && LOADS <= 7, "counted wait");
+  };
+  wait_all_but_newest();                      // own part of K tile 0 landed
 
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
     const int st2 = stage >= 1 ? stage - 1 : NSTAGE5 - 1;      // (kt + 2) % 3: the stage of K tile kt - 1
     issue_group(st2);
     advance_cursor();
-    if constexpr (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own part of K tile kt + 1
+    wait_all_but_newest();                                      // own part of K tile kt + 1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the fragment reads have returned: the stage may be restaged one phase from now
     __builtin_amdgcn_sched_barrier(0);
     MX5_BAR();
@@ -250,14 +255,18 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the past-the-end DMAs are drained before the workgroup retires
 }
 
-int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn) {
-  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, 256)) * (a.N / bn);
+// bn: 160 or 128 features per tile; rows: 256, or 128 when the 256-row tiling would leave most CUs idle (small M)
+int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows) {
+  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, rows)) * (a.N / bn);
   dim3 grid(tiles), block(512);
-  if (bn == 160) {
-    if (conv) hipLaunchKernelGGL((gemm_v5_kernel<160, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_v5_kernel<160, false>), grid, block, 0, s, a);
-  } else {
-    if (conv) hipLaunchKernelGGL((gemm_v5_kernel<128, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_v5_kernel<128, false>), grid, block, 0, s, a);
-  }
+#define MX_V5(BN_, MI_) \
+  do { \
+    if (conv) hipLaunchKernelGGL((gemm_v5_kernel<BN_, MI_, true>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((gemm_v5_kernel<BN_, MI_, false>), grid, block, 0, s, a); \
+  } while (0)
+  (void)rows;                                 // (the 128-row instantiation MI = 2 was measured and is not built: see the dispatcher in gemm_bf16.hip)
+  if (bn == 160) MX_V5(160, 4); else MX_V5(128, 4);
+#undef MX_V5
   return 0;
 }
 

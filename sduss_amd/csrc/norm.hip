@@ -273,13 +273,12 @@ static int gn_geom(GnGeom& g, int B, int H, int W, int C, int patch) {
   if (g.L > 32) g.L = 32;
   // spatial tile: full rows of the image (or of the patch), about 256 pixels -- fewer at the small levels, where 256-pixel tiles leave
   // most CUs without a statistics block (8 images of 32 x 32: 32 blocks); halved until the launch has two blocks per CU
-  static const int tile_pix = [] { const char* e = getenv("MX_GN_TILE_PIX"); return e ? atoi(e) : 256; }();
+  constexpr int tile_pix = 256;
   int tw = (patch > 0) ? patch : W;
   int th = tile_pix / tw; if (th < 1) th = 1;
   const int hlim = (patch > 0) ? patch : H;
   while (hlim % th != 0) --th;
-  static const bool spread = [] { const char* e = getenv("MX_GN_SPREAD"); return !(e && e[0] == '0'); }();     // 0: the round-1 geometry (A/B)
-  while (spread && th > 1 && th * tw >= 64 && (long)B * (H / th) * (W / tw) < 2L * cu_count()) { th /= 2; while (hlim % th != 0) --th; }   // >= 32 pixels per tile
+  while (th > 1 && th * tw >= 64 && (long)B * (H / th) * (W / tw) < 2L * cu_count()) { th /= 2; while (hlim % th != 0) --th; }   // >= 32 pixels per tile
   g.th = th; g.tw = tw;
   if (patch > 0) MX_CHECK(H % patch == 0 && W % patch == 0, "groupnorm: H, W must be multiples of patch");
   g.tiles_y = H / th; g.tiles_x = W / tw;

@@ -741,3 +741,34 @@ def test_host_side_plans_under_address_and_ub_sanitizers():
     exe = os.path.join(ROOT, "build", "asan", "asan_walk")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert r.returncode == 0 and "ASAN_WALK_OK" in r.stdout, (r.stdout[-2000:] + r.stderr[-4000:])
+
+
+def test_slo_tables_for_mi355x_have_the_reference_formats():
+    """SURVEY 8f rank 3, second half: profiles/esymred_mi355x.json must load the way sduss/worker/scheduler/esymred_utils.py:14-43 loads
+    configs/esymred.json (STANDALONE denoising / postprocessing per model and resolution -> deadlines = (denoising [+ postprocessing]) * SLO),
+    and profiles/exec_time_mi355x/sm_util_<model>_<res>.csv the way policy/ESyMReD.py:105-118 reads the last column ("post time" per batch size)."""
+    import json
+    data = json.load(open(os.path.join(ROOT, "profiles", "esymred_mi355x.json")))
+    hp, standalone, discard = data["Hyper_Parameter"], data["STANDALONE"], data["DISCARD_SLACK"]
+    assert discard == 500 and hp["postprocessing_ratio"] == 0.9 and set(standalone) == {"sdxl", "sd3"}
+    slo = 5
+    for model in standalone:
+        den, post = standalone[model]["denoising"], standalone[model]["postprocessing"]
+        assert list(den) == list(post) == ["512", "768", "1024"]
+        ddl_post = {r: (den[r] + post[r]) * slo for r in den}          # esymred_utils.py:27-35
+        ddl_den = {r: den[r] * slo for r in den}                        # :37-43
+        assert 0 < ddl_den["512"] < ddl_den["768"] < ddl_den["1024"] < ddl_post["1024"]
+        assert den["1024"] < 3.7 if model == "sdxl" else den["1024"] < 5.92      # faster than the H100 values the reference ships (esymred.json:24-38)
+        for res in (512, 768, 1024):
+            path = os.path.join(ROOT, "profiles", "exec_time_mi355x", f"sm_util_{model}_{res}.csv")
+            rows = []
+            with open(path) as f:
+                first = True
+                for line in f:                                          # ESyMReD.py:109-118
+                    if first:
+                        first = False
+                        continue
+                    rows.append(float(line.strip().split(",")[-1]))
+            assert len(rows) == 8 and all(b > a > 0 for a, b in zip(rows, rows[1:])), (model, res, rows)
+            unet = [float(l.split(",")[1]) for l in open(path).read().strip().splitlines()[1:]]
+            assert abs(unet[0] - den[str(res)]) < 0.02 * den[str(res)] + 1e-3         # batch-1 row == the STANDALONE entry

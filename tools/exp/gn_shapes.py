@@ -1,5 +1,5 @@
 """NHWC GroupNorm(+SiLU) at the SDXL step's shapes (batch 8 and 2): time per call and HBM rate (3 passes over the tensor).
-MX_GN_TILE_PIX (default 256) = pixels per statistics tile, for the A/B of the tile geometry.  Usage: python tools/exp/gn_shapes.py"""
+(the MX_GN_TILE_PIX switch of the round-2 A/B is gone from the library: the tile is 256 pixels, halved until the launch has two blocks per CU).  Usage: python tools/exp/gn_shapes.py"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sduss_amd import lib

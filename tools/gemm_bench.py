@@ -1,5 +1,5 @@
 """GEMM / conv microbenchmark over the SDXL step shapes (random bf16 data), through the C ABI.
-Usage on the GPU box: MX_V2_VAR=1 python tools/gemm_bench.py"""
+Usage on the GPU box: python tools/gemm_bench.py   (SHAPES=small: the single-request shapes)"""
 import os
 import sys
 
@@ -44,7 +44,6 @@ def main():
         SHAPES = SMALL
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
-    print(f"MX_V2_VAR={os.environ.get('MX_V2_VAR', '0')} MX_GEMM_V2={os.environ.get('MX_GEMM_V2', '1')}")
     for kind, m, n, k in SHAPES:
         if kind == "conv":
             hw, cin = k
