@@ -40,14 +40,15 @@ STEPS_PER_IMAGE = 50
 MFMA_PEAK_BF16 = 2.5e15                    # dense, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<128,true> (conv3x3)",
-              "gemm_kernel<64,true> (conv3x3)", "attn_fwd_kernel", "groupnorm (3 kernels)", "gemm_v2_kernel<160,false>",
-              "gemm_v2_kernel<160,true> (conv3x3)", "gemm_v2_kernel<128,false>", "gemm_v2_kernel<128,true> (conv3x3)",
+              "gemm_kernel<64,true> (conv3x3)", "attn_fwd_kernel", "groupnorm (3 kernels)", "gemm_v5/v2_kernel<160,false>",
+              "gemm_v5/v2_kernel<160,true> (conv3x3)", "gemm_v5/v2_kernel<128,false>", "gemm_v5/v2_kernel<128,true> (conv3x3)",
               "gemm_v4_kernel (256x256 ping-pong)", "attn_cross_kernel (Lk<=96)"]
 
 
 KIND_SYMBOLS = {  # bench kernel label -> regex over the symbols in the rocprofv3 summaries (all instantiations of the kind)
-    "gemm_v2_kernel<160,false>": r"mx::gemm_v2_kernel<160, \d+, false", "gemm_v2_kernel<160,true> (conv3x3)": r"mx::gemm_v2_kernel<160, \d+, true",
-    "gemm_v2_kernel<128,false>": r"mx::gemm_v2_kernel<128, \d+, false", "gemm_v2_kernel<128,true> (conv3x3)": r"mx::gemm_v2_kernel<128, \d+, true",
+    # (the 160- and 128-feature kinds are served by gemm_v5_kernel for 256-row tiles and gemm_v2_kernel for 128-row tiles: one kind, both symbols)
+    "gemm_v5/v2_kernel<160,false>": r"mx::gemm_v[25]_kernel<160, \d+, false", "gemm_v5/v2_kernel<160,true> (conv3x3)": r"mx::gemm_v[25]_kernel<160, \d+, true",
+    "gemm_v5/v2_kernel<128,false>": r"mx::gemm_v[25]_kernel<128, \d+, false", "gemm_v5/v2_kernel<128,true> (conv3x3)": r"mx::gemm_v[25]_kernel<128, \d+, true",
     "gemm_v4_kernel (256x256 ping-pong)": r"mx::gemm_v[34]_kernel<", "attn_fwd_kernel": r"mx::attn_fwd", "attn_cross_kernel (Lk<=96)": r"mx::attn_cross_kernel",
 }
 
@@ -549,6 +550,14 @@ def main():
                 blk["kernels"], roof3 = roofline_leg(step3, "sd3")
                 if roof3:
                     blk["roofline"] = roof3
+            if args.mix > 0:            # configs[4] for the second model: a short mixed-resolution stream through the MMDiT's single launch sequence
+                rows3, win3 = run_mix(den3, cfg3, args, device, {}, 1.0, max(8, args.mix // 2), 0, 1, "sd3")
+                lat3 = [l for _r, l in rows3]
+                ok3 = sum(1 for r, l in rows3 if l <= REF_DEADLINES_S["sd3"][int(r)])
+                blk["mixed_stream"] = {"offered_req_per_s_per_gpu": 1.0, "requests": len(rows3), "slo_rate": ok3 / len(rows3),
+                                       "p50_latency_s": float(np.percentile(lat3, 50)), "p90_latency_s": float(np.percentile(lat3, 90)),
+                                       "goodput_req_per_s": ok3 / (win3[1] - win3[0]), "throughput_req_per_s": len(rows3) / (win3[1] - win3[0]),
+                                       "policy": "FCFS mixed batching, is_sliced=True / patch 256, the resolutions of a step in ONE launch sequence"}
             result["sd3"] = blk
             del step3, den3, net3, reqs3
             torch.cuda.empty_cache()

@@ -93,6 +93,14 @@ __device__ unsigned long long g_v4_sums[256 * 8 * 16];
 #define MX_TWAIT() do {} while (0)
 #endif
 
+#if MX_EXP == 8   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime) per workgroup and tile, read back by tools/exp/timeline_v4.py
+__device__ unsigned long long g_v4_stamps[256 * 2 * 64];
+#define MX_STAMP(slot) do { if (lane == 0 && (wave == 0 || wave == 7) && (slot) < 64) \
+    g_v4_stamps[(blockIdx.x * 2 + (wave == 7)) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MX_STAMP(slot) do {} while (0)
+#endif
+
 template <bool VEC>
 __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   constexpr int NI = 4;                        // 16-wide feature blocks per wave (64 features)
@@ -111,6 +119,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   const char* abase = reinterpret_cast<const char*>(pk.a);   // grouped: the lowest of the problems' bases (launch_v4 checks the 32-bit reach)
   const char* wbase = reinterpret_cast<const char*>(pk.w);
   const int cs = tid & 7;
+  MX_STAMP(0);
+  [[maybe_unused]] int stamp_i = 1;
 
   // ---- issue side: four cursors, one per half-tile kind (0 XH0, 1 WH0, 2 WH1, 3 XH1 = stream order inside a K tile).  Cursor c
   //      points at the next (tile, K tile) of its kind, holds ready-made per-thread byte offsets (the chooser guarantees they fit
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
     const float ln_rstd[MI] = {};              // (no folded LayerNorm in this kernel: pick_tile, gemm_bf16.hip)
 
     if (wm == 1) MX_BAR();                     // wave row 1 runs one barrier behind row 0
+    MX_STAMP(stamp_i);
 
     // one K tile; HOT: no cursor leaves its tile during this iteration (plain pointer increments, no control flow)
     auto k_tile = [&](auto hot_tag) __attribute__((always_inline)) {
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
 #if MX_EXP == 7
     t_prev_end = 0;
 #endif
+    MX_STAMP(stamp_i + 1);
     if (wm == 0) MX_BAR();                     // re-align the two wave rows
 
     int tm, tn;
@@ -327,6 +339,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
     const int m0 = tm * BM4, n0 = tn * BN4;
     if (p.flags & MX_EPI_GEGLU) gemm_epilogue_regs<NI, MI, true, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
     else gemm_epilogue_regs<NI, MI, false, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
+    MX_STAMP(stamp_i + 2);
+    stamp_i += 3;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end DMAs before the workgroup retires
 #if MX_EXP == 7
@@ -335,6 +349,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
 #endif
 }
 
+#if MX_EXP == 8
+extern "C" int mx_debug_v4_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v4_stamps), sizeof(g_v4_stamps)); }
+#endif
 #if MX_EXP == 7
 extern "C" int mx_debug_v4_sums(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v4_sums), sizeof(g_v4_sums)); }
 #endif

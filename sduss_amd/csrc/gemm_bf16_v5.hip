@@ -48,6 +48,15 @@ __device__ __forceinline__ void glds16_5(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_sched_barrier(0);            \
   } while (0)
 
+#if defined(MX_EXP) && MX_EXP == 8   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime) per workgroup, read back by tools/exp/timeline_v4.py
+__device__ unsigned long long g_v5_stamps[1024 * 2 * 4];
+#define MX5_STAMP(slot) do { if (lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < 1024) \
+    g_v5_stamps[(blockIdx.x * 2 + (wave == 7)) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int mx_debug_v5_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v5_stamps), sizeof(g_v5_stamps)); }
+#else
+#define MX5_STAMP(slot) do {} while (0)
+#endif
+
 template <int BN, int MI, bool CONV>       // MI: 16-wide token blocks per wave; tile rows BM5 = 64 * MI (256, or 128 for small M)
 __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   constexpr int BM5 = 64 * MI;
@@ -65,6 +74,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   const int wm = wave >> 1;                   // 0..3: token quarter of the tile; groups: wm 0-1 = A, wm 2-3 = B
   const int wn = wave & 1;
   const bool group_b = wave >= 4;
+  MX5_STAMP(0);
   GemmArgs p = pk;
   int tm, tn;
   gemm_tile_of_block(blockIdx.x, gemm_m_tiles(pk, BM5), pk.N / BN, pk.xcd_map, tm, tn);
@@ -212,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   }
   MX5_BAR();                                  // every wave's part of K tile 0 has landed
   if (group_b) MX5_BAR();                     // group B runs one barrier behind group A
+  MX5_STAMP(1);
 
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -244,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
     MX5_BAR();
     stage = stage == NSTAGE5 - 1 ? 0 : stage + 1;
   }
+  MX5_STAMP(2);
   if (!group_b) MX5_BAR();                    // re-align the two groups
 
   const int m0 = tm * BM5, n0 = tn * BN;
@@ -252,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   } else {
     gemm_epilogue_regs<NI, MI, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
   }
+  MX5_STAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the past-the-end DMAs are drained before the workgroup retires
 }
 

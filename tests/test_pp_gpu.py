@@ -25,6 +25,7 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(8)                 # several ranks share the host: 128 torch threads each made the world-4 run take 190 s
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import sdxl_unet_ref as ref
@@ -96,6 +97,7 @@ def test_four_ranks_equal_one_rank(cuda_device):
 
 def _stale_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(8)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import sdxl_unet_ref as ref
@@ -179,6 +181,7 @@ def test_stale_async_steps(cuda_device):
 
 def _sd3_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(8)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import sd3_mmdit_ref as ref
