@@ -25,8 +25,11 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {     // one v_cvt_pk_bf16_f32 (round to nearest even, as the scalar cast)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
@@ -48,10 +51,30 @@ __device__ __forceinline__ float erf_as(float x) {
 // tanh-approximated GELU (torch F.gelu(approximate="tanh")): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2u)
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));    // (v_rcp_f32, 1 ulp: the IEEE division sequence is ~10 instructions per element)
 }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// GELU (erf form) by Abramowitz-Stegun 7.1.28: erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16 (z >= 0, |abs err| <= 3e-7), so
+//   gelu(x) = x (1 - h) for x >= 0 and x h for x < 0, with h = 0.5 / poly(|x| / sqrt 2)^16
+// -- ONE transcendental (v_rcp) per element instead of the two of 7.1.26 (rcp + exp), and a plain polynomial that the two-element form
+// runs on packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32).  Measured against the float64 erf form: |abs err| <= 7.1e-7 over
+// [-12, 12] (7.1.26: 4.6e-7); the GEGLU epilogue evaluates it for every FF1 output element and was VALU-bound on it (round 3,
+// tools/exp/timeline_v4.py).
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2 gelu_fast2(const gelu_f32x2 x) {
+  const gelu_f32x2 ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+  gelu_f32x2 p = ax * 0.0000430638f + 0.0002765672f;
+  p = p * ax + 0.0001520143f;
+  p = p * ax + 0.0092705272f;
+  p = p * ax + 0.0422820123f;
+  p = p * ax + 0.0705230784f;
+  p = p * ax + 1.0f;
+  p = p * p; p = p * p; p = p * p; p = p * p;              // ^16 (overflow -> inf -> h = 0: erf = 1)
+  const gelu_f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+  const gelu_f32x2 xh = x * (r * 0.5f);
+  return gelu_f32x2{x[0] >= 0.f ? x[0] - xh[0] : xh[0], x[1] >= 0.f ? x[1] - xh[1] : xh[1]};
+}
+__device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(gelu_f32x2{x, x})[0]; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -378,7 +378,17 @@ __device__ __forceinline__ u32x4 lane_xor1(const u32x4 x) {
 // VPF: per-sample vectors are loaded one token block ahead (costs 8 * NIO registers; off in the persistent 256 x 256 kernel)
 // STATS: can write row statistics (stats_out) and apply the folded LayerNorm's rstd (ln_rstd_a); off in the 256 x 256 kernels, whose
 // register budget is spent (pick_tile keeps launches with ln_stats / stats_out away from them)
-template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true>
+// FEAT: which of the runtime-selected epilogue features are COMPILED IN (the launcher picks the smallest instantiation that serves the
+// launch's flags).  Round 3 (tools/exp/timeline_v4.py): with every feature behind a runtime branch the 256 x 256 kernel was 164 KB of code
+// -- 2.5 instruction caches -- and a plain bias-only epilogue took 14 us per tile of branching through it.
+constexpr int EPI_F_QKV = 1;                  // MX_EPI_QKV (segmented output, V^T, RMSNorm of the heads)
+constexpr int EPI_F_ACT = 2;                  // MX_EPI_SILU / GELU / GELU_TANH / QUICK_GELU
+constexpr int EPI_F_ALL = 3;
+__host__ __device__ inline int gemm_epi_features(int flags) {
+  return ((flags & MX_EPI_QKV) ? EPI_F_QKV : 0) |
+         ((flags & (MX_EPI_SILU | MX_EPI_GELU | MX_EPI_GELU_TANH | MX_EPI_QUICK_GELU | MX_EPI_GEGLU_TANH)) ? EPI_F_ACT : 0);
+}
+template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true, int FEAT = EPI_F_ALL>
 __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
                                                    const int fr, const int fq, const float (&ln_rstd_a)[MI]) {
   constexpr int NIO = GEGLU ? NI / 2 : NI;     // output blocks per wave
@@ -387,7 +397,8 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   constexpr int DEPTH = 2;                     // residual loads run this many token blocks ahead
   static_assert(!GEGLU || NI % 4 == 0, "GEGLU: hidden and gate halves must be whole pairs");
   const int flags = p.flags;
-  const bool qkv = (flags & MX_EPI_QKV) != 0;
+  constexpr bool ACT = (FEAT & EPI_F_ACT) != 0;
+  const bool qkv = (FEAT & EPI_F_QKV) != 0 && (flags & MX_EPI_QKV) != 0;
   int seg_idx = 0, seg_grp = 0, seg_pos = 0;
   bool to_vt = false;
   if (qkv) {                                   // the wave's feature range lies inside one segment (seg % (16 NI) == 0)
@@ -419,29 +430,60 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   // and acc * 1 + bias is acc + bias exactly)
   const bool stats = STATS && !GEGLU && !qkv && p.stats_out != nullptr;
 
-  // row addressing of token block j: accumulator layout (token = lane & 15) and row layout are the same token
+  // ---- rows.  Lane (fr, fq) holds token m_j = m_wave0 + 16 j + fr of token block j; its lane pair (fr ^ 1) holds tokens A_j = m_j & ~1 and
+  //      B_j = A_j + 1.  A token is (batch b, row r inside the batch): m = b * rows_per_batch + r, and its output row is b * c_batch_rows +
+  //      c_row_off + r (joint-sequence remap; without it the row is m).  ONE integer division per lane finds (b, r) of A_0; every later
+  //      token is 16 rows further, a compare-and-wrap (the launcher keeps rows_per_batch == 0 or >= 16: pick_tile).  Round 3: the
+  //      divisions, 64-bit multiplies and selects of the per-block form were most of the epilogue's 4 000 instructions per wave.
+  //      Tokens past M take the row of token M - 1: loads stay in bounds and need no branch, stores are masked by m < M. ----
+  const bool odd_lane = (fr & 1) != 0;
+  const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : 0x7fffffff;          // no batches: one batch holds every row
+  const int cbr = p.c_batch_rows > 0 ? p.c_batch_rows : (p.rows_per_batch > 0 ? p.rows_per_batch : 0);
+  const int cro = p.c_batch_rows > 0 ? p.c_row_off : 0;
+  const int b_last = p.rows_per_batch > 0 ? (p.M - 1) / p.rows_per_batch : 0;     // (wave-uniform: scalar unit)
+  const int r_last = p.M - 1 - b_last * (p.rows_per_batch > 0 ? p.rows_per_batch : 0);
+  const int row_last = b_last * cbr + cro + r_last;
+  const int mA0 = (m_wave0 + fr) & ~1;
+  int row_a[MI], row_b[MI];                    // output rows of A_j, B_j
+  int b_own[(VEC || (FEAT & EPI_F_QKV)) ? MI : 1], r_own[(FEAT & EPI_F_QKV) ? MI : 1];   // batch / row in batch of the lane's own token
+  {
+    int bA = p.rows_per_batch > 0 ? mA0 / p.rows_per_batch : 0;
+    int rA = mA0 - bA * (p.rows_per_batch > 0 ? p.rows_per_batch : 0);
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      int bB = bA, rB = rA + 1;
+      if (rB >= rpb) { rB = 0; ++bB; }
+      const int mA = mA0 + 16 * j;
+      row_a[j] = mA < p.M ? bA * cbr + cro + rA : row_last;
+      row_b[j] = mA + 1 < p.M ? bB * cbr + cro + rB : row_last;
+      if constexpr (VEC || (FEAT & EPI_F_QKV)) { const int b = odd_lane ? bB : bA; b_own[j] = b < b_last ? b : b_last; }
+      if constexpr ((FEAT & EPI_F_QKV) != 0) r_own[j] = odd_lane ? rB : rA;
+      rA += 16;
+      if (rA >= rpb) { rA -= rpb; ++bA; }
+    }
+  }
   auto token = [&](int j) __attribute__((always_inline)) { return m_wave0 + j * 16 + fr; };
+  auto row_own = [&](int j) __attribute__((always_inline)) { return odd_lane ? row_b[j] : row_a[j]; };
+  // byte addresses: base + row * (leading dimension in bytes) -- one v_mad_u64_u32 per access
+  const char* const res_base = reinterpret_cast<const char*>(p.residual);
+  char* const c_base = reinterpret_cast<char*>(p.c);
+  const unsigned ldr_b = (unsigned)p.ldr * 2u, ldc_b = (unsigned)p.ldc * 2u;
+  auto res_at = [&](int row, int col) __attribute__((always_inline)) { return res_base + (unsigned long long)(unsigned)row * ldr_b + (unsigned)(col * 2); };
+  auto c_at = [&](int row, int col) __attribute__((always_inline)) { return c_base + (unsigned long long)(unsigned)row * ldc_b + (unsigned)(col * 2); };
+
   auto load_res = [&](int j, int pr) __attribute__((always_inline)) -> u32x4 {
-    const int m = token(j);
-    if (!has_res || m >= p.M) return u32x4{0u, 0u, 0u, 0u};
-    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
-    const long rrow = (flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
-    return *reinterpret_cast<const u32x4*>(p.residual + rrow * p.ldr + col0 + pr * 32 + fq * 8);
+    if (!has_res) return u32x4{0u, 0u, 0u, 0u};
+    return *reinterpret_cast<const u32x4*>(res_at(row_own(j), col0 + pr * 32 + fq * 8));
   };
   auto load_res_odd = [&](int j) __attribute__((always_inline)) -> u32x2 {
-    const int m = token(j);
-    if (!has_res || m >= p.M) return u32x2{0u, 0u};
-    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
-    const long rrow = (flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
-    return *reinterpret_cast<const u32x2*>(p.residual + rrow * p.ldr + col0 + NP * 32 + fq * 4);
+    if (!has_res) return u32x2{0u, 0u};
+    return *reinterpret_cast<const u32x2*>(res_at(row_own(j), col0 + NP * 32 + fq * 4));
   };
   // per-sample vectors (row bias of the time embedding, AdaLN gate) of the lane's token: one token block ahead
   f32x4 rb_r[VEC ? NIO : 1], gate_r[VEC ? NIO : 1];
   auto load_batch_vectors = [&](int j) __attribute__((always_inline)) {
     if constexpr (VEC) {
-      const int m = token(j);
-      const int mc = m < p.M ? m : p.M - 1;
-      const int bidx = (p.rows_per_batch > 0) ? (mc / p.rows_per_batch) : 0;
+      const int bidx = b_own[j];
 #pragma unroll
       for (int i = 0; i < NIO; ++i) {
         const int n = wave_n0 + i * 16 + fq * 4;
@@ -457,14 +499,11 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   // store rate of 64-byte row pieces (profiles/r02_a_dma_stream_and_store_microbench.txt).  The residual is read the same way.
   constexpr int NG = NP / 2;                   // groups of two pairs
   constexpr bool fullmode = NG > 0;     // (fp32 output is served by the generic kernel: pick_tile)
-  const bool odd_lane = (fr & 1) != 0;
+  const int col_full = col0 + (odd_lane ? 32 : 0) + fq * 8;     // this lane's column in group 0 (group g: + 64 g)
   // slot 2g of a group: (token A = even token of the lane pair, this lane's column pair); slot 2g + 1: (token B = odd token, same pair)
   auto load_res_full = [&](int j, int g, int which) __attribute__((always_inline)) -> u32x4 {
-    const int m = (token(j) & ~1) + which;
-    if (!has_res || m >= p.M) return u32x4{0u, 0u, 0u, 0u};
-    const int bidx = (p.rows_per_batch > 0) ? (m / p.rows_per_batch) : 0;
-    const long rrow = (flags & MX_EPI_RES_BCAST) ? (long)(m - bidx * p.rows_per_batch) : gemm_out_row(p, m, bidx);
-    return *reinterpret_cast<const u32x4*>(p.residual + rrow * p.ldr + col0 + (2 * g + (odd_lane ? 1 : 0)) * 32 + fq * 8);
+    if (!has_res) return u32x4{0u, 0u, 0u, 0u};
+    return *reinterpret_cast<const u32x4*>(res_at(which ? row_b[j] : row_a[j], col_full + 64 * g));
   };
   auto load_res_any = [&](int j, int pr) __attribute__((always_inline)) -> u32x4 {
     if (pr < 2 * NG) return load_res_full(j, pr >> 1, pr & 1);
@@ -484,8 +523,6 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = token(j);
-    const int mc = m < p.M ? m : p.M - 1;
-    const int bidx = (p.rows_per_batch > 0) ? (mc / p.rows_per_batch) : 0;
     // ---- accumulator layout: bias, RMSNorm / scale, GEGLU, per-sample vectors ----
     float v[NIO][4];
     float rms_mul = 1.0f;
@@ -507,8 +544,13 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       f32x4 t = STATS ? acc[i][j] * ln_rstd + bias_r[i] : acc[i][j] + bias_r[i];
       if constexpr (GEGLU) {
         const f32x4 g = STATS ? acc[i + NI / 2][j] * ln_rstd + bias_r[i + NI / 2] : acc[i + NI / 2][j] + bias_r[i + NI / 2];
+        if (ACT && (flags & MX_EPI_GEGLU_TANH)) {  // (GEGLU: ACT = the tanh form is compiled in)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = t[q] * ((flags & MX_EPI_GEGLU_TANH) ? gelu_tanh_f(g[q]) : gelu_fast(g[q]));
+          for (int q = 0; q < 4; ++q) t[q] = t[q] * gelu_tanh_f(g[q]);
+        } else {                                   // two elements per packed instruction
+          const gelu_f32x2 g01 = gelu_fast2(gelu_f32x2{g[0], g[1]}), g23 = gelu_fast2(gelu_f32x2{g[2], g[3]});
+          t[0] *= g01[0]; t[1] *= g01[1]; t[2] *= g23[0]; t[3] *= g23[1];
+        }
       } else {
         if (rms) {
 #pragma unroll
@@ -525,37 +567,37 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       for (int q = 0; q < 4; ++q) v[i][q] = t[q];
     }
     if constexpr (VPF) { if (j + 1 < MI && (has_rb || has_gate)) load_batch_vectors(j + 1); }
-    if (qkv && to_vt) {                        // V^T: keys along the lanes, 2-byte stores (see gemm_epilogue)
-      if (m < p.M) {
-        const int key0 = (p.c_batch_rows > 0 ? p.c_row_off : 0) + m - bidx * p.rows_per_batch;
-        const int key = MX_VT_POS(key0);
-        const int nv = p.N / p.period;
+    if constexpr ((FEAT & EPI_F_QKV) != 0) {
+      if (qkv && to_vt) {                      // V^T: keys along the lanes, 2-byte stores (see gemm_epilogue)
+        if (m < p.M) {
+          const int key = MX_VT_POS(cro + r_own[j]);
+          const int nv = p.N / p.period;
 #pragma unroll
-        for (int i = 0; i < NIO; ++i) {
-          const int nin = wave_n0 + i * 16 + fq * 4 - seg_idx * p.seg;
-          bf16_t* dst = p.vt + ((long)bidx * nv + (long)seg_grp * p.seg + nin) * p.ldvt + key;
+          for (int i = 0; i < NIO; ++i) {
+            const int nin = wave_n0 + i * 16 + fq * 4 - seg_idx * p.seg;
+            bf16_t* dst = p.vt + ((long)b_own[j] * nv + (long)seg_grp * p.seg + nin) * p.ldvt + key;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dst[(long)q * p.ldvt] = f32_to_bf16(v[i][q]);
+            for (int q = 0; q < 4; ++q) dst[(long)q * p.ldvt] = f32_to_bf16(v[i][q]);
+          }
         }
+        continue;
       }
-      continue;
     }
-    const long orow = gemm_out_row(p, mc, bidx);
     // ---- pairs of blocks: exchange, then residual -> activation -> store in the row layout ----
     auto finish8 = [&](float (&o)[8], const u32x4 rr) __attribute__((always_inline)) {
       if (has_res) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o[2 * q] += bf16lo_to_f32(rr[q]); o[2 * q + 1] += bf16hi_to_f32(rr[q]); }
       }
-      if (flags & MX_EPI_SILU) {
+      if (ACT && (flags & MX_EPI_SILU)) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
       }
-      if (flags & MX_EPI_GELU_TANH) {
+      if (ACT && (flags & MX_EPI_GELU_TANH)) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = gelu_tanh_f(o[q]);
       }
-      if (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU)) {
+      if (ACT && (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU))) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = (flags & MX_EPI_GELU) ? gelu_fast(o[q]) : quick_gelu_f(o[q]);
       }
@@ -565,12 +607,6 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       }
     };
     if constexpr (fullmode) {
-      // rows of the lane pair's two tokens
-      const int mp = m ^ 1;
-      const int mpc = mp < p.M ? mp : p.M - 1;
-      const int bp = (p.rows_per_batch > 0) ? (mpc / p.rows_per_batch) : 0;
-      const long prow = gemm_out_row(p, mpc, bp);
-      const long row_a = odd_lane ? prow : orow, row_b = odd_lane ? orow : prow;
       const bool ok_a = (m & ~1) < p.M, ok_b = (m | 1) < p.M;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
@@ -585,21 +621,21 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
         if (has_res) {
           // even lane: ra = (T, pair 2g) is its own; it lacks (T, pair 2g + 1) = the odd lane's ra.  Odd lane: rb = (T + 1, pair 2g + 1)
           // is its own; it lacks (T + 1, pair 2g) = the even lane's rb.
-          const u32x4 got = lane_xor1(odd_lane ? ra : rb);
-          res_a = odd_lane ? got : ra;
-          res_b = odd_lane ? rb : got;
+          const u32x4 nb_ra = lane_xor1(ra), nb_rb = lane_xor1(rb);
+          res_a = odd_lane ? nb_rb : ra;
+          res_b = odd_lane ? rb : nb_ra;
         }
         finish8(oa, res_a);
         finish8(ob, res_b);
         const u32x4 wa = {pack_bf16x2(oa[0], oa[1]), pack_bf16x2(oa[2], oa[3]), pack_bf16x2(oa[4], oa[5]), pack_bf16x2(oa[6], oa[7])};
         const u32x4 wb = {pack_bf16x2(ob[0], ob[1]), pack_bf16x2(ob[2], ob[3]), pack_bf16x2(ob[4], ob[5]), pack_bf16x2(ob[6], ob[7])};
         // even lane gives away its second pair and receives the odd token's first pair; the odd lane the other way round
-        const u32x4 got = lane_xor1(odd_lane ? wa : wb);
-        const u32x4 st_a = odd_lane ? got : wa;      // token A (even): even lane pair 2g, odd lane pair 2g + 1
-        const u32x4 st_b = odd_lane ? wb : got;      // token B (odd)
-        const int col = col0 + (2 * g + (odd_lane ? 1 : 0)) * 32 + fq * 8;
-        if (ok_a) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + row_a * p.ldc + col) = st_a;
-        if (ok_b) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + row_b * p.ldc + col) = st_b;
+        // (two unconditional neighbour reads, each consumed by one select: the DPP move folds into the v_cndmask)
+        const u32x4 nb_b = lane_xor1(wb), nb_a = lane_xor1(wa);
+        const u32x4 st_a = odd_lane ? nb_b : wa;     // token A (even): even lane pair 2g, odd lane pair 2g + 1 (the even lane's wb)
+        const u32x4 st_b = odd_lane ? wb : nb_a;     // token B (odd): even lane pair 2g (the odd lane's wa), odd lane pair 2g + 1
+        if (ok_a) *reinterpret_cast<u32x4*>(c_at(row_a[j], col_full + 64 * g)) = st_a;
+        if (ok_b) *reinterpret_cast<u32x4*>(c_at(row_b[j], col_full + 64 * g)) = st_b;
       }
     }
 #pragma unroll
@@ -612,9 +648,8 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       if (j + DEPTH < MI) res_r[j % DEPTH][pr] = load_res(j + DEPTH, pr);
       finish8(o, rr);
       if (m < p.M) {
-        const int col = col0 + pr * 32 + fq * 8;
         const u32x4 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = w;
+        *reinterpret_cast<u32x4*>(c_at(row_own(j), col0 + pr * 32 + fq * 8)) = w;
       }
     }
     // ---- odd last block: straight from the accumulator layout ----
@@ -625,15 +660,15 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       const u32x2 rr = res_o[j % DEPTH];
       if (j + DEPTH < MI) res_o[j % DEPTH] = load_res_odd(j + DEPTH);
       if (has_res) { o[0] += bf16lo_to_f32(rr[0]); o[1] += bf16hi_to_f32(rr[0]); o[2] += bf16lo_to_f32(rr[1]); o[3] += bf16hi_to_f32(rr[1]); }
-      if (flags & MX_EPI_SILU) {
+      if (ACT && (flags & MX_EPI_SILU)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = silu_f(o[q]);
       }
-      if (flags & MX_EPI_GELU_TANH) {
+      if (ACT && (flags & MX_EPI_GELU_TANH)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = gelu_tanh_f(o[q]);
       }
-      if (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU)) {
+      if (ACT && (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU))) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = (flags & MX_EPI_GELU) ? gelu_fast(o[q]) : quick_gelu_f(o[q]);
       }
@@ -641,10 +676,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
         for (int q = 0; q < 4; ++q) { st1 += o[q]; st2 += o[q] * o[q]; }
       }
-      if (m < p.M) {
-        const int col = col0 + NP * 32 + fq * 4;
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + orow * p.ldc + col) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-      }
+      if (m < p.M) *reinterpret_cast<u32x2*>(c_at(row_own(j), col0 + NP * 32 + fq * 4)) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
     }
     if (stats) {                               // the token's four lanes hold disjoint columns of the wave's panel: slab = panel index
       st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);

@@ -213,7 +213,10 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
   const TileChoice none = {0, 0};
   const long Mtot = rows_of(d);
   if (Mtot < 128 || d->K < 128) return none;
-  if (d->flags & MX_EPI_OUT_F32) return none;     // the register-exchange epilogue of the 256-row kernels writes bf16 only
+  if (d->flags & (MX_EPI_OUT_F32 | MX_EPI_RES_BCAST)) return none;   // the register-exchange epilogue writes bf16 only and adds a per-row residual
+  // its row walk steps 16 tokens at a time with one wrap per step (gemm_epilogue_regs): batches shorter than that go to the generic kernel
+  if (d->n_segs <= 0) { if (d->rows_per_batch > 0 && d->rows_per_batch < 16) return none; }
+  else for (int i = 0; i < d->n_segs; ++i) if (d->segs[i].rows_per_batch > 0 && d->segs[i].rows_per_batch < 16) return none;
   // their LDS-staged epilogue moves 16-byte pieces of C and of the residual
   if (d->ldc % 8 != 0 || ((uintptr_t)d->c & 15) != 0) return none;
   if (d->residual && (d->ldr % 8 != 0 || ((uintptr_t)d->residual & 15) != 0)) return none;

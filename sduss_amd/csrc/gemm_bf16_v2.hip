@@ -46,7 +46,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int BN, int MI, bool CONV>      // MI: 16-wide token blocks per wave; tile rows BM2 = 64 * MI (256, or 128 for small M)
+// MI: 16-wide token blocks per wave; tile rows BM2 = 64 * MI (256, or 128 for small M); FEAT / GEGLU: the epilogue features compiled in
+// (gemm_args.h EPI_F_*; the launcher picks the smallest instantiation that serves the launch)
+template <int BN, int MI, bool CONV, int FEAT, bool GEGLU>
 __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
   constexpr int BM2 = 64 * MI;
   constexpr int NI = BN / 32;                 // 16-wide feature blocks per wave (wave covers BN/2 features)
@@ -272,11 +274,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
 
     const int m0 = tm * BM2, n0 = tn * BN;
     // register-exchange epilogue (gemm_args.h): no LDS, no barrier; the past-the-end DMAs are drained before the workgroup retires
-    if (p.flags & MX_EPI_GEGLU) {
-      if constexpr (NI % 4 == 0 && !CONV) gemm_epilogue_regs<NI, MI, true>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
-    } else {
-      gemm_epilogue_regs<NI, MI, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
-    }
+    static_assert(!GEGLU || (NI % 4 == 0 && !CONV), "the gated epilogue pairs whole 32-feature halves");
+    gemm_epilogue_regs<NI, MI, GEGLU, true, true, true, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 }
@@ -287,11 +286,19 @@ int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows) {
   (void)rows;
   const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, 128)) * (a.N / bn);
   dim3 grid(tiles), block(512);
-  if (bn == 160) {
-    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<160, 2, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_v2_kernel<160, 2, false>), grid, block, 0, s, a);
+#define MX_V2(BN_, CONV_, FEAT_, GEGLU_) hipLaunchKernelGGL((gemm_v2_kernel<BN_, 2, CONV_, FEAT_, GEGLU_>), grid, block, 0, s, a)
+  const int feat = gemm_epi_features(a.flags);
+  if (a.flags & MX_EPI_GEGLU) {               // (pick_tile: 128 features only)
+    if (feat & EPI_F_ACT) MX_V2(128, false, EPI_F_ACT, true); else MX_V2(128, false, 0, true);
+  } else if (conv) {
+    if (bn == 160) { if (feat == 0) MX_V2(160, true, 0, false); else MX_V2(160, true, EPI_F_ALL, false); }
+    else { if (feat == 0) MX_V2(128, true, 0, false); else MX_V2(128, true, EPI_F_ALL, false); }
+  } else if (bn == 160) {
+    if (feat == 0) MX_V2(160, false, 0, false); else if (feat == EPI_F_QKV) MX_V2(160, false, EPI_F_QKV, false); else MX_V2(160, false, EPI_F_ALL, false);
   } else {
-    if (conv) hipLaunchKernelGGL((gemm_v2_kernel<128, 2, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_v2_kernel<128, 2, false>), grid, block, 0, s, a);
+    if (feat == 0) MX_V2(128, false, 0, false); else if (feat == EPI_F_QKV) MX_V2(128, false, EPI_F_QKV, false); else MX_V2(128, false, EPI_F_ALL, false);
   }
+#undef MX_V2
   return 0;
 }
 

@@ -101,7 +101,8 @@ __device__ unsigned long long g_v4_stamps[256 * 2 * 64];
 #define MX_STAMP(slot) do {} while (0)
 #endif
 
-template <bool VEC>
+// VEC: per-sample vectors (row bias, gate) compiled in; FEAT: gemm_args.h EPI_F_*; GEGLU: the gated epilogue INSTEAD of the plain one
+template <bool VEC, int FEAT, bool GEGLU>
 __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   constexpr int NI = 4;                        // 16-wide feature blocks per wave (64 features)
   constexpr int MI = 8;                        // 16-wide token blocks per wave (128 tokens)
@@ -119,6 +120,16 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   const char* abase = reinterpret_cast<const char*>(pk.a);   // grouped: the lowest of the problems' bases (launch_v4 checks the 32-bit reach)
   const char* wbase = reinterpret_cast<const char*>(pk.w);
   const int cs = tid & 7;
+#if MX_EXP == 8 && defined(MX_STAGGER_PHASES)
+  // experiment: idle stagger -- workgroup phase g of MX_STAGGER_PHASES (alternating inside each XCD) starts g * MX_STAGGER_US / PHASES late,
+  // so that the epilogues' store bursts of the phases do not coincide (tools/exp/timeline_v4.py shows what that does to the epilogue time)
+  {
+    const int g = (blockIdx.x >> 3) % MX_STAGGER_PHASES;
+    const unsigned long long want = (unsigned long long)(g * MX_STAGGER_US * 100 / MX_STAGGER_PHASES);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < want) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   MX_STAMP(0);
   [[maybe_unused]] int stamp_i = 1;
 
@@ -337,8 +348,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
     GemmArgs p = pk;
     gemm_select_seg(p, pk, tm);
     const int m0 = tm * BM4, n0 = tn * BN4;
-    if (p.flags & MX_EPI_GEGLU) gemm_epilogue_regs<NI, MI, true, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
-    else gemm_epilogue_regs<NI, MI, false, VEC, false, false>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
+    gemm_epilogue_regs<NI, MI, GEGLU, VEC, false, false, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
     MX_STAMP(stamp_i + 2);
     stamp_i += 3;
   }
@@ -360,8 +370,21 @@ int launch_v4(hipStream_t s, const GemmArgs& a) {
   const int ncu = cu_count();
   const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, BM4)) * (a.N / BN4);
   const dim3 grid(tiles > ncu && ncu > 0 ? ncu : tiles), block(512);
-  if (a.rowbias || a.gate) hipLaunchKernelGGL(gemm_v4_kernel<true>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(gemm_v4_kernel<false>, grid, block, 0, s, a);
+  // the smallest instantiation that serves the launch (each carries only its own epilogue code: gemm_args.h, EPI_F_*)
+  const bool vec = a.rowbias || a.gate;
+  const int feat = gemm_epi_features(a.flags);
+#define MX_V4(VEC_, FEAT_, GEGLU_) hipLaunchKernelGGL((gemm_v4_kernel<VEC_, FEAT_, GEGLU_>), grid, block, 0, s, a)
+  if (a.flags & MX_EPI_GEGLU) {
+    if (feat & EPI_F_ACT) MX_V4(false, EPI_F_ACT, true); else MX_V4(false, 0, true);      // (the gated epilogue takes no per-sample vectors)
+  } else if (!vec) {
+    if (feat == 0) MX_V4(false, 0, false);
+    else if (feat == EPI_F_QKV) MX_V4(false, EPI_F_QKV, false);
+    else if (feat == EPI_F_ACT) MX_V4(false, EPI_F_ACT, false);
+    else MX_V4(true, EPI_F_ALL, false);
+  } else {
+    if (feat == 0) MX_V4(true, 0, false); else MX_V4(true, EPI_F_ALL, false);
+  }
+#undef MX_V4
   return 0;
 }
 

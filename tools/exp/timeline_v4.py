@@ -17,6 +17,7 @@ from sduss_amd import lib, ops  # noqa: E402
 SHAPES = [  # (label, M, N, K, geglu, residual)
     ("to_qkv  (256x256)", 8192, 3840, 1280, False, False),
     ("GEGLU   (256x256)", 8192, 10240, 1280, True, False),
+    ("GEGLU 64x64 level (256x256)", 32768, 5120, 640, True, False),
     ("ff.out  (256x160)", 8192, 1280, 5120, False, True),
     ("to_out  (256x160)", 8192, 1280, 1280, False, True),
     ("to_out  no residual", 8192, 1280, 1280, False, False),
@@ -36,7 +37,10 @@ def event_us(fn, n=20):
 def main():
     l = lib.load()
     g = torch.Generator(device="cuda:0").manual_seed(0)
+    only_v4 = len(sys.argv) > 1 and sys.argv[1] == "v4"
     for label, m, n, k, geglu, res in SHAPES:
+        if only_v4 and not (n % 256 == 0 and n >= 2560):
+            continue
         a = torch.randn(m, k, device="cuda:0", generator=g).to(torch.bfloat16)
         w = (torch.randn(n, k, device="cuda:0", generator=g) * k ** -0.5).to(torch.bfloat16)
         bias = torch.randn(n, device="cuda:0", generator=g)
