@@ -75,6 +75,13 @@ __device__ __forceinline__ gelu_f32x2 gelu_fast2(const gelu_f32x2 x) {
   return gelu_f32x2{x[0] >= 0.f ? x[0] - xh[0] : xh[0], x[1] >= 0.f ? x[1] - xh[1] : xh[1]};
 }
 __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(gelu_f32x2{x, x})[0]; }
+// tanh-form GELU, two elements: x sigmoid(2 u), u = sqrt(2 / pi) (x + 0.044715 x^3) -- the polynomial and the scaling on packed fp32
+__device__ __forceinline__ gelu_f32x2 gelu_tanh2(const gelu_f32x2 x) {
+  const gelu_f32x2 w = (x * x) * (0.044715f * 0.7978845608028654f) + 0.7978845608028654f;
+  const gelu_f32x2 a = (x * w) * (-2.0f * 1.4426950408889634f);          // -2 u log2(e)
+  const gelu_f32x2 d = gelu_f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
+  return x * gelu_f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

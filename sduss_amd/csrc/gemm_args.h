@@ -382,11 +382,12 @@ __device__ __forceinline__ u32x4 lane_xor1(const u32x4 x) {
 // launch's flags).  Round 3 (tools/exp/timeline_v4.py): with every feature behind a runtime branch the 256 x 256 kernel was 164 KB of code
 // -- 2.5 instruction caches -- and a plain bias-only epilogue took 14 us per tile of branching through it.
 constexpr int EPI_F_QKV = 1;                  // MX_EPI_QKV (segmented output, V^T, RMSNorm of the heads)
-constexpr int EPI_F_ACT = 2;                  // MX_EPI_SILU / GELU / GELU_TANH / QUICK_GELU
+constexpr int EPI_F_ACT = 2;                  // any of MX_EPI_SILU / GELU / GELU_TANH / QUICK_GELU (and GEGLU_TANH in the gated epilogue), chosen at run time
 constexpr int EPI_F_ALL = 3;
+constexpr int EPI_F_TANH = 4;                 // MX_EPI_GELU_TANH alone (the MMDiT feed-forward): only that activation is compiled in
 __host__ __device__ inline int gemm_epi_features(int flags) {
-  return ((flags & MX_EPI_QKV) ? EPI_F_QKV : 0) |
-         ((flags & (MX_EPI_SILU | MX_EPI_GELU | MX_EPI_GELU_TANH | MX_EPI_QUICK_GELU | MX_EPI_GEGLU_TANH)) ? EPI_F_ACT : 0);
+  const int acts = flags & (MX_EPI_SILU | MX_EPI_GELU | MX_EPI_GELU_TANH | MX_EPI_QUICK_GELU | MX_EPI_GEGLU_TANH);
+  return ((flags & MX_EPI_QKV) ? EPI_F_QKV : 0) | (acts == 0 ? 0 : acts == MX_EPI_GELU_TANH ? EPI_F_TANH : EPI_F_ACT);
 }
 template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true, int FEAT = EPI_F_ALL>
 __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
@@ -398,6 +399,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   static_assert(!GEGLU || NI % 4 == 0, "GEGLU: hidden and gate halves must be whole pairs");
   const int flags = p.flags;
   constexpr bool ACT = (FEAT & EPI_F_ACT) != 0;
+  constexpr bool TANH = (FEAT & (EPI_F_ACT | EPI_F_TANH)) != 0;
   const bool qkv = (FEAT & EPI_F_QKV) != 0 && (flags & MX_EPI_QKV) != 0;
   int seg_idx = 0, seg_grp = 0, seg_pos = 0;
   bool to_vt = false;
@@ -593,9 +595,9 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
       }
-      if (ACT && (flags & MX_EPI_GELU_TANH)) {
+      if (TANH && (flags & MX_EPI_GELU_TANH)) {       // two elements per packed instruction
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = gelu_tanh_f(o[q]);
+        for (int q = 0; q < 8; q += 2) { const gelu_f32x2 t2 = gelu_tanh2(gelu_f32x2{o[q], o[q + 1]}); o[q] = t2[0]; o[q + 1] = t2[1]; }
       }
       if (ACT && (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU))) {
 #pragma unroll
@@ -664,9 +666,9 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = silu_f(o[q]);
       }
-      if (ACT && (flags & MX_EPI_GELU_TANH)) {
+      if (TANH && (flags & MX_EPI_GELU_TANH)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = gelu_tanh_f(o[q]);
+        for (int q = 0; q < 4; q += 2) { const gelu_f32x2 t2 = gelu_tanh2(gelu_f32x2{o[q], o[q + 1]}); o[q] = t2[0]; o[q + 1] = t2[1]; }
       }
       if (ACT && (flags & (MX_EPI_GELU | MX_EPI_QUICK_GELU))) {
 #pragma unroll

@@ -379,7 +379,7 @@ int launch_v4(hipStream_t s, const GemmArgs& a) {
   } else if (!vec) {
     if (feat == 0) MX_V4(false, 0, false);
     else if (feat == EPI_F_QKV) MX_V4(false, EPI_F_QKV, false);
-    else if (feat == EPI_F_ACT) MX_V4(false, EPI_F_ACT, false);
+    else if (feat == EPI_F_TANH) MX_V4(false, EPI_F_TANH, false);
     else MX_V4(true, EPI_F_ALL, false);
   } else {
     if (feat == 0) MX_V4(true, 0, false); else MX_V4(true, EPI_F_ALL, false);
