@@ -12,11 +12,9 @@ done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/libmx_exp8.so $OBJ/gemm_bf16_v2.o $OBJ/gemm_bf16.o build/exp/gemm_bf16_v4_exp8.o \
   build/exp/gemm_bf16_v5_exp8.o $OBJ/attention.o $OBJ/norm.o $OBJ/elementwise.o $OBJ/gn_halo_nchw.o $OBJ/unet_sdxl.o $OBJ/mmdit_sd3.o $OBJ/capi.o \
   $OBJ/clip_text.o $OBJ/t5_text.o $OBJ/vae_sdxl.o
-# idle-stagger variants of the 256x256 kernel: 2 and 4 phases over one tile period (~40 us)
-for ph in 2 4; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMX_EXP=8 -DMX_STAGGER_PHASES=$ph -DMX_STAGGER_US=40 -c sduss_amd/csrc/gemm_bf16_v4.hip -o build/exp/gemm_bf16_v4_exp8s$ph.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/libmx_exp8s$ph.so $OBJ/gemm_bf16_v2.o $OBJ/gemm_bf16.o build/exp/gemm_bf16_v4_exp8s$ph.o \
-    build/exp/gemm_bf16_v5_exp8.o $OBJ/attention.o $OBJ/norm.o $OBJ/elementwise.o $OBJ/gn_halo_nchw.o $OBJ/unet_sdxl.o $OBJ/mmdit_sd3.o $OBJ/capi.o \
-    $OBJ/clip_text.o $OBJ/t5_text.o $OBJ/vae_sdxl.o
-done
+# the same stamps in the two-segment experiment kernel (A/B of the K loop and of the shader clock under it)
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMX_EXP=8 -Isduss_amd/csrc -c tools/exp/gemm_bf16_v4_twophase.hip -o build/exp/gemm_bf16_v4_twophase_exp8.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/exp/libmx_exp8_twophase.so $OBJ/gemm_bf16_v2.o $OBJ/gemm_bf16.o build/exp/gemm_bf16_v4_twophase_exp8.o \
+  build/exp/gemm_bf16_v5_exp8.o $OBJ/attention.o $OBJ/norm.o $OBJ/elementwise.o $OBJ/gn_halo_nchw.o $OBJ/unet_sdxl.o $OBJ/mmdit_sd3.o $OBJ/capi.o \
+  $OBJ/clip_text.o $OBJ/t5_text.o $OBJ/vae_sdxl.o
 ls -la build/exp/libmx_exp8*.so

@@ -55,7 +55,8 @@ def main():
             buf = np.zeros(256 * 2 * 64, dtype=np.uint64)
             fn = l.mx_debug_v4_stamps; fn.argtypes = [C.c_void_p]
             assert fn(buf.ctypes.data) == 0
-            st = buf.reshape(256, 2, 64).astype(np.float64) / 100.0
+            raw = buf.reshape(256, 2, 64).astype(np.float64)
+            st = raw / 100.0
             tiles = (m + 255) // 256 * (n // 256)
             per_cu = (tiles + 255) // 256
             for wv, name in ((0, "wave 0 (row 0)"), (1, "wave 7 (row 1)")):
@@ -66,8 +67,12 @@ def main():
                     if not ok.any():
                         break
                     k0 = st[ok, wv, 1 + 3 * t] - t0; k1 = st[ok, wv, 2 + 3 * t] - t0; e = st[ok, wv, 3 + 3 * t] - t0
+                    if 3 + 3 * t >= 32:
+                        break
+                    # shader clock over the K loop: s_memtime ticks (slots 32..) per microsecond of s_memrealtime
+                    ck = (raw[ok, wv, 32 + 2 + 3 * t] - raw[ok, wv, 32 + 1 + 3 * t]) / np.maximum(k1 - k0, 1e-9)
                     print(f"    tile {t} (n={int(ok.sum()):3d}): first K tile at {np.median(k0):7.2f} (min {k0.min():6.2f} max {k0.max():6.2f})  K loop {np.median(k1 - k0):6.2f} "
-                          f"(max {np.max(k1 - k0):6.2f})  epilogue issue {np.median(e - k1):5.2f} (max {np.max(e - k1):5.2f})  ends at {np.median(e):7.2f} (max {e.max():7.2f})")
+                          f"(max {np.max(k1 - k0):6.2f})  epilogue issue {np.median(e - k1):5.2f} (max {np.max(e - k1):5.2f})  ends at {np.median(e):7.2f} (max {e.max():7.2f})  shader clock in the K loop {np.median(ck):6.0f} MHz")
         else:
             buf = np.zeros(1024 * 2 * 4, dtype=np.uint64)
             fn = l.mx_debug_v5_stamps; fn.argtypes = [C.c_void_p]
