@@ -64,6 +64,22 @@ def test_gemm_rowbias(cuda_device):
     _close(got, want, 2.0 ** -7, "gemm+rowbias")
 
 
+@pytest.mark.parametrize("bsz,rows,n,k", [(40, 17, 256, 128), (23, 31, 320, 192), (9, 100, 1280, 256), (64, 16, 640, 128), (50, 15, 256, 128),
+                                          (3, 333, 1280, 640), (2, 1025, 1280, 1280)])
+def test_gemm_rowbias_residual_row_walk(cuda_device, bsz, rows, n, k):
+    """the register epilogue's row bookkeeping (one division per lane, then a 16-token compare-and-wrap walk): batches that are odd, not a
+    multiple of 16, shorter than a 128-token wave tile (a wave crosses several samples) or of exactly 16 tokens; 15 tokens go to the generic
+    kernel.  Per-sample row bias + residual, M not a multiple of the tile."""
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(bsz * 1000 + rows)
+    a = _rt(torch.randn(bsz * rows, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
+    b = torch.randn(n, generator=g); r = _rt(torch.randn(bsz * rows, n, generator=g))
+    rb = torch.randn(bsz, n, generator=g)
+    want = a @ w.t() + b + rb.repeat_interleave(rows, dim=0) + r
+    got = ops.gemm(_bf(a).cuda(), _bf(w).cuda(), b.cuda(), residual=_bf(r).cuda(), rowbias=rb.cuda(), rows_per_batch=rows)
+    _close(got, want, 2.0 ** -7, f"gemm+rowbias+residual, {bsz} samples of {rows} rows")
+
+
 def test_gemm_geglu(cuda_device):
     from sduss_amd import ops
     from sduss_amd.weights import _geglu_interleave
@@ -84,11 +100,11 @@ def _geglu_case(m, dim):
     _close(got, want, 2.0 ** -7, "gemm+geglu")
 
 
-@pytest.mark.parametrize("period,rows,dim", [(3, 64, 128), (2, 77, 64), (3, 256, 64), (3, 256, 640), (2, 77, 320), (3, 512, 128)])
+@pytest.mark.parametrize("period,rows,dim", [(3, 64, 128), (2, 77, 64), (3, 256, 64), (3, 256, 640), (2, 77, 320), (3, 512, 128), (3, 333, 128), (3, 17, 128)])
 def test_gemm_qkv_split(cuda_device, period, rows, dim):
     from sduss_amd import ops
     g = torch.Generator().manual_seed(period * 11 + rows)
-    nb, k, groups = (2 if rows > 77 else 5), 128, 2 if period == 2 else 1
+    nb, k, groups = (2 if rows > 77 else 5 if rows > 17 else 24), 128, 2 if period == 2 else 1
     n = groups * period * dim
     a = _rt(torch.randn(nb * rows, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
     full = a @ w.t()
