@@ -55,7 +55,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 // GELU (erf form) by Abramowitz-Stegun 7.1.28: erf(z) = 1 - 1 / (1 + a1 z + ... + a6 z^6)^16 (z >= 0, |abs err| <= 3e-7), so
-//   gelu(x) = x (1 - h) for x >= 0 and x h for x < 0, with h = 0.5 / poly(|x| / sqrt 2)^16
+//   gelu(x) = x (1 - h) for x >= 0 and x h for x < 0 (= max(x, 0) - |x h|), with h = 0.5 / poly(|x| / sqrt 2)^16
 // -- ONE transcendental (v_rcp) per element instead of the two of 7.1.26 (rcp + exp), and a plain polynomial that the two-element form
 // runs on packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32).  Measured against the float64 erf form: |abs err| <= 7.1e-7 over
 // [-12, 12] (7.1.26: 4.6e-7); the GEGLU epilogue evaluates it for every FF1 output element and was VALU-bound on it (round 3,
@@ -71,8 +71,9 @@ __device__ __forceinline__ gelu_f32x2 gelu_fast2(const gelu_f32x2 x) {
   p = p * ax + 1.0f;
   p = p * p; p = p * p; p = p * p; p = p * p;              // ^16 (overflow -> inf -> h = 0: erf = 1)
   const gelu_f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
-  const gelu_f32x2 xh = x * (r * 0.5f);
-  return gelu_f32x2{x[0] >= 0.f ? x[0] - xh[0] : xh[0], x[1] >= 0.f ? x[1] - xh[1] : xh[1]};
+  const gelu_f32x2 xh = x * (r * 0.5f);          // same sign as x
+  // x >= 0: x - x h;  x < 0: x h = -|x h|   ==   max(x, 0) - |x h|   (a v_max and a v_sub with the abs modifier: no compare / select)
+  return gelu_f32x2{fmaxf(x[0], 0.f) - fabsf(xh[0]), fmaxf(x[1], 0.f) - fabsf(xh[1])};
 }
 __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(gelu_f32x2{x, x})[0]; }
 // tanh-form GELU, two elements: x sigmoid(2 u), u = sqrt(2 / pi) (x + 0.044715 x^3) -- the polynomial and the scaling on packed fp32
