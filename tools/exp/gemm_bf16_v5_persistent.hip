@@ -1,0 +1,328 @@
+// EXPERIMENT (round 3, not shipped): the PERSISTENT form of sduss_amd/csrc/gemm_bf16_v5.hip (a workgroup walks tiles t, t + grid, ...; the loader's
+// cursor runs on into the next tile; per-sample vectors as a template flag so that the cursor state fits beside the epilogue).  Correct (GEMM / grouped
+// / LayerNorm-fold tests).  Same-box interleaved A/B (profiles/r03_h_gemm_bench_ab_v5_persistent.txt): launches of 2-6 rounds with short K gain 2-6 us
+// (M32768 N640 K640 43.5 -> 41.8 us, N1920 K640 124.5 -> 118.8), K = 2560 loses 5 us and the one-round launches that dominate the step lose 0.7 us:
+// the boundary code in the L phase (tile set-up inlined into the cursor's advance) lengthens every K-tile iteration by ~6 %.  Net for the headline
+// step: nil.  To build: copy over csrc/gemm_bf16_v5.hip.
+//
+// bf16 MFMA GEMM / implicit-GEMM conv3x3, 256 tokens x {160, 128} features, PING-PONG schedule of the two wave-row pairs (round 3).
+//
+// Same tile, loader (LDS-DMA with the XOR swizzle on the source address, zero page for padding taps, per-tap row pointers), math, orientation
+// and epilogue as the 256-row form of gemm_bf16_v2.hip -- what changes is how the eight waves share the CU.  gemm_v2's loop is lock-step: all
+// eight waves wait, pass ONE barrier per K tile, read their 18 fragments together (LDS saturated, matrix pipe idle), then compete for the
+// matrix pipe together.  Measured there (profiles/r02_g_shape_profile_b4.txt): 1.15 us per K tile against 0.62 us of matrix-pipe time and
+// 0.62 us of operand streaming -- the two ADD instead of overlapping.  gemm_v4 (256 x 256) removed that for the large-N launches; this kernel
+// does it for the N <= 1280 family and the convs, a third of the step each.
+//
+//   waves 0-3 (token rows 0-127 of the tile) = group A, waves 4-7 (rows 128-255) = group B: every SIMD holds one wave of each group.
+//   per K tile and wave:   L | M        (| = s_barrier; group B runs the same program ONE barrier behind group A)
+//     L  read ALL fragments of the K tile (10 W + 8 X ds_read_b128 for BN 160), issue the wave's share of the LDS-DMA for K tile t + 2,
+//        move the loader's cursor (tap changes of the conv included), wait until its own DMA of tile t + 1 has landed (counted vmcnt) and
+//        its fragment reads have returned (lgkmcnt 0)
+//     M  40 MFMAs on registers only
+//   so in every phase one group streams operands while the other owns the matrix pipe.
+//   * LDS: the same three-stage ring (all 160 KB).  K tile t + 2 overwrites the stage of tile t - 1, last read by group B one phase before
+//     group A issues (reads retired by the lgkmcnt(0) in front of the barrier: cdna guide, "restage a buffer 1 phase after when an lgkmcnt
+//     before the reading phase's first barrier retired those reads") and two phases before group B issues;
+//   * RAW: a wave's DMA of tile t + 1 is waited for in its L phase of tile t, at least one barrier before either group reads it;
+//   * the groups re-align for the register-exchange epilogue (group A takes one extra barrier after the loop, group B one before it);
+//   * PERSISTENT when the launch has more tiles than CUs (round 3): a workgroup walks tiles t, t + grid, ... and the loader's cursor runs on
+//     into the next tile two K tiles ahead of the MFMAs, so a later tile's first operands land during the epilogue of the one before it
+//     instead of costing a workgroup dispatch, the argument fetch, the address set-up and the first DMA's latency (~5 us per round of the
+//     one-tile form; the 64 x 64 and 128 x 128 levels run 2-16 rounds per launch).
+#include <cstdlib>
+
+#include "common.h"
+#include "../../include/mxdenoise.h"
+#include "gemm_args.h"
+
+namespace mx {
+
+// zero page the loaders read for padding taps / past-the-end DMAs: as long as the widest input channel count (2 * Cin bytes); one per
+// translation unit (device symbols are not linked across them)
+__device__ __attribute__((aligned(64))) unsigned int g_zero_page5[16384 / 4] = {0};
+
+constexpr int BK5 = 64;
+constexpr int NSTAGE5 = 3;
+
+__device__ __forceinline__ int swz5(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ void glds16_5(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// raw barrier that neither the compiler's memory motion nor its instruction scheduler crosses
+#define MX5_BAR()                                 \
+  do {                                            \
+    asm volatile("" ::: "memory");                \
+    __builtin_amdgcn_s_barrier();                 \
+    asm volatile("" ::: "memory");                \
+    __builtin_amdgcn_sched_barrier(0);            \
+  } while (0)
+
+#if defined(MX_EXP) && MX_EXP == 8   // diagnostic build: wall-clock stamps (100 MHz s_memrealtime) per workgroup, read back by tools/exp/timeline_v4.py
+__device__ unsigned long long g_v5_stamps[1024 * 2 * 4];
+#define MX5_STAMP(slot) do { if (lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < 1024) \
+    g_v5_stamps[(blockIdx.x * 2 + (wave == 7)) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int mx_debug_v5_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v5_stamps), sizeof(g_v5_stamps)); }
+#else
+#define MX5_STAMP(slot) do {} while (0)
+#endif
+
+// MI: 16-wide token blocks per wave; tile rows BM5 = 64 * MI (256, or 128 for small M); FEAT / GEGLU: the epilogue features compiled in
+// (gemm_args.h EPI_F_*; the launcher picks the smallest instantiation that serves the launch)
+template <int BN, int MI, bool CONV, int FEAT, bool GEGLU, bool VEC>
+__global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
+  constexpr int BM5 = 64 * MI;
+  constexpr int NI = BN / 32;                 // 16-wide feature blocks per wave (BN / 2 features)
+  constexpr int WCH = BN * 8;                 // 16-byte chunks of the W tile
+  constexpr int XI = BM5 * 8 / 512;           // X load instructions per thread per tile (4, or 2 for the 128-row tile)
+  constexpr int WI = (WCH + 511) / 512;       // W load instructions per thread per tile (3 for BN 160, 2 for 128)
+  constexpr int LOADS = XI + WI;
+  constexpr int STAGE_ELEMS = (BM5 + BN) * BK5;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE5 * STAGE_ELEMS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1;                   // 0..3: token quarter of the tile; groups: wm 0-1 = A, wm 2-3 = B
+  const int wn = wave & 1;
+  const bool group_b = wave >= 4;
+  MX5_STAMP(0);
+  const int n_mt = gemm_m_tiles(pk, BM5), n_nt = pk.N / BN;
+  const int total_tiles = n_mt * n_nt;
+  const int nk = pk.K / BK5;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page5);
+  const int cs = tid & 7;
+  const int tiles_per_tap = CONV ? pk.Cin / BK5 : 1;
+  // the loader runs two K tiles ahead of the MFMAs, so near a tile boundary it works on the NEXT tile: its own tile index and arguments
+  // (`ip`: the tile's problem of a grouped launch selected); the compute side's are `tile` / `p` below
+  int i_tile = blockIdx.x;
+  int itm = 0, itn = 0;
+  GemmArgs ip = pk;
+
+  // ---- issue side (as gemm_v2): the K tile the NEXT DMA group belongs to and ready-made per-thread source pointers for it ----
+  bool parked = false;
+  int is_kt = 0;
+  const char* xsrc[XI];
+  long xjump[XI];
+  const char* wsrc[WI];
+  int cb[XI], cy[XI], cx[XI];
+  unsigned xchb[XI];
+  int tap_next = 0, in_tap = 0;
+
+  auto conv_set_tap = [&](int tap) __attribute__((always_inline)) {
+    const int dy = tap / 3 - 1;
+    const int dx = tap - (tap / 3) * 3 - 1;
+    const int Hv = ip.Hin << ip.up, Wv = ip.Win << ip.up;
+    const int P = ip.corner_patch;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      int iy = cy[i] + dy;
+      const int ix = cx[i] + dx;
+      if (P > 0 && dy != 0 && dx != 0) {
+        // halo-corner rule of the reference's sliced path (norm_silu_concat.cu:210-221, 228-239)
+        const bool cross_r = ((iy + P) / P) != ((cy[i] + P) / P);
+        const bool cross_c = ((ix + P) / P) != ((cx[i] + P) / P);
+        if (cross_r && cross_c) iy = cy[i];
+      }
+      const bool ok = (cb[i] >= 0) && (iy >= -ip.vhalo) && (iy < Hv + ip.vhalo) && (ix >= 0) && (ix < Wv);
+      const long off = ((((long)cb[i] * (ip.Hin + 2 * ip.vhalo) + (iy >> ip.up) + ip.vhalo) * ip.Win + (ix >> ip.up)) * ip.Cin) * 2;
+      xsrc[i] = (ok ? reinterpret_cast<const char*>(ip.a) + off : zero) + xchb[i];
+    }
+  };
+  auto setup_tile = [&]() __attribute__((always_inline)) {
+    gemm_tile_of_block(i_tile, n_mt, n_nt, pk.xcd_map, itm, itn);
+    ip = pk;
+    gemm_select_seg(ip, pk, itm);
+    const int m0 = itm * BM5;
+    const int n0 = itn * BN;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int row = (i * 512 + tid) >> 3;
+      const int ch = swz5(row, cs);
+      const int m = m0 + row;
+      if constexpr (!CONV) {
+        const int mc = m < ip.M ? m : ip.M - 1;
+        xsrc[i] = reinterpret_cast<const char*>(ip.a) + (gemm_in_row(ip, mc) * ip.lda + ch * 8) * 2;
+        xjump[i] = ip.a2 != nullptr ? (reinterpret_cast<const char*>(ip.a2) + ((long)mc * ip.lda2 + ch * 8) * 2) - (xsrc[i] + (long)ip.k_split * 2) : 0;
+      } else {
+        xchb[i] = ch * 16;
+        if (m < ip.M) {
+          const int hw = ip.Hout * ip.Wout;
+          const int b = m / hw;
+          const int r = m - b * hw;
+          const int oy = r / ip.Wout;
+          cb[i] = b; cy[i] = oy * ip.stride; cx[i] = (r - oy * ip.Wout) * ip.stride;
+        } else {
+          cb[i] = -1; cy[i] = 0; cx[i] = 0;
+        }
+      }
+    }
+    if constexpr (CONV) conv_set_tap(0);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      int q = i * 512 + tid;
+      if (q >= WCH) q -= WCH;                 // BN=160: the last instruction re-fetches rows 0..31 (same bytes, same slot)
+      const int row = q >> 3;
+      wsrc[i] = reinterpret_cast<const char*>(ip.w) + ((long)(n0 + row) * ip.K + swz5(row, cs) * 8) * 2;
+    }
+    tap_next = 0; in_tap = 0;
+  };
+  auto park_on_zero_page = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) xsrc[i] = zero + lane * 16;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wsrc[i] = zero + lane * 16;
+  };
+  auto issue_group = [&](int stage) __attribute__((always_inline)) {
+    bf16_t* st = smem + stage * STAGE_ELEMS;
+    bf16_t* sw = st + BM5 * BK5;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) glds16_5(xsrc[i], st + (i * 512 + wave * 64) * 8);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int qb = (i * 512 + wave * 64 >= WCH) ? i * 512 + wave * 64 - WCH : i * 512 + wave * 64;
+      glds16_5(wsrc[i], sw + qb * 8);
+    }
+  };
+  auto advance_cursor = [&]() __attribute__((always_inline)) {
+    if (parked) return;
+    if (++is_kt == nk) {
+      is_kt = 0;
+      i_tile += (int)gridDim.x;
+      if (i_tile < total_tiles) setup_tile(); else { parked = true; park_on_zero_page(); }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wsrc[i] += BK5 * 2;
+    if constexpr (!CONV) {
+      const bool to_a2 = ip.a2 != nullptr && is_kt * BK5 == ip.k_split;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) xsrc[i] += BK5 * 2 + (to_a2 ? xjump[i] : 0L);
+    } else {
+      if (++in_tap == tiles_per_tap) {
+        in_tap = 0;
+        conv_set_tap(++tap_next);
+      } else {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) xsrc[i] += BK5 * 2;
+      }
+    }
+  };
+
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  // fragment addresses (bytes inside a stage): lane (fr, fq) reads row base + fr, chunk 4 ks + fq
+  unsigned wrd[2], xrd[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int wrow = wn * (BN / 2) + fr, xrow = wm * 16 * MI + fr;
+    wrd[ks] = (unsigned)(((BM5 * BK5) + wrow * BK5 + swz5(wrow, ks * 4 + fq) * 8) * 2);   // (16 i more rows keep the swizzle: (row >> 1) & 7 of row + 16 i)
+    xrd[ks] = (unsigned)((xrow * BK5 + swz5(xrow, ks * 4 + fq) * 8) * 2);
+  }
+
+  setup_tile();
+  issue_group(0); advance_cursor();
+  issue_group(1); advance_cursor();
+  auto wait_all_but_newest = [&]() __attribute__((always_inline)) {       // all of this thread's DMA groups but the youngest have landed
+    if constexpr (LOADS == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (LOADS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    static_assert(LOADS >= 4 && LOADS <= 7, "counted wait");
+  };
+  wait_all_but_newest();                      // own part of K tile 0 landed
+
+  int stage = 0;
+  bool first_tile = true;
+  [[maybe_unused]] int stamp_i = 1;
+  for (int tile = blockIdx.x; tile < total_tiles; tile += (int)gridDim.x) {
+    int tm, tn;
+    gemm_tile_of_block(tile, n_mt, n_nt, pk.xcd_map, tm, tn);
+    GemmArgs p = pk;
+    gemm_select_seg(p, pk, tm);
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ln_rstd[MI];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) ln_rstd[j] = 1.0f;
+    if constexpr (!CONV) {
+      if (p.ln_stats != nullptr) gemm_ln_init<NI, MI>(p, acc, tm * BM5 + wm * 16 * MI, tn * BN + wn * (BN / 2), fr, fq, ln_rstd);
+    }
+    // every wave's part of K tile 0 has landed: the first tile says so here; a later tile's K tile 0 was waited for in the last L phase of
+    // the tile before it, two barriers ago
+    if (first_tile) { MX5_BAR(); first_tile = false; }
+    if (group_b) MX5_BAR();                   // group B runs one barrier behind group A
+    if (stamp_i == 1) MX5_STAMP(1);
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---- L: all fragments of this K tile, the DMA share of the K tile two ahead (of this tile or the next), the cursor ----
+      const char* sb = reinterpret_cast<const char*>(smem) + stage * (STAGE_ELEMS * 2);
+      bf16x8 wf[2][NI], xf[2][MI];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(sb + wrd[ks] + i * (16 * BK5 * 2));
+#pragma unroll
+        for (int j = 0; j < MI; ++j) xf[ks][j] = *reinterpret_cast<const bf16x8*>(sb + xrd[ks] + j * (16 * BK5 * 2));
+      }
+      const int st2 = stage >= 1 ? stage - 1 : NSTAGE5 - 1;      // (kt + 2) % 3: the stage of K tile kt - 1
+      issue_group(st2);
+      advance_cursor();
+      wait_all_but_newest();                                      // own part of K tile kt + 1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the fragment reads have returned: the stage may be restaged one phase from now
+      __builtin_amdgcn_sched_barrier(0);
+      MX5_BAR();
+      // ---- M: registers only ----
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      MX5_BAR();
+      stage = stage == NSTAGE5 - 1 ? 0 : stage + 1;
+    }
+    if (stamp_i == 1) MX5_STAMP(2);
+    if (!group_b) MX5_BAR();                  // re-align the two groups
+
+    const int m0 = tm * BM5, n0 = tn * BN;
+    static_assert(!GEGLU || (NI % 4 == 0 && !CONV), "the gated epilogue pairs whole 32-feature halves");
+    gemm_epilogue_regs<NI, MI, GEGLU, VEC, true, true, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
+    if (stamp_i == 1) MX5_STAMP(3);
+    stamp_i = 2;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the past-the-end DMAs are drained before the workgroup retires
+}
+
+// bn: 160 or 128 features per tile; rows: 256, or 128 when the 256-row tiling would leave most CUs idle (small M)
+int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows) {
+  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, rows)) * (a.N / bn);
+  const int ncu = cu_count();
+  dim3 grid(tiles > ncu && ncu > 0 ? ncu : tiles), block(512);      // persistent above one tile per CU
+#define MX_V5(BN_, CONV_, FEAT_, GEGLU_, VEC_) hipLaunchKernelGGL((gemm_v5_kernel<BN_, 4, CONV_, FEAT_, GEGLU_, VEC_>), grid, block, 0, s, a)
+  (void)rows;                                 // (the 128-row instantiation MI = 2 was measured and is not built: see the dispatcher in gemm_bf16.hip)
+  const int feat = gemm_epi_features(a.flags);
+  const bool vec = a.rowbias || a.gate;       // per-sample vectors: compiled in only where asked for (40 registers of the epilogue)
+  if (a.flags & MX_EPI_GEGLU) {               // (pick_tile: 128 features only; the gated epilogue takes no per-sample vectors)
+    if (feat & EPI_F_ACT) MX_V5(128, false, EPI_F_ACT, true, false); else MX_V5(128, false, 0, true, false);
+  } else if (conv) {
+    if (bn == 160) { if (feat == 0 && !vec) MX_V5(160, true, 0, false, false); else if (feat == 0) MX_V5(160, true, 0, false, true); else MX_V5(160, true, EPI_F_ALL, false, true); }
+    else { if (feat == 0 && !vec) MX_V5(128, true, 0, false, false); else if (feat == 0) MX_V5(128, true, 0, false, true); else MX_V5(128, true, EPI_F_ALL, false, true); }
+  } else if (bn == 160) {
+    if (feat == 0 && !vec) MX_V5(160, false, 0, false, false); else if (feat == EPI_F_QKV && !vec) MX_V5(160, false, EPI_F_QKV, false, false);
+    else MX_V5(160, false, EPI_F_ALL, false, true);
+  } else {
+    if (feat == 0 && !vec) MX_V5(128, false, 0, false, false); else if (feat == EPI_F_QKV && !vec) MX_V5(128, false, EPI_F_QKV, false, false);
+    else MX_V5(128, false, EPI_F_ALL, false, true);
+  }
+#undef MX_V5
+  return 0;
+}
+
+}  // namespace mx

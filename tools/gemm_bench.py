@@ -13,6 +13,8 @@ SHAPES = [  # (kind, M, N, K or (hw, cin))
     ("gemm", 8192, 1280, 1280), ("gemm", 8192, 1280, 5120), ("gemm", 8192, 3840, 1280), ("geglu", 8192, 10240, 1280),
     ("gemm", 32768, 640, 640), ("geglu", 32768, 5120, 640), ("gemm", 32768, 640, 2560),
     ("conv", 8, 1280, (32, 1280)), ("conv", 8, 320, (128, 320)), ("conv", 8, 640, (64, 640)),
+    # more launches of several rounds of 256 x 160 tiles (the 64 x 64 and 128 x 128 levels)
+    ("gemm", 32768, 1920, 640), ("conv", 8, 320, (128, 640)), ("conv", 8, 640, (64, 1280)),
     # SD3.5-medium image-stream shapes (M = 8 x 4096 tokens, d = 1536)
     ("gemm", 32768, 4608, 1536), ("gemm", 32768, 1536, 1536), ("gemm", 32768, 6144, 1536), ("gemm", 32768, 1536, 6144),
 ]
