@@ -432,6 +432,38 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   // and acc * 1 + bias is acc + bias exactly)
   const bool stats = STATS && !GEGLU && !qkv && p.stats_out != nullptr;
 
+  // ---- V^T waves of the fused q | k | v projection: keys along the lanes, 2-byte stores (see gemm_epilogue); nothing else applies to them
+  //      (no RMSNorm, no q scale, no residual), so they take their own short path here -- with their own token walk, so that neither this
+  //      path's state nor the row arrays below are alive in the other (round 3: held together they spilled, and every reload of a spilled
+  //      address waits on vmcnt = on all the stores issued before it) ----
+  if constexpr ((FEAT & EPI_F_QKV) != 0) {
+    if (qkv && to_vt) {
+      const int rpb_v = p.rows_per_batch > 0 ? p.rows_per_batch : 0x7fffffff;
+      const int m_first = m_wave0 + fr;
+      int bv = p.rows_per_batch > 0 ? m_first / p.rows_per_batch : 0;
+      int rv = m_first - bv * (p.rows_per_batch > 0 ? p.rows_per_batch : 0);
+      const int key_off = p.c_batch_rows > 0 ? p.c_row_off : 0;
+      const int nv = p.N / p.period;
+      const long feat0 = (long)seg_grp * p.seg + (wave_n0 - seg_idx * p.seg) + fq * 4;     // V feature of v[0][0]
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        if (m_first + 16 * j < p.M) {
+          const int key = MX_VT_POS(key_off + rv);
+          bf16_t* dst = p.vt + ((long)bv * nv + feat0) * p.ldvt + key;
+          const float rs = STATS ? ln_rstd_a[j] : 1.0f;
+#pragma unroll
+          for (int i = 0; i < NIO; ++i) {
+            const f32x4 t = STATS ? acc[i][j] * rs + bias_r[i] : acc[i][j] + bias_r[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[(long)(i * 16 + q) * p.ldvt] = f32_to_bf16(t[q]);
+          }
+        }
+        rv += 16;
+        if (rv >= rpb_v) { rv -= rpb_v; ++bv; }
+      }
+      return;
+    }
+  }
   // ---- rows.  Lane (fr, fq) holds token m_j = m_wave0 + 16 j + fr of token block j; its lane pair (fr ^ 1) holds tokens A_j = m_j & ~1 and
   //      B_j = A_j + 1.  A token is (batch b, row r inside the batch): m = b * rows_per_batch + r, and its output row is b * c_batch_rows +
   //      c_row_off + r (joint-sequence remap; without it the row is m).  ONE integer division per lane finds (b, r) of A_0; every later
@@ -447,7 +479,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   const int row_last = b_last * cbr + cro + r_last;
   const int mA0 = (m_wave0 + fr) & ~1;
   int row_a[MI], row_b[MI];                    // output rows of A_j, B_j
-  int b_own[(VEC || (FEAT & EPI_F_QKV)) ? MI : 1], r_own[(FEAT & EPI_F_QKV) ? MI : 1];   // batch / row in batch of the lane's own token
+  int bo_walk = 0, ro_walk = 0;                // batch / row in batch of the lane's OWN token at the block load_batch_vectors is called for next
   {
     int bA = p.rows_per_batch > 0 ? mA0 / p.rows_per_batch : 0;
     int rA = mA0 - bA * (p.rows_per_batch > 0 ? p.rows_per_batch : 0);
@@ -458,8 +490,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       const int mA = mA0 + 16 * j;
       row_a[j] = mA < p.M ? bA * cbr + cro + rA : row_last;
       row_b[j] = mA + 1 < p.M ? bB * cbr + cro + rB : row_last;
-      if constexpr (VEC || (FEAT & EPI_F_QKV)) { const int b = odd_lane ? bB : bA; b_own[j] = b < b_last ? b : b_last; }
-      if constexpr ((FEAT & EPI_F_QKV) != 0) r_own[j] = odd_lane ? rB : rA;
+      if constexpr (VEC) { if (j == 0) { bo_walk = odd_lane ? bB : bA; ro_walk = odd_lane ? rB : rA; } }
       rA += 16;
       if (rA >= rpb) { rA -= rpb; ++bA; }
     }
@@ -484,8 +515,11 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   // per-sample vectors (row bias of the time embedding, AdaLN gate) of the lane's token: one token block ahead
   f32x4 rb_r[VEC ? NIO : 1], gate_r[VEC ? NIO : 1];
   auto load_batch_vectors = [&](int j) __attribute__((always_inline)) {
-    if constexpr (VEC) {
-      const int bidx = b_own[j];
+    if constexpr (VEC) {                       // (called for j = 0, 1, 2, ... in order: the walk advances one block per call)
+      (void)j;
+      const int bidx = bo_walk < b_last ? bo_walk : b_last;
+      ro_walk += 16;
+      if (ro_walk >= rpb) { ro_walk -= rpb; ++bo_walk; }
 #pragma unroll
       for (int i = 0; i < NIO; ++i) {
         const int n = wave_n0 + i * 16 + fq * 4;
@@ -513,7 +547,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   };
   u32x4 res_r[DEPTH][NP > 0 ? NP : 1];
   u32x2 res_o[DEPTH];
-  if (!(qkv && to_vt)) {
+  {
 #pragma unroll
     for (int d = 0; d < DEPTH && d < MI; ++d) {
 #pragma unroll
@@ -569,22 +603,6 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       for (int q = 0; q < 4; ++q) v[i][q] = t[q];
     }
     if constexpr (VPF) { if (j + 1 < MI && (has_rb || has_gate)) load_batch_vectors(j + 1); }
-    if constexpr ((FEAT & EPI_F_QKV) != 0) {
-      if (qkv && to_vt) {                      // V^T: keys along the lanes, 2-byte stores (see gemm_epilogue)
-        if (m < p.M) {
-          const int key = MX_VT_POS(cro + r_own[j]);
-          const int nv = p.N / p.period;
-#pragma unroll
-          for (int i = 0; i < NIO; ++i) {
-            const int nin = wave_n0 + i * 16 + fq * 4 - seg_idx * p.seg;
-            bf16_t* dst = p.vt + ((long)b_own[j] * nv + (long)seg_grp * p.seg + nin) * p.ldvt + key;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[(long)q * p.ldvt] = f32_to_bf16(v[i][q]);
-          }
-        }
-        continue;
-      }
-    }
     // ---- pairs of blocks: exchange, then residual -> activation -> store in the row layout ----
     auto finish8 = [&](float (&o)[8], const u32x4 rr) __attribute__((always_inline)) {
       if (has_res) {

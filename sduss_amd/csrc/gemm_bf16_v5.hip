@@ -59,7 +59,8 @@ extern "C" int mx_debug_v5_stamps(unsigned long long* out) { return (int)hipMemc
 
 // MI: 16-wide token blocks per wave; tile rows BM5 = 64 * MI (256, or 128 for small M); FEAT / GEGLU: the epilogue features compiled in
 // (gemm_args.h EPI_F_*; the launcher picks the smallest instantiation that serves the launch)
-template <int BN, int MI, bool CONV, int FEAT, bool GEGLU>
+// VEC: the per-sample vectors (row bias, gate) are compiled in -- 40 registers of the epilogue; without them the QKV form does not spill
+template <int BN, int MI, bool CONV, int FEAT, bool GEGLU, bool VEC>
 __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   constexpr int BM5 = 64 * MI;
   constexpr int NI = BN / 32;                 // 16-wide feature blocks per wave (BN / 2 features)
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
 
   const int m0 = tm * BM5, n0 = tn * BN;
   static_assert(!GEGLU || (NI % 4 == 0 && !CONV), "the gated epilogue pairs whole 32-feature halves");
-  gemm_epilogue_regs<NI, MI, GEGLU, true, true, true, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
+  gemm_epilogue_regs<NI, MI, GEGLU, VEC, true, true, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
   MX5_STAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the past-the-end DMAs are drained before the workgroup retires
 }
@@ -271,18 +272,21 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
 int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows) {
   const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, rows)) * (a.N / bn);
   dim3 grid(tiles), block(512);
-#define MX_V5(BN_, CONV_, FEAT_, GEGLU_) hipLaunchKernelGGL((gemm_v5_kernel<BN_, 4, CONV_, FEAT_, GEGLU_>), grid, block, 0, s, a)
+#define MX_V5(BN_, CONV_, FEAT_, GEGLU_, VEC_) hipLaunchKernelGGL((gemm_v5_kernel<BN_, 4, CONV_, FEAT_, GEGLU_, VEC_>), grid, block, 0, s, a)
   (void)rows;                                 // (the 128-row instantiation MI = 2 was measured and is not built: see the dispatcher in gemm_bf16.hip)
   const int feat = gemm_epi_features(a.flags);
-  if (a.flags & MX_EPI_GEGLU) {               // (pick_tile: 128 features only)
-    if (feat & EPI_F_ACT) MX_V5(128, false, EPI_F_ACT, true); else MX_V5(128, false, 0, true);
+  const bool vec = a.rowbias || a.gate;       // per-sample vectors: compiled in only where asked for
+  if (a.flags & MX_EPI_GEGLU) {               // (pick_tile: 128 features only; the gated epilogue takes no per-sample vectors)
+    if (feat & EPI_F_ACT) MX_V5(128, false, EPI_F_ACT, true, false); else MX_V5(128, false, 0, true, false);
   } else if (conv) {
-    if (bn == 160) { if (feat == 0) MX_V5(160, true, 0, false); else MX_V5(160, true, EPI_F_ALL, false); }
-    else { if (feat == 0) MX_V5(128, true, 0, false); else MX_V5(128, true, EPI_F_ALL, false); }
+    if (bn == 160) { if (feat == 0 && !vec) MX_V5(160, true, 0, false, false); else if (feat == 0) MX_V5(160, true, 0, false, true); else MX_V5(160, true, EPI_F_ALL, false, true); }
+    else { if (feat == 0 && !vec) MX_V5(128, true, 0, false, false); else if (feat == 0) MX_V5(128, true, 0, false, true); else MX_V5(128, true, EPI_F_ALL, false, true); }
   } else if (bn == 160) {
-    if (feat == 0) MX_V5(160, false, 0, false); else if (feat == EPI_F_QKV) MX_V5(160, false, EPI_F_QKV, false); else MX_V5(160, false, EPI_F_ALL, false);
+    if (feat == 0 && !vec) MX_V5(160, false, 0, false, false); else if (feat == EPI_F_QKV && !vec) MX_V5(160, false, EPI_F_QKV, false, false);
+    else MX_V5(160, false, EPI_F_ALL, false, true);
   } else {
-    if (feat == 0) MX_V5(128, false, 0, false); else if (feat == EPI_F_QKV) MX_V5(128, false, EPI_F_QKV, false); else MX_V5(128, false, EPI_F_ALL, false);
+    if (feat == 0 && !vec) MX_V5(128, false, 0, false, false); else if (feat == EPI_F_QKV && !vec) MX_V5(128, false, EPI_F_QKV, false, false);
+    else MX_V5(128, false, EPI_F_ALL, false, true);
   }
 #undef MX_V5
   return 0;

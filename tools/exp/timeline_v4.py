@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from sduss_amd import lib, ops  # noqa: E402
 
-SHAPES = [  # (label, M, N, K, geglu, residual)
+SHAPES = [  # (label, M, N, K, geglu, residual)  -- label starting with "QKV": the fused q | k | v projection with its V^T epilogue
+    ("QKV epilogue (256x256)", 8192, 3840, 1280, False, False),
     ("to_qkv  (256x256)", 8192, 3840, 1280, False, False),
     ("GEGLU   (256x256)", 8192, 10240, 1280, True, False),
     ("GEGLU 64x64 level (256x256)", 32768, 5120, 640, True, False),
@@ -46,6 +47,8 @@ def main():
         bias = torch.randn(n, device="cuda:0", generator=g)
         r = torch.randn(m, n, device="cuda:0", generator=g).to(torch.bfloat16) if res else None
         run = lambda: ops.gemm(a, w, bias, geglu=geglu, residual=r)  # noqa: E731
+        if label.startswith("QKV"):
+            run = lambda: ops.gemm_qkv(a, w, n // 3, 3, 1024, q_scale=0.125, bias=bias)  # noqa: E731
         us = event_us(run)
         torch.cuda.synchronize()
         run(); torch.cuda.synchronize()
