@@ -395,7 +395,10 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   constexpr int NIO = GEGLU ? NI / 2 : NI;     // output blocks per wave
   constexpr int NP = NIO / 2;                  // exchanged pairs
   constexpr bool ODD = (NIO & 1) != 0;         // a last block stored from the accumulator layout
-  constexpr int DEPTH = 2;                     // residual loads run this many token blocks ahead
+  // residual loads run this many token blocks ahead.  Stores and loads share vmcnt on gfx9 and retire in issue order, so a residual load issued
+  // AFTER a block's stores cannot be consumed before those stores are acknowledged: the 256-row x 160/128 kernels (MI = 4) therefore request
+  // the whole residual tile before their first store (40 registers); the 256 x 256 kernel (MI = 8) has no room for that and stays 2 ahead
+  constexpr int DEPTH = MI <= 4 ? MI : 2;
   static_assert(!GEGLU || NI % 4 == 0, "GEGLU: hidden and gate halves must be whole pairs");
   const int flags = p.flags;
   constexpr bool ACT = (FEAT & EPI_F_ACT) != 0;
