@@ -81,7 +81,8 @@ enum {
   MX_EPI_GEGLU    = 1 << 1,  /* weight rows interleaved [32 hidden | 32 gate]; out[M, N/2] = h * gelu(g) */
   MX_EPI_OUT_F32  = 1 << 2,  /* C is fp32 instead of bf16 */
   MX_EPI_QKV      = 1 << 3,  /* column segments of width seg: segment s with (s % period) == period-1
-                                is written transposed into vt[b][vcol][key]; others row-major, compacted */
+                                is written transposed into vt[b][vcol][key]; others row-major, compacted.
+                                Excludes rowbias / gate / residual (error otherwise) */
   MX_EPI_GELU_TANH = 1 << 4, /* out = gelu(v), tanh approximation (diffusers FeedForward "gelu-approximate") */
   MX_EPI_RES_BCAST = 1 << 5, /* residual row = output row modulo rows_per_batch (positional table broadcast over the batch) */
   MX_EPI_RMSNORM  = 1 << 6,  /* with MX_EPI_QKV: RMS-normalise every 64-wide head of the q and k segments (see rms_wq below) */

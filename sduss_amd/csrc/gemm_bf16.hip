@@ -398,6 +398,7 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     }
     MX_CHECK(d->ldc >= d->N / d->period * (d->period - 1) && d->ldc % 4 == 0, "gemm: bad ldc for QKV");
     MX_CHECK(!(d->flags & MX_EPI_OUT_F32), "gemm: QKV output is bf16");
+    MX_CHECK(!d->rowbias && !d->gate && !d->residual, "gemm: QKV excludes the per-sample vectors and the residual (its V^T segment takes none of them)");
     if (d->flags & MX_EPI_RMSNORM)
       MX_CHECK(d->rms_wq && d->rms_wk && d->period == 3 && d->N % 128 == 0 && !conv, "gemm: RMSNORM needs rms_wq/rms_wk, period 3, N % 128 == 0");
   } else {
