@@ -94,10 +94,32 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sd3", action="store_true", help="skip the SD3.5-medium block (configs[2]) of the default SDXL run")
     ap.add_argument("--no-parity", action="store_true", help="skip the check of one row of the bench batch against the oracle")
+    ap.add_argument("--pp", type=int, default=None, help="configs[3] leg: ONE 1024^2 request row-split over this many ranks (distrifuser-style patch parallelism, "
+                                                         "stale-asynchronous mode after its warm-up); default = --gpus when --gpus > 1 (0 = skip); must divide --gpus")
+    ap.add_argument("--pp-steps", type=int, default=10, help="timed stale steps of the --pp leg (after the 5 synchronous warm-up steps, which are timed too)")
+    ap.add_argument("--no-two-model", action="store_true", help="skip the configs[4] leg with SDXL and SD3.5 requests interleaved in one stream")
     a = ap.parse_args()
     if a.mix is None:
         a.mix = 40 if (a.model == "sdxl" and a.res == 1024) else 0
+    if a.pp is None:
+        a.pp = a.gpus if (a.gpus > 1 and a.model == "sdxl") else 0
+    if a.pp and (a.pp < 2 or a.gpus % a.pp):
+        ap.error(f"--pp {a.pp} must be >= 2 and divide --gpus {a.gpus}")
     return a
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves -- one process per GPU, the reference's
+    worker layout (sduss/executor/mp_executor.py:54-158; distrifuser/scalibility.sh:31 uses torchrun) -- as a CHILD `python -m torch.distributed.run`
+    of this process, which has not touched the GPU (no HIP call, no torch.cuda.is_available()), and hand its exit code back.  Never an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def make_batch(den, cfg, n, res, device, shared, base_id=0):
@@ -200,6 +222,152 @@ def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world
         active = [r for r in active if not r.done()]
     rows = [(r.resolution, r.finish - r.arrival) for r in done]
     return rows, (min(r.arrival for r in done), max(r.finish for r in done))
+
+
+def run_two_model(dens, args, device, rate_per_gpu, n_per_gpu, rank, world):
+    """configs[4] as BASELINE.json writes it: ONE arrival-ordered Poisson stream of SDXL *and* SD3.5 requests against replicas that hold BOTH
+    denoisers resident (the reference traces exp/sdxl/qps_*.csv and exp/sd3/qps_*.csv share their column shape and step histogram; the model of a
+    request is drawn uniformly here).  Placement: arrivals and completions replayed through the greedy least-outstanding-pixels dispatcher
+    (dp.replay_placement).  On a replica each model keeps its own FCFS continuous batch (<= --mix-max-batch requests, all resolutions of a step in
+    ONE launch sequence, is_sliced=True / patch 256 as policy/FCFS_Mixed.py:69-70 forces); when both models have work their step batches
+    ALTERNATE, the model holding the oldest request first.  Metrics per model as scripts/draw/get_metric.py (its SLO = 5 deadlines)."""
+    from sduss_amd import dp
+    from sduss_amd.pipeline import synthetic_request
+    from sduss_amd.pipeline_sd3 import synthetic_sd3_request
+    n_total = n_per_gpu * world
+    rng = np.random.RandomState(10086)
+    arrivals = np.cumsum(rng.exponential(1.0 / (rate_per_gpu * world), size=n_total))
+    res_all = rng.choice([512, 768, 1024], size=n_total)
+    steps_all = rng.choice([s for s, _ in REF_STEP_MIX], size=n_total, p=[p for _, p in REF_STEP_MIX])
+    model_all = rng.choice(["sdxl", "sd3"], size=n_total)
+    svc = {r: max(STEP_SECONDS["sdxl"][r], STEP_SECONDS["sd3"][r]) for r in (512, 768, 1024)}
+    place = dp.replay_placement(arrivals, [int(r) for r in res_all], [int(v) for v in steps_all], world, svc, args.mix_max_batch)
+    pending, shared = [], {"sdxl": {}, "sd3": {}}
+    for i in range(n_total):
+        if place[i] != rank:
+            continue
+        m = str(model_all[i])
+        den, cfg = dens[m]
+        mk = synthetic_request if m == "sdxl" else synthetic_sd3_request
+        r = mk(7000 + i, int(res_all[i]), int(steps_all[i]), cfg, den, device, shared=shared[m])
+        r.arrival, r.model = float(arrivals[i]), m
+        pending.append(r)
+    active = {"sdxl": [], "sd3": []}
+    done, last = [], None
+    t0 = time.perf_counter()
+    while pending or active["sdxl"] or active["sd3"]:
+        now = time.perf_counter() - t0
+        keep = []
+        for r in pending:                                   # FCFS admission per model: a full batch of one model does not block the other
+            if r.arrival <= now and len(active[r.model]) < args.mix_max_batch:
+                active[r.model].append(r)
+            else:
+                keep.append(r)
+        pending = keep
+        ready = [m for m in ("sdxl", "sd3") if active[m]]
+        if not ready:
+            time.sleep(max(0.0, min(r.arrival for r in pending) - now))
+            continue
+        if len(ready) == 2:                                 # alternate; the model of the oldest request goes first
+            m = ("sd3" if last == "sdxl" else "sdxl") if last else min(ready, key=lambda k: min(r.arrival for r in active[k]))
+        else:
+            m = ready[0]
+        last = m
+        by_res = {}
+        for r in active[m]:
+            by_res.setdefault(str(r.resolution), []).append(r)
+        dens[m][0].denoising_step(by_res, is_sliced=True, patch_size=256)
+        torch.cuda.synchronize()
+        now = time.perf_counter() - t0
+        for r in [r for r in active[m] if r.done()]:
+            r.finish = now
+            done.append(r)
+        active[m] = [r for r in active[m] if not r.done()]
+    rows = [(r.model, r.resolution, r.finish - r.arrival) for r in done]
+    return rows, (min(r.arrival for r in done), max(r.finish for r in done))
+
+
+def two_model_summary(rows, window, rate):
+    span = window[1] - window[0]
+    out = {"offered_req_per_s_per_gpu": rate, "requests": len(rows), "throughput_req_per_s": len(rows) / span, "per_model": {}}
+    ok_all = 0
+    for m in ("sdxl", "sd3"):
+        mine = [(r, l) for mm, r, l in rows if mm == m]
+        if not mine:
+            continue
+        ok = sum(1 for r, l in mine if l <= REF_DEADLINES_S[m][int(r)])
+        ok_all += ok
+        lat = [l for _r, l in mine]
+        out["per_model"][m] = {"requests": len(mine), "slo_rate": ok / len(mine), "p50_latency_s": float(np.percentile(lat, 50)),
+                               "p90_latency_s": float(np.percentile(lat, 90)), "avg_latency_s": float(np.mean(lat)), "goodput_req_per_s": ok / span,
+                               "deadlines_s": REF_DEADLINES_S[m]}
+    out["slo_rate"], out["goodput_req_per_s"] = ok_all / len(rows), ok_all / span
+    out["policy"] = ("both denoisers resident on every replica; one arrival-ordered stream, the model of a request drawn uniformly; per model an FCFS continuous batch "
+                     "(all resolutions of a step in ONE launch sequence, is_sliced=True / patch 256); the two models' step batches alternate")
+    return out
+
+
+def run_pp(net, args, dist, device, rank, world):
+    """configs[3]: ONE 1024^2 SDXL request (CFG: UNet batch 2) with its latent rows split over --pp ranks, distrifuser's DistriUNetPP
+    (distrifuser/distrifuser/distrifuser/models/distri_sdxl_unet_pp.py:15-216; launched there by scalibility.sh:31) in its default mode: 5 synchronous
+    warm-up steps, then stale-asynchronous steps ("corrected_async_gn").  Every group of --pp consecutive ranks serves its own request.  Reports the
+    per-step time of both modes (max over ranks, fenced), the bytes a rank sends / receives per stale step and the collectives it issues, beside the
+    same request on ONE GPU."""
+    from sduss_amd import dp
+    from sduss_amd.patch_parallel import CommLog, PatchParallelUNet
+    pp = args.pp
+    group = None
+    if pp != world:
+        groups = [dist.new_group(list(range(g * pp, (g + 1) * pp))) for g in range(world // pp)]
+        group = groups[rank // pp]
+    log = CommLog()
+    ppnet = PatchParallelUNet(net, group=group, log=log, mode="corrected_async_gn")
+    cfg = net.cfg
+    g = torch.Generator().manual_seed(10086)                       # the same request on every rank of a group
+    h = args.res // 8
+    lat = torch.randn(2, cfg.in_channels, h, h, generator=g).to(device=device, dtype=torch.bfloat16)
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).to(device=device, dtype=torch.bfloat16)
+    text = torch.randn(2, cfg.text_embed_dim, generator=g).to(device=device, dtype=torch.bfloat16)
+    tids = torch.tensor([[args.res, args.res, 0, 0, args.res, args.res]] * 2, dtype=torch.float32, device=device)
+    ts = torch.full((2,), 801.0, device=device)
+    use_dev = None if dist.get_backend() == "gloo" else device
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        ppnet.wait_pending()
+        fence()
+        return dp.max_over_ranks((time.perf_counter() - t0) / n, dist, use_dev), out
+
+    one = lambda: net.forward_one(lat, ts, ehs, text, tids)
+    one(); one()
+    single_s, want = timed(one, max(3, args.pp_steps))
+    f = lambda: ppnet.forward(lat, ts, ehs, text, tids)
+    sync_s, out_sync = timed(f, ppnet.warmup_steps + 1)            # the warm-up steps ARE the synchronous mode
+    sync_calls = len(log.calls) // (ppnet.warmup_steps + 1)
+    sync_bytes = sum(nb for _s, _r, nb in log.calls) // (ppnet.warmup_steps + 1)
+    log.calls.clear()
+    stale_s, out_stale = timed(f, args.pp_steps)
+    assert ppnet.last_step_mode == 2, "the timed steps of the --pp leg must be stale-asynchronous ones"
+    stale_calls = len(log.calls) // args.pp_steps
+    stale_bytes = sum(nb for _s, _r, nb in log.calls) // args.pp_steps
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    return {"ranks_per_request": pp, "request_groups": world // pp, "resolution": args.res, "unet_batch": 2,
+            "mode": "distrifuser default: 5 synchronous warm-up steps, then stale-asynchronous steps (corrected_async_gn)",
+            "ms_per_step_one_gpu": 1e3 * single_s, "ms_per_step_sync": 1e3 * sync_s, "ms_per_step_stale": 1e3 * stale_s,
+            "speedup_stale_vs_one_gpu": single_s / stale_s,
+            "collectives_per_step": {"sync": sync_calls, "stale": stale_calls},
+            "sent_MB_per_rank_per_step": {"sync": sync_bytes / 1e6, "stale": stale_bytes / 1e6},
+            "received_MB_per_rank_per_step": {"sync": sync_bytes * (pp - 1) / 1e6, "stale": stale_bytes * (pp - 1) / 1e6},
+            "rel_l2_vs_one_gpu": {"sync": rel(out_sync, want), "stale_on_unchanged_inputs": rel(out_stale, want)},
+            "backend": dist.get_backend(),
+            "note": "UNet forward incl. the final gather of the output rows; the element-wise scheduler step either side (microseconds) is not in it"}
 
 
 def probe_diffusers():
@@ -404,15 +572,54 @@ def parity_row_inputs(net, reqs, P, guidance_rows=True):
     return got[k:k + 1].float().cpu(), (P32, f(x), f(ts2).reshape(1), f(ehs), f(pooled), f(tids)), k
 
 
+def dry_rehearsal(args, rank, world):
+    """MX_BENCH_REHEARSE=dry (tests/test_dp_gloo.py, no GPU): the launch / rendezvous / fence / max-over-ranks / single-line control flow of an
+    N-rank run with the denoising step replaced by a 1-ms sleep.  Nothing is computed and the line says so; it exists so that the self-spawn path
+    and the rank accounting can be exercised where no GPU is present."""
+    from sduss_amd import dp
+    dist = None
+    seen = [(rank, "cpu")]
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, "cpu"))
+    if len({s_[0] for s_ in seen}) != args.gpus:
+        raise SystemExit(f"bench.py: {len(seen)} ranks answered, --gpus {args.gpus}")
+    fence = (lambda: dist.barrier()) if dist is not None else (lambda: None)
+    for _ in range(args.warmup):
+        time.sleep(1e-3)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    fence()
+    step_s = dp.max_over_ranks(time.perf_counter() - t0, dist, None) / args.steps
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec (node), SDXL 1024^2 50-step, fixed prompt, CFG", "value": world * args.batch / (MODELS[args.model]["steps"] * step_s),
+                          "unit": "images/s", "rehearsal": "MX_BENCH_REHEARSE=dry: NO GPU WORK -- the step is a 1-ms sleep; control-flow check of the N-rank launch only",
+                          "n_gpus": world, "ranks_seen": len({s_[0] for s_ in seen}), "rank_devices": [s_[1] for s_ in sorted(seen)],
+                          "backend": "gloo" if dist is not None else "none (single process)", "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none"}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     global STEPS_PER_IMAGE
     args = parse()
     mdl = MODELS[args.model]
     STEPS_PER_IMAGE = mdl["steps"]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                    # before any GPU call in this process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined (WORLD_SIZE={world}): refusing to report a line for fewer ranks than asked")
+    if os.environ.get("MX_BENCH_REHEARSE") == "dry":
+        return dry_rehearsal(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # MX_BENCH_REHEARSE=1: all ranks on cuda:0 over gloo -- walks the N > 1 control flow (barriers, max over ranks, gathers, rank-0 line)
@@ -428,6 +635,13 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)   # RCCL; used for the barrier + max-over-ranks only: replicas share nothing
+    ranks_seen, rank_devices, backend = 1, [dev_index], None
+    if dist is not None:
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, dev_index, torch.cuda.get_device_properties(dev_index).name))
+        ranks_seen, rank_devices, backend = len({s_[0] for s_ in seen}), [s_[1] for s_ in sorted(seen)], dist.get_backend()
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"bench.py: {ranks_seen} distinct ranks answered, --gpus {args.gpus}")
 
     from sduss_amd import dp
     cfg, net, den, P = build_model(args.model, device)
@@ -463,7 +677,7 @@ def main():
     result = {
         "metric": h["metric"], "value": h["value"], "unit": "images/s",
         **({"rehearsal": "MX_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- control-flow check only, the numbers mean nothing"} if rehearse else {}),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["ms_per_step"],
+        "n_gpus": world, "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend or "none (single process)", "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": h["config"], "outputs_finite": finite,
         "achieved_tflops_whole_step": h["achieved_tflops_whole_step"], "frac_of_mfma_peak_whole_step": h["frac_of_mfma_peak_whole_step"],
@@ -525,6 +739,33 @@ def main():
                                       "policy": "FCFS mixed batching (policy/FCFS_Mixed.py); the resolutions of a step run in ONE launch sequence "
                                                 "(grouped launches)" if args.model == "sdxl" else "FCFS mixed batching; resolutions of a step as concurrent launch sequences"}
 
+    # ---- configs[3] leg: one request row-split over --pp ranks (patch parallelism), every rank takes part ----
+    if args.pp and dist is not None and args.model == "sdxl":
+        try:
+            pp_res = run_pp(net, args, dist, device, rank, world)
+        except Exception as e:                                  # never fatal for the headline line (all ranks fail or pass together: same code path)
+            pp_res = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            result["patch_parallel"] = pp_res
+        dist.barrier()
+
+    # ---- configs[4] as written: SDXL and SD3.5 requests interleaved in one stream, both denoisers resident (every rank) ----
+    sd3_built = None
+    if args.model == "sdxl" and args.res == 1024 and args.mix > 0 and not args.no_two_model and not args.no_sd3:
+        try:
+            cfg3, net3, den3, P3 = build_model("sd3", device)
+            del P3
+            sd3_built = (cfg3, net3, den3)
+            rows2, win2 = run_two_model({"sdxl": (den, cfg), "sd3": (den3, cfg3)}, args, device, 1.0, args.mix, rank, world)
+            rows2, win2 = dp.gather_stream_stats(rows2, win2, dist)
+            if rank == 0:
+                result.setdefault("mixed_stream", {})["two_model"] = two_model_summary(rows2, win2, 1.0)
+        except Exception as e:
+            if rank == 0:
+                result.setdefault("mixed_stream", {})["two_model"] = {"error": f"{type(e).__name__}: {e}"}
+        if dist is not None:
+            dist.barrier()
+
     # ---- informative: the stages either side of the denoising loop (not part of `value`, which is the loop as BASELINE.json defines it) ----
     if rank == 0 and not args.no_stages and args.model == "sdxl" and args.res == 1024:
         try:
@@ -539,8 +780,12 @@ def main():
             torch.cuda.empty_cache()
             m3 = MODELS["sd3"]
             STEPS_PER_IMAGE = m3["steps"]
-            cfg3, net3, den3, P3 = build_model("sd3", device)
-            del P3
+            if sd3_built is not None:
+                cfg3, net3, den3 = sd3_built
+                sd3_built = None
+            else:
+                cfg3, net3, den3, P3 = build_model("sd3", device)
+                del P3
             reqs3 = make_batch(den3, cfg3, args.batch, 1024, device, {})
             s3, step3 = timed_steps(den3, reqs3, "1024", args, None, device, False)
             fin3 = all(torch.isfinite(r.latents.float()).all().item() for r in reqs3)

@@ -59,6 +59,10 @@ int mx_profile_records(double* out, int max_records);
  *   Differences, on purpose: statistics are kept in fp32 (the reference rounds them to the
  *   tensor dtype, cpp:84-85); the merge is out of place (the reference's in-place merge races);
  *   no device synchronisation (reference: cudaDeviceSynchronize after every launch).
+ *   The halo is GATHERED by the receiving plane through the inverse of padding_idx (receiver r's side d is written by the b with
+ *   padding_idx[b][opposite(d)] == r) with the SENDER's statistics, so the result equals the reference's sender-driven scatter for every
+ *   table in which a halo side has at most one writer -- symmetric adjacency (what split_sample produces) is NOT required; with two
+ *   writers for one cell the reference's scatter races and the value here is that of one of them.  Entries must be -1 or in [0, N).
  *
  * mx_halo_only == esymred_mp.mock_groupnorm (cpp:66-74): the same scatter with identity values.
  * ------------------------------------------------------------------------------------------ */

@@ -34,21 +34,25 @@ from .sdxl_unet_ref import (UNetConfig, attention, time_and_aug_embedding)
 # --------------------------------------------------------------------------------------
 # split / concat   (unet.py:104-202)
 # --------------------------------------------------------------------------------------
-def split_sample(samples: Dict[str, torch.Tensor], patch_size: int):
+def split_sample(samples: Dict[str, torch.Tensor], patch_size: int, input_indices: Optional[Dict[str, List[str]]] = None):
     """Returns (padding_idx[int32, 4N] (top,left,bottom,right), latent_offset, resolution_offset,
-    patches [N, C, p+2, p+2], patch_map (1-based latent index per patch))."""
+    patches [N, C, p+2, p+2], patch_map (1-based latent index per patch)); with ``input_indices`` (request ids per resolution) also the
+    per-patch cache keys "<id>-<h>-<w>" (unet.py:163; modules/utils.py:37,60).  Pinned bit for bit against the reference function itself:
+    tests/golden/ref_split_sample.npz (tests/test_ref_fixtures.py)."""
     latent_offset = [0]
     patch_map: List[int] = []
     resolution_offset = [0]
     padding_idx: List[List[int]] = []
     new_sample: List[torch.Tensor] = []
+    keys: List[str] = []
     for resolution, res_sample in samples.items():
+        res_key = resolution
         resolution = int(resolution)
         pn = resolution // patch_size
         lp = patch_size // 8
         if res_sample is None or res_sample.shape[0] == 0:
             continue
-        for sample in res_sample:
+        for si, sample in enumerate(res_sample):
             latent_offset.append(latent_offset[-1] + pn ** 2)
             s = F.pad(sample, (1, 1, 1, 1), "constant", 0).unsqueeze(0)
             for h in range(pn):
@@ -65,9 +69,12 @@ def split_sample(samples: Dict[str, torch.Tensor], patch_size: int):
                     new_sample.append(s[:, :, h * lp:(h + 1) * lp + 2, w * lp:(w + 1) * lp + 2])
                     patch_map.append(len(latent_offset) - 1)
                     padding_idx.append(pad)
+                    if input_indices is not None:
+                        keys.append(input_indices[str(res_key)][si] + f"-{h}-{w}")
         resolution_offset.append(len(latent_offset) - 1)
-    return (torch.tensor(padding_idx, dtype=torch.int32).reshape(-1), latent_offset, resolution_offset,
-            torch.cat(new_sample, dim=0), torch.tensor(patch_map, dtype=torch.int32))
+    out = (torch.tensor(padding_idx, dtype=torch.int32).reshape(-1), latent_offset, resolution_offset,
+           torch.cat(new_sample, dim=0), torch.tensor(patch_map, dtype=torch.int32))
+    return out + (keys,) if input_indices is not None else out
 
 
 def concat_sample(patch_size: int, new_sample: torch.Tensor, latent_offset: List[int]) -> Dict[str, torch.Tensor]:

@@ -9,8 +9,9 @@
 //   merge_kernel        mean of patch means, rsqrt(mean of patch variances+eps) (cu:361-386)
 //   apply_gather_kernel y = x*(rstd*gamma) + (beta - rstd*gamma*mean) into the interior of the [H+2, W+2] plane, and the plane's
 //                       1-pixel frame GATHERED from the neighbour patches' edge pixels (the reference scatters them from the
-//                       sender, cu:164-241, 285-357; the cells and values are the same: a neighbour belongs to the same latent, so
-//                       after the merge it has the same mean / rstd, and the same channel's gamma / beta).  Every block writes its
+//                       sender, cu:164-241, 285-357; the cells and values are the same: round 4 -- the writer of a halo side is looked up
+//                       in the INVERSE of padding_idx, built per block in LDS, and the sender's mean / rstd are applied, so no symmetry
+//                       of the table and no same-latent assumption is needed).  Every block writes its
 //                       whole padded plane and nothing else: no zero pass (torch::zeros, cpp:71,92), no cross-block writes, and the
 //                       plane leaves as aligned 8-byte / 16-byte stores after a transpose-free staging in LDS (round 2: the round-1
 //                       form moved 2 bytes per lane).  Moments read 16 bytes per lane.
@@ -92,14 +93,27 @@ template <typename T, bool AFFINE>
 __global__ __launch_bounds__(256) void apply_gather_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ gamma,
                                                            const T* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const int* __restrict__ padding_idx, int C,
-                                                           int H, int W, int cpg, int PB, long planes) {
+                                                           int H, int W, int cpg, int PB, long planes, int N) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int HW = H * W, W2 = W + 2, total = (H + 2) * W2;
   T* tile = reinterpret_cast<T*>(lds_raw);                  // [PB][total]
   float* coef = reinterpret_cast<float*>(lds_raw + (((size_t)PB * total * sizeof(T)) + 15) / 16 * 16);   // [PB][2]
+  int* inv = reinterpret_cast<int*>(coef + 2 * PB);          // [patches of this block][4]: who WRITES my top / left / bottom / right halo
   const long plane0 = (long)blockIdx.x * PB;
   const int npl = (int)((planes - plane0) < PB ? (planes - plane0) : PB);
   const int t = threadIdx.x;
+  // The reference scatters: sender b writes into the halo of padding_idx[b][d] (cu:164-241).  This kernel gathers, so it needs the inverse:
+  // the sender of receiver r's side d is the b with padding_idx[b][opposite(d)] == r.  For split_sample's tables that is padding_idx[r][d]
+  // itself (symmetric adjacency); computing it makes the op equal to the reference's for ANY table in which a halo cell has one writer
+  // (with several the reference races).  The planes of a block span at most PB / C + 2 patches; the whole table is N * 4 ints in L2.
+  const int n_first = (int)(plane0 / C), n_last = (int)((plane0 + npl - 1) / C);
+  for (int e = t; e < (n_last - n_first + 1) * 4; e += 256) inv[e] = -1;
+  __syncthreads();
+  for (int e = t; e < N * 4; e += 256) {
+    const int nb = padding_idx[e];
+    if (nb >= n_first && nb <= n_last) inv[(nb - n_first) * 4 + (((e & 3) + 2) & 3)] = e >> 2;
+  }
+  // (published by the barrier below / the one in front of the frame pass)
   if (AFFINE) {
     for (int pl = t; pl < npl; pl += 256) {
       const long plane = plane0 + pl;
@@ -113,6 +127,14 @@ __global__ __launch_bounds__(256) void apply_gather_kernel(const T* __restrict__
     __syncthreads();
   }
   auto tr = [&](T v, int pl) __attribute__((always_inline)) -> T { return AFFINE ? cvt<T>(ldf<T>(&v, 0) * coef[2 * pl] + coef[2 * pl + 1]) : v; };
+  // a halo cell carries the SENDER's normalisation (it is a copy of the sender's output pixel): the same numbers as the receiver's when both
+  // lie in one latent, which split_sample guarantees; evaluated here for the sender so that tables linking two latents are served too
+  auto tr_from = [&](T v, int nb, int c) __attribute__((always_inline)) -> T {
+    if (!AFFINE) return v;
+    const int G = C / cpg, g = c / cpg;
+    const float sc = rstd[nb * G + g] * (gamma ? ldf<T>(gamma, c) : 1.f);
+    return cvt<T>(ldf<T>(&v, 0) * sc + ((beta ? ldf<T>(beta, c) : 0.f) - sc * mean[nb * G + g]));
+  };
   // ---- interiors: the npl input planes are one contiguous run ----
   const T* xp = x + plane0 * HW;
   constexpr int VE = 16 / (int)sizeof(T);
@@ -136,6 +158,7 @@ __global__ __launch_bounds__(256) void apply_gather_kernel(const T* __restrict__
     }
   }
   // ---- frames: rows from the top / bottom neighbours, columns and corners from the left / right neighbours (cu:186-241) ----
+  __syncthreads();                                           // inv complete (also when !AFFINE, which has no barrier above)
   const T zero = cvt<T>(0.f);
   const int per = 2 * W2 + 2 * H;
   for (int kk = t; kk < npl * per; kk += 256) {
@@ -148,14 +171,14 @@ __global__ __launch_bounds__(256) void apply_gather_kernel(const T* __restrict__
     else { const int j = k - 2 * W2; row = 1 + (j >> 1); col = (j & 1) ? W + 1 : 0; }
     T v = zero;
     if (col == 0 || col == W + 1) {
-      const int nb = padding_idx[n * 4 + (col == 0 ? 1 : 3)];   // left neighbour's last column / right neighbour's first column;
+      const int nb = inv[(n - n_first) * 4 + (col == 0 ? 1 : 3)];   // written by the patch on my left (its last column) / right (its first);
       if (nb != -1) {                                          // corners replicate that neighbour's corner pixel (cu:210-221, 228-239)
         const int sr = row == 0 ? 0 : row == H + 1 ? H - 1 : row - 1;
-        v = tr(x[((long)nb * C + c) * HW + (long)sr * W + (col == 0 ? W - 1 : 0)], pl);
+        v = tr_from(x[((long)nb * C + c) * HW + (long)sr * W + (col == 0 ? W - 1 : 0)], nb, c);
       }
     } else {
-      const int nb = padding_idx[n * 4 + (row == 0 ? 0 : 2)];   // top neighbour's last row / bottom neighbour's first row, columns 1..W
-      if (nb != -1) v = tr(x[((long)nb * C + c) * HW + (long)(row == 0 ? H - 1 : 0) * W + (col - 1)], pl);
+      const int nb = inv[(n - n_first) * 4 + (row == 0 ? 0 : 2)];   // written by the patch above (its last row) / below (its first row), columns 1..W
+      if (nb != -1) v = tr_from(x[((long)nb * C + c) * HW + (long)(row == 0 ? H - 1 : 0) * W + (col - 1)], nb, c);
     }
     tile[pl * total + row * W2 + col] = v;
   }
@@ -221,12 +244,12 @@ static int run(hipStream_t s, const void* x, const void* gamma, const void* beta
     int PB = 2048 / (H * W);                   // ~2k input elements per block
     if (PB < 1) PB = 1;
     if (PB > 32) PB = 32;
-    const size_t lds = (((size_t)PB * total * sizeof(T)) + 15) / 16 * 16 + (size_t)PB * 2 * sizeof(float);
+    const size_t lds = (((size_t)PB * total * sizeof(T)) + 15) / 16 * 16 + (size_t)PB * 2 * sizeof(float) + (size_t)(PB / C + 2) * 4 * sizeof(int);
     MX_CHECK(lds <= 64 * 1024, "groupnorm_halo: patch plane too large for the LDS staging (H, W <= 126)");
     const long planes = (long)N * C;
     dim3 pgrid((unsigned)cdiv64(planes, PB));
-    if (affine) hipLaunchKernelGGL((apply_gather_kernel<T, true>), pgrid, block, lds, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, padding_idx, C, H, W, cpg, PB, planes);
-    else hipLaunchKernelGGL((apply_gather_kernel<T, false>), pgrid, block, lds, s, (const T*)x, (T*)y, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, padding_idx, C, H, W, 1, PB, planes);
+    if (affine) hipLaunchKernelGGL((apply_gather_kernel<T, true>), pgrid, block, lds, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, padding_idx, C, H, W, cpg, PB, planes, N);
+    else hipLaunchKernelGGL((apply_gather_kernel<T, false>), pgrid, block, lds, s, (const T*)x, (T*)y, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, padding_idx, C, H, W, 1, PB, planes, N);
   } else {
     hipLaunchKernelGGL((apply_plain_kernel<T>), grid, block, 0, s, (const T*)x, (T*)y, (const T*)gamma, (const T*)beta, (const float*)mean2, (const float*)rstd2, C, H * W, cpg);
   }

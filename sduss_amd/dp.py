@@ -102,6 +102,57 @@ def replay_placement(arrivals: Sequence[float], resolutions: Sequence[int], step
     return out
 
 
+class FcfsMixed:
+    """Mirror of the per-cycle batching decisions of the reference's worker scheduler under its FCFS_Mixed policy
+    (sduss/worker/scheduler/policy/FCFS_Mixed.py:25-76 inside scheduler.py:56-166 over request_pool.py): every cycle the OLDEST unfinished
+    request names the stage (PREPARE -> DENOISING -> POSTPROCESSING), and the cycle runs the `max_num` oldest requests that are in that same
+    stage, grouped by resolution in age order; is_sliced / patch_size are forced to True / 256 (FCFS_Mixed.py:69-70).  Consequences the
+    mirror reproduces: a request that arrives while older ones denoise waits in PREPARE until it is the oldest (batches drain before new
+    ones form), and a request that finished its steps waits in POSTPROCESSING until it is the oldest.  ``update`` is
+    Scheduler.update_reqs_status + process_output: PREPARE -> DENOISING; one step less, POSTPROCESSING at zero; postprocessed requests
+    leave.  Checked cycle by cycle against the reference classes themselves: tests/golden/ref_fcfs_mixed.json, tests/test_ref_fixtures.py."""
+    PREPARE, DENOISING, POSTPROCESSING = "PREPARE", "DENOISING", "POSTPROCESSING"
+
+    def __init__(self, max_num: int):
+        self.max_num = max_num
+        self._req: Dict[int, list] = {}                      # id -> [arrival, resolution, status, remaining steps]; insertion order = pool order
+
+    def add(self, rid: int, arrival: float, resolution: int, steps: int) -> None:
+        if rid in self._req:
+            raise RuntimeError(f"WorkerRequest with id {rid} already exists.")      # request_pool.py:39-40
+        self._req[rid] = [float(arrival), int(resolution), self.PREPARE, int(steps)]
+
+    def has_unfinished(self) -> bool:
+        return bool(self._req)
+
+    def schedule(self):
+        """(status, {resolution: [ids]}, is_sliced, patch_size) of the next cycle"""
+        order = sorted(self._req, key=lambda i: self._req[i][0])     # stable: ties keep pool order, as the reference's sort does
+        status = self._req[order[0]][2]
+        chosen: Dict[int, List[int]] = {}
+        for rid in [i for i in order if self._req[i][2] == status][:self.max_num]:
+            chosen.setdefault(self._req[rid][1], []).append(rid)
+        return status, chosen, True, 256
+
+    def update(self, decision) -> List[int]:
+        """apply a cycle's effect; returns the ids that finished (left the pool)"""
+        status, chosen = decision[0], decision[1]
+        ids = [i for v in chosen.values() for i in v]
+        if status == self.PREPARE:
+            for i in ids:
+                self._req[i][2] = self.DENOISING
+        elif status == self.DENOISING:
+            for i in ids:
+                self._req[i][3] -= 1
+                if self._req[i][3] == 0:
+                    self._req[i][2] = self.POSTPROCESSING
+        else:
+            for i in ids:
+                del self._req[i]
+            return ids
+        return []
+
+
 def max_over_ranks(value: float, dist=None, device=None) -> float:
     """max of a host scalar over ranks (the timed region of bench.py)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -10,7 +10,13 @@ section 8c), but three pure-Python pieces on or next to the hot path import clea
 * ``Predictor.predict`` of sduss/worker/scheduler/policy/ESyMReD.py:20-53 -- on the reference's own
   exp/schedule_predictor_{sdxl,sd3}.pkl and on this repo's MI355X re-fit (profiles/schedule_predictor_*_mi355x.pkl);
 * ``GreedyDispath.dispatch_requests`` + ``RequestPool`` of sduss/dispatcher/{policy/greedy.py:16-36,request_pool.py} --
-  the data-parallel placement that sduss_amd/dp.py mirrors.
+  the data-parallel placement that sduss_amd/dp.py mirrors;
+* (round 4) ``split_sample`` of sduss/model_executor/modules/utils.py:4-84 -- the index tables of the sliced path (padding_idx, latent_offset,
+  resolution_offset, patch_map, the per-patch cache keys) and the halo'd patches; it calls ``.cuda()`` / ``device="cuda"`` on its INTEGER
+  tables only, neutralised here for the duration of the call (torch.Tensor.cuda -> identity, torch.tensor(device="cuda") -> CPU);
+* (round 4) ``FCFS_Mixed.schedule_requests`` (sduss/worker/scheduler/policy/FCFS_Mixed.py:25-76) inside the reference ``Scheduler``
+  (scheduler.py:56-166: schedule / update_reqs_status / process_output) over ``WorkerRequestPool``, driven cycle by cycle through seeded
+  arrival traces on a virtual clock -- the per-step batching decisions that bench.py's mixed-stream legs restate (sduss_amd/dp.py FcfsMixed).
 
 Only the resulting DATA travels (tests/golden/ref_*.npz / .json); tests/test_ref_fixtures.py checks the oracle's
 restatements and the host mirrors against it.  These fixtures pin the pieces they cover, not the denoiser arithmetic.
@@ -146,6 +152,112 @@ def greedy_dispatch_cases():
     return scenarios
 
 
+def split_sample_cases(ru):
+    """PatchUNet's split (modules/utils.py:4-84) on small seeded latents: integer tables + the halo'd patches, bit for bit."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def no_cuda():
+        real_cuda, real_tensor = torch.Tensor.cuda, torch.tensor
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.tensor = lambda *a, **k: real_tensor(*a, **{kk: v for kk, v in k.items() if not (kk == "device" and str(v).startswith("cuda"))})
+        try:
+            yield
+        finally:
+            torch.Tensor.cuda, torch.tensor = real_cuda, real_tensor
+
+    out = {}
+    g = torch.Generator().manual_seed(10086)
+    cases = {
+        "a": ({"128": 2, "256": 1}, 64, 2),             # scaled-down resolutions: the tables depend on resolution // patch_size only
+        "b": ({"256": 3}, 256, 1),                      # one patch per latent: all neighbours -1
+        "c": ({"512": 1, "768": 2, "1024": 1}, 256, 1),  # the reference's serving mix at its patch size
+        "d": ({"128": 2, "192": 0, "256": 1}, 32, 1),   # an empty resolution in the dict is skipped
+        "e": ({"256": 2}, 128, 3),
+    }
+    for name, (counts, patch, ch) in cases.items():
+        samples, indices = {}, {}
+        rid = 0
+        for res, n in counts.items():
+            samples[res] = torch.randn(n, ch, int(res) // 8, int(res) // 8, generator=g)
+            indices[res] = [f"req{rid + i}" for i in range(n)]
+            rid += n
+        with no_cuda():
+            idx, pad, lat_off, res_off, new_sample, pmap = ru.split_sample(samples, patch, indices)
+        for res, t in samples.items():
+            out[f"{name}.in.{res}"] = t.numpy()
+        out[f"{name}.patch"] = np.array([patch])
+        out[f"{name}.input_indices"] = np.array(json.dumps(indices))
+        out[f"{name}.indices"] = np.array(idx)
+        out[f"{name}.padding_idx"] = pad["cuda"].numpy().astype(np.int32)
+        out[f"{name}.latent_offset"] = np.array(lat_off["cpu"], dtype=np.int64)
+        out[f"{name}.resolution_offset"] = np.array(res_off["cpu"], dtype=np.int64)
+        out[f"{name}.patch_map"] = np.array(pmap["cpu"], dtype=np.int64)
+        out[f"{name}.new_sample"] = new_sample.numpy()
+    return out
+
+
+def fcfs_mixed_cases():
+    """The reference Scheduler + FCFS_Mixed policy, cycle by cycle, on a virtual clock.  Per cycle (worker.py:92-140): requests whose arrival time
+    has passed are added; schedule(); the virtual clock advances by a service time that depends only on the decision (so the mirror can replay
+    it); update_reqs_status(); process_output() of the PREVIOUS cycle is folded into the same cycle (blocking execution: the decisions do not
+    depend on the overlap).  Recorded per cycle: [status, {resolution: [request ids]}, is_sliced, patch_size]."""
+    os.environ.setdefault("SLO", "5")
+    os.environ.setdefault("MODEL", "sdxl")
+    sys.path.insert(0, REF)
+    from sduss.worker.scheduler.policy.FCFS_Mixed import FCFS_Mixed
+    from sduss.worker.scheduler.request_pool import WorkerRequestPool
+    from sduss.worker.scheduler.scheduler import Scheduler
+    from sduss.worker.wrappers import WorkerReqStatus, WorkerRequest
+
+    class _SP:
+        def __init__(self, resolution, steps):
+            self.resolution, self.num_inference_steps = resolution, steps
+
+    class _Out:
+        def __init__(self, ids):
+            self.req_output_dict = {i: None for i in ids}
+
+    scenarios = []
+    rng = np.random.RandomState(10086)
+    for n_req, rate, max_num in ((30, 1.0, 8), (40, 2.0, 8), (25, 0.5, 4), (30, 4.0, 3)):
+        arrivals = np.cumsum(rng.exponential(1.0 / rate, size=n_req))
+        res = rng.choice([512, 768, 1024], size=n_req)
+        steps = rng.choice([3, 4, 5, 6], size=n_req)            # short loops: the decisions, not the arithmetic
+        sched = object.__new__(Scheduler)                        # Scheduler.__init__ only unpacks config objects into these fields
+        sched.support_resolutions = [512, 768, 1024]
+        sched.max_batchsize = max_num
+        sched.request_pool = WorkerRequestPool(sched.support_resolutions)
+        sched.policy = FCFS_Mixed(request_pool=sched.request_pool, support_resolutions=sched.support_resolutions)
+        sched.cycle_counter = 0
+        svc = {"PREPARE": 0.02, "DENOISING": {512: 0.12, 768: 0.2, 1024: 0.35}, "POSTPROCESSING": 0.05}   # slow enough for queues to build
+        clock, nxt, cycles, finished = 0.0, 0, [], {}
+        while nxt < n_req or sched.has_unfinished_requests():
+            while nxt < n_req and arrivals[nxt] <= clock:
+                r = WorkerRequest(int(nxt), _SP(int(res[nxt]), int(steps[nxt])))
+                r.arrival_time = float(arrivals[nxt])
+                sched.add_requests([r])
+                nxt += 1
+            if not sched.has_unfinished_requests():
+                clock = float(arrivals[nxt])
+                continue
+            out = sched.schedule()
+            ids = {int(rr): [int(i) for i in d] for rr, d in out.scheduled_requests.items()}
+            name = WorkerReqStatus(out.status).name
+            cycles.append([name, ids, out.is_sliced, out.patch_size])
+            clock += (max(svc["DENOISING"][rr] for rr in ids) if name == "DENOISING" else svc[name] * sum(len(v) for v in ids.values()))
+            sched.update_reqs_status(out)
+            done = sched.process_output(out, _Out(out.get_req_ids()))
+            for r in done:
+                finished[int(r.request_id)] = clock
+        scenarios.append({"max_num": max_num, "arrivals": [float(a) for a in arrivals], "resolutions": [int(r) for r in res],
+                          "steps": [int(v) for v in steps], "service": {"PREPARE": svc["PREPARE"], "POSTPROCESSING": svc["POSTPROCESSING"],
+                                                                       "DENOISING": {str(k): v for k, v in svc["DENOISING"].items()}},
+                          "cycles": [[c[0], {str(k): v for k, v in c[1].items()}, c[2], c[3]] for c in cycles],
+                          "finish_clock": {str(k): v for k, v in finished.items()}})
+    return scenarios
+
+
 def main():
     assert os.path.isdir(REF), "run in the build container (needs /root/reference)"
     ru = load_ref_utils()
@@ -155,7 +267,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_predictor.npz"), **predictor_cases())
     with open(os.path.join(HERE, "ref_greedy_dispatch.json"), "w") as f:
         json.dump(greedy_dispatch_cases(), f)
-    for n in ("ref_utils_sd3.npz", "ref_predictor.npz", "ref_greedy_dispatch.json"):
+    np.savez_compressed(os.path.join(HERE, "ref_split_sample.npz"), **split_sample_cases(ru))
+    with open(os.path.join(HERE, "ref_fcfs_mixed.json"), "w") as f:
+        json.dump(fcfs_mixed_cases(), f)
+    for n in ("ref_utils_sd3.npz", "ref_predictor.npz", "ref_greedy_dispatch.json", "ref_split_sample.npz", "ref_fcfs_mixed.json"):
         print(n, os.path.getsize(os.path.join(HERE, n)), "bytes")
 
 

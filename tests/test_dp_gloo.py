@@ -60,3 +60,35 @@ def test_dp_bookkeeping_world2_gloo():
     assert e0 == e1 == 2.0                                  # max over ranks
     assert lat0 == lat1 and len(lat0) == 9                  # every request exactly once, same view on both ranks
     assert w0 == w1 == (0.0, 11.0)
+
+
+def _run_bench(argv, env_extra, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_without_a_launcher_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver calls the N = 1 case) must start the 2 ranks itself -- a child
+    `python -m torch.distributed.run`, the reference's one-process-per-GPU layout (executor/mp_executor.py:54-158) -- and print ONE line with
+    n_gpus 2.  Dry rehearsal: gloo, the step is a sleep (no GPU in this container); the GPU-box form is tests/test_pp_gpu.py."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"MX_BENCH_REHEARSE": "dry"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo" and "rehearsal" in out
+    assert len(out["rank_devices"]) == 2
+
+
+@pytest.mark.timeout(120)
+def test_bench_refuses_a_world_smaller_than_gpus():
+    """one rank answering for --gpus 2 (a launcher that started too few) is an error, not a line with n_gpus 1"""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"MX_BENCH_REHEARSE": "dry", "WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "rank(s) joined" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -212,6 +212,42 @@ def test_esymred_groupnorm(cuda_device, dtype, tol, padding):
     _close(got, want, tol, f"esymred_mp.groupnorm {dtype} pad={padding}")
 
 
+def _asymmetric_table(n):
+    """an adjacency table split_sample would never produce: one-directional links, a link between two latents, a self link --
+    every halo side still has at most one writer (with two the reference's scatter races)"""
+    pidx = torch.full((n, 4), -1, dtype=torch.int32)
+    pidx[0, 3] = 1          # 0 writes into 1's left halo, 1 does NOT name 0 as its left neighbour
+    pidx[1, 2] = 4          # 1 -> 4 downwards, across a latent boundary
+    pidx[4, 0] = 2          # 4 -> 2 upwards (not the inverse of the link above)
+    pidx[3, 1] = 3          # a patch that is its own left neighbour
+    pidx[5, 3] = 0
+    pidx[2, 0] = 5
+    return pidx.reshape(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_esymred_halo_on_an_asymmetric_table_equals_the_senders_scatter(cuda_device, dtype):
+    """The library gathers halos by the receiver while the reference scatters them from the sender (norm_silu_concat.cu:164-241).  The two agree
+    for any table once the receiver looks its writer up in the INVERSE table and applies the SENDER's statistics (csrc/gn_halo_nchw.hip); here on a
+    table with one-directional, cross-latent and self links, against the oracle's literal sender-driven scatter: halo-only bit for bit, GroupNorm +
+    halo within the dtype's tolerance (the statistics differ between the two latents, so a receiver-statistics shortcut would fail)."""
+    from sduss_amd import esymred_mp
+    g = torch.Generator().manual_seed(23)
+    n, c, h, w, cpg = 6, 16, 8, 8, 4
+    x = (torch.randn(n, c, h, w, generator=g) * torch.tensor([1., 1., 1., 5., 5., 5.]).view(n, 1, 1, 1) + torch.arange(n).view(n, 1, 1, 1).float()).to(dtype)
+    pidx = _asymmetric_table(n)
+    got = esymred_mp.mock_groupnorm(x.cuda(), n, c, h, w, 1, pidx.cuda()).cpu()
+    want = patch_ref.mock_groupnorm(x, pidx)
+    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+    lat_off, pmap = [0, 3, 6], torch.tensor([1, 1, 1, 2, 2, 2], dtype=torch.int32)
+    ga = torch.randn(c, generator=g).to(dtype).float(); be = torch.randn(c, generator=g).to(dtype).float()
+    want = patch_ref.groupnorm(x.float(), ga, be, cpg, 1e-5, True, lat_off, pmap, pidx)
+    got = esymred_mp.groupnorm(x.cuda(), ga.to(dtype).cuda(), be.to(dtype).cuda(), n, c, h, w, cpg, 1e-5, True,
+                               torch.tensor(lat_off, dtype=torch.int32).cuda(), pmap.cuda(), pidx.cuda())
+    tol = {torch.float32: 1e-5, torch.float16: 2.0 ** -9, torch.bfloat16: 2.0 ** -7}[dtype]
+    _close(got, want, tol, f"asymmetric table {dtype}")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_esymred_mock_groupnorm_bit_exact(cuda_device, dtype):
     """Halo exchange is pure data movement: bit-exact."""

@@ -248,3 +248,31 @@ def test_sd3_two_ranks_equal_one_rank_and_stale_steps(cuda_device):
         assert r["ncalls"] == 2 * tiny_layers + 2 * 2           # q|k and V^T per joint block, twice more for the two dual blocks
         assert r["warm_eq"] and r["same_eq"]
         assert r["lag"] < 0.75 * r["moved"] and r["lag"] < r["old"] and r["settled"] < r["lag"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus2_self_spawn_with_pp_leg_on_the_shared_gpu(cuda_device):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts its two ranks itself (a child torch.distributed.run; the pytest process is only the
+    grandparent), both on cuda:0 over gloo (MX_BENCH_REHEARSE=1), walks the timed region and the configs[3] --pp leg (one 1024 px request row-split
+    over the 2 ranks, 5 synchronous + stale steps) and prints ONE line with n_gpus 2 and a patch_parallel block.  The numbers of a rehearsal mean
+    nothing; the control flow, the rank accounting and the pp leg's exchange accounting are what is asserted."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MX_BENCH_REHEARSE"] = "1"
+    env["OMP_NUM_THREADS"] = "8"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "1", "--steps", "2", "--warmup", "1", "--pp-steps", "2",
+                        "--stream-requests", "0", "--mix", "0", "--no-cpu-baseline", "--no-roofline", "--no-sd3", "--no-stages", "--no-parity"],
+                       env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo" and "rehearsal" in out
+    pp = out["patch_parallel"]
+    assert "error" not in pp, pp
+    assert pp["ranks_per_request"] == 2 and pp["collectives_per_step"]["stale"] <= 9 < pp["collectives_per_step"]["sync"]
+    assert pp["sent_MB_per_rank_per_step"]["stale"] > 1.0
+    assert pp["rel_l2_vs_one_gpu"]["sync"] < 0.03 and pp["rel_l2_vs_one_gpu"]["stale_on_unchanged_inputs"] < 0.03

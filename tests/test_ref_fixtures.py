@@ -88,3 +88,74 @@ def test_greedy_placer_matches_reference_dispatcher():
             else:
                 pl.finish(ev["ids"])
     assert n_add > 200
+
+
+def test_fcfs_mixed_mirror_reproduces_the_reference_scheduler_cycle_by_cycle():
+    """sduss_amd.dp.FcfsMixed vs the reference Scheduler + FCFS_Mixed + WorkerRequestPool (run by make_ref_fixtures.py on a virtual clock):
+    the same stage, the same requests grouped by resolution in the same order, every cycle, and the same finish clocks."""
+    from sduss_amd.dp import FcfsMixed
+    with open(os.path.join(GOLD, "ref_fcfs_mixed.json")) as f:
+        scenarios = json.load(f)
+    n_cycles = n_mixed = 0
+    for s in scenarios:
+        sch = FcfsMixed(s["max_num"])
+        arr, res, steps, svc = s["arrivals"], s["resolutions"], s["steps"], s["service"]
+        clock, nxt, finished = 0.0, 0, {}
+        for want in s["cycles"]:
+            while True:
+                while nxt < len(arr) and arr[nxt] <= clock:
+                    sch.add(nxt, arr[nxt], res[nxt], steps[nxt])
+                    nxt += 1
+                if sch.has_unfinished():
+                    break
+                clock = arr[nxt]
+            status, chosen, sliced, patch = sch.schedule()
+            assert [status, {str(k): v for k, v in chosen.items()}, sliced, patch] == want
+            assert list(map(str, chosen)) == list(want[1])                      # resolution groups in age order, as the reference's dict
+            n_req = sum(len(v) for v in chosen.values())
+            clock += max(svc["DENOISING"][str(k)] for k in chosen) if status == "DENOISING" else svc[status] * n_req
+            for rid in sch.update((status, chosen)):
+                finished[str(rid)] = clock
+            n_cycles += 1
+            n_mixed += len(chosen) > 1
+        assert not sch.has_unfinished() and nxt == len(arr)
+        assert finished.keys() == s["finish_clock"].keys()
+        assert all(abs(finished[k] - v) < 1e-9 for k, v in s["finish_clock"].items())
+    assert n_cycles > 300 and n_mixed > 50
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d", "e"])
+def test_split_sample_tables_and_patches_match_reference_bit_for_bit(case):
+    """oracle.patch_ref.split_sample vs modules/utils.py:4-84 run on the same latents: padding_idx (top, left, bottom, right), latent_offset,
+    resolution_offset, patch_map, the per-patch cache keys "<request id>-<h>-<w>" and the halo'd patches themselves -- integer / copy work,
+    bit-exact."""
+    from oracle import patch_ref
+    z = np.load(os.path.join(GOLD, "ref_split_sample.npz"))
+    indices = json.loads(str(z[f"{case}.input_indices"]))
+    patch = int(z[f"{case}.patch"][0])
+    samples = {res: torch.from_numpy(z[f"{case}.in.{res}"]) for res in indices}
+    pad, lat_off, res_off, patches, pmap, keys = patch_ref.split_sample(samples, patch, indices)
+    assert np.array_equal(pad.numpy(), z[f"{case}.padding_idx"]) and pad.dtype == torch.int32
+    assert lat_off == z[f"{case}.latent_offset"].tolist() and res_off == z[f"{case}.resolution_offset"].tolist()
+    assert pmap.tolist() == z[f"{case}.patch_map"].tolist()
+    assert keys == [str(k) for k in z[f"{case}.indices"]]
+    assert np.array_equal(patches.numpy(), z[f"{case}.new_sample"])
+    # and back: concat_sample drops the halos again
+    inner = patches[:, :, 1:-1, 1:-1]
+    back = patch_ref.concat_sample(patch, inner, lat_off)
+    for res, t in samples.items():
+        if t.shape[0]:
+            assert torch.equal(back[res], t)
+
+
+def test_split_sample_adjacency_is_symmetric_and_stays_inside_a_latent():
+    """The property mx_groupnorm_halo's receiver-driven gather relies on (include/mxdenoise.h): in the tables split_sample produces, b's right
+    neighbour has b as its left neighbour (likewise top / bottom) and neighbours always belong to the same latent."""
+    z = np.load(os.path.join(GOLD, "ref_split_sample.npz"))
+    for case in "abcde":
+        pad = z[f"{case}.padding_idx"].reshape(-1, 4)
+        pmap = z[f"{case}.patch_map"]
+        for b, (top, left, bottom, right) in enumerate(pad):
+            for nb, back in ((top, 2), (bottom, 0), (left, 3), (right, 1)):
+                if nb >= 0:
+                    assert pad[nb][back] == b and pmap[nb] == pmap[b]
