@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--stream-rates", type=str, default="1.0,0.8,1.2",
                     help="offered loads in requests/s PER GPU (the reference sweeps {0.8..1.2} x N_gpu req/s, scripts/paper/scalibility.sh:12-13); "
                          "the first is the main leg, the others run stream-requests/5 requests each")
-    ap.add_argument("--mix", type=int, default=None, help="(default: 40 on the default SDXL run, else 0) configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
+    ap.add_argument("--mix", type=int, default=None, help="(default: 32 on the default SDXL run, else 0) configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
                                                        "reference traces exp/<model>/qps_*.csv) per offered load of --mix-rates; reports the reference's metrics "
                                                        "(scripts/draw/get_metric.py: SLO rate, average latency, goodput, throughput)")
     ap.add_argument("--mix-rates", type=str, default="1.0,2.0")
@@ -100,7 +100,7 @@ def parse():
     ap.add_argument("--no-two-model", action="store_true", help="skip the configs[4] leg with SDXL and SD3.5 requests interleaved in one stream")
     a = ap.parse_args()
     if a.mix is None:
-        a.mix = 40 if (a.model == "sdxl" and a.res == 1024) else 0
+        a.mix = 32 if (a.model == "sdxl" and a.res == 1024) else 0
     if a.pp is None:
         a.pp = a.gpus if (a.gpus > 1 and a.model == "sdxl") else 0
     if a.pp and (a.pp < 2 or a.gpus % a.pp):
@@ -175,13 +175,18 @@ STEP_SECONDS = {  # single-request seconds per step on MI355X (profiles/predicto
     "sdxl": {512: 0.0178, 768: 0.0208, 1024: 0.0271}, "sd3": {512: 0.0111, 768: 0.0179, 1024: 0.0286}}
 
 
-def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world, model):
+def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world, model, policy="continuous"):
     """configs[4]: a mixed-resolution Poisson stream with the column shape of the reference traces (arrival ms, resolution, steps;
     tests/server/direct_test.py replays them): resolutions uniform over 512 / 768 / 1024, steps by the traces' histogram, exponential
     inter-arrivals (numpy seed 10086), placed by replaying arrivals and completions through the greedy least-outstanding-pixels dispatcher
-    (dp.replay_placement), continuous batching FCFS with at most --mix-max-batch requests per step, is_sliced=True / patch 256 as the
-    reference's mixed policies force (policy/FCFS_Mixed.py:69-70); the resolutions of a step run in ONE launch sequence (pipeline.py
-    _step_mixed; SD3: concurrent per-resolution sequences).
+    (dp.replay_placement), at most --mix-max-batch requests per step, is_sliced=True / patch 256 as the reference's mixed policies force
+    (policy/FCFS_Mixed.py:69-70); the resolutions of a step run in ONE launch sequence (pipeline.py _step_mixed).
+    policy "fcfs_mixed": the per-cycle decisions of the reference's worker scheduler under FCFS_Mixed (dp.FcfsMixed, pinned cycle by cycle against
+    the reference classes: tests/golden/ref_fcfs_mixed.json) -- the oldest request names the stage, a batch drains before the waiting requests are
+    prepared together, a finished request leaves when it is the oldest; PREPARE costs nothing here (fixed prompt: the embeddings are cached,
+    SURVEY.md 8d) and POSTPROCESSING (the VAE decode) is outside this bench's loop as everywhere else.
+    policy "continuous": a request joins the running batch as soon as a slot is free (FCFS admission, sticky until done) -- what the denoiser
+    allows and the reference's ESyMReD policy approaches; reported beside the pinned one.
     Metrics as scripts/draw/get_metric.py computes them (deadlines: its SLO = 5 table, measured on H100 by the reference)."""
     from sduss_amd import dp
     n_total = n_per_gpu * world
@@ -203,6 +208,26 @@ def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world
         pending.append(r)
     active, done = [], []
     t0 = time.perf_counter()
+    if policy == "fcfs_mixed":
+        sch, byid = dp.FcfsMixed(args.mix_max_batch), {}
+        while pending or sch.has_unfinished():
+            now = time.perf_counter() - t0
+            while pending and pending[0].arrival <= now:
+                r = pending.pop(0)
+                byid[r.request_id] = r
+                sch.add(r.request_id, r.arrival, r.resolution, r.num_inference_steps)
+            if not sch.has_unfinished():
+                time.sleep(max(0.0, pending[0].arrival - now))
+                continue
+            status, chosen, sliced, patch = sch.schedule()
+            if status == dp.FcfsMixed.DENOISING:
+                den.denoising_step({str(res): [byid[i] for i in ids] for res, ids in sorted(chosen.items())}, is_sliced=sliced, patch_size=patch)
+                torch.cuda.synchronize()
+            for rid in sch.update((status, chosen)):
+                byid[rid].finish = time.perf_counter() - t0
+                done.append(byid[rid])
+        rows = [(r.resolution, r.finish - r.arrival) for r in done]
+        return rows, (min(r.arrival for r in done), max(r.finish for r in done))
     while pending or active:
         now = time.perf_counter() - t0
         while pending and len(active) < args.mix_max_batch and pending[0].arrival <= now:
@@ -606,6 +631,37 @@ def dry_rehearsal(args, rank, world):
         dist.destroy_process_group()
 
 
+def sd3_parity_start(net3, reqs3, P3):
+    """The SD3.5 block's parity check (configs[2] at the batch the bench times): the HIP forward of the WHOLE batch of 2 x requests on its
+    first-step inputs now, and the fp32 oracle's answer for its last row (the conditional row of the last request) computed by a background
+    host thread while the GPU legs run (the oracle costs ~75 s of host time and is not a timed quantity).  Returns (hip row, thread, box)."""
+    import threading
+    from oracle import sd3_mmdit_ref as mref
+    n = len(reqs3)
+    lat = torch.cat([r.latents for r in reqs3], dim=0)
+    x = torch.cat([lat, lat], dim=0)
+    ts = torch.tensor([float(r.timesteps[0]) for r in reqs3], device=lat.device)
+    ts2 = torch.cat([ts, ts])
+    ehs = torch.cat([r.negative_prompt_embeds for r in reqs3] + [r.prompt_embeds for r in reqs3], dim=0)
+    pooled = torch.cat([r.negative_pooled_prompt_embeds for r in reqs3] + [r.pooled_prompt_embeds for r in reqs3], dim=0)
+    got = net3.forward_one(x, ts2, ehs, pooled)
+    k = 2 * n - 1
+    f = lambda t: t[k:k + 1].float().cpu()
+    row = (f(x), f(ts2).reshape(1), f(ehs), f(pooled))
+    P32 = {name: v.float().cpu() for name, v in P3.items()}
+    box = {}
+
+    def work():
+        try:
+            with torch.inference_mode():
+                box["want"] = mref.mmdit_forward(P32, mref.MMDiTConfig.sd35_medium(), *row)
+        except Exception as e:                                  # noqa: BLE001
+            box["error"] = f"{type(e).__name__}: {e}"
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    return got[k:k + 1].float().cpu(), th, box, k
+
+
 def main():
     global STEPS_PER_IMAGE
     args = parse()
@@ -691,6 +747,25 @@ def main():
     if dist is not None:
         dist.barrier()
 
+    # ---- the second model (configs[2] / configs[4]) is built NOW so that the oracle of its parity check can run on host threads beside the
+    #      stream legs below; both denoisers stay resident from here (SDXL 5.1 GB + SD3.5 5 GB of weights) ----
+    sd3_built = sd3_parity = None
+    want_sd3_block = rank == 0 and world == 1 and args.model == "sdxl" and args.res == 1024 and not args.no_sd3
+    want_two_model = args.model == "sdxl" and args.res == 1024 and args.mix > 0 and not args.no_two_model and not args.no_sd3
+    if want_sd3_block or want_two_model:
+        try:
+            cfg3, net3, den3, P3 = build_model("sd3", device)
+            sd3_built = (cfg3, net3, den3)
+            if want_sd3_block and not args.no_parity and not args.no_cpu_baseline:
+                STEPS_PER_IMAGE = MODELS["sd3"]["steps"]
+                sd3_parity = sd3_parity_start(net3, make_batch(den3, cfg3, args.batch, 1024, device, {}), P3)
+                STEPS_PER_IMAGE = mdl["steps"]
+            del P3
+        except Exception as e:
+            sd3_built = None
+            if rank == 0:
+                result["sd3"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- stream legs: request latency under Poisson arrivals at the reference's offered loads ----
     if args.stream_requests > 0:
         legs = []
@@ -717,15 +792,15 @@ def main():
     # ---- configs[4] leg: mixed-resolution stream, the reference's metrics ----
     if args.mix > 0:
         legs = []
-        for rate in [float(x) for x in args.mix_rates.split(",") if x]:
-            rows, window = run_mix(den, cfg, args, device, shared, rate, args.mix, rank, world, args.model)
+        for rate, policy in [(float(x), pol) for x in args.mix_rates.split(",") if x for pol in ("fcfs_mixed", "continuous")]:
+            rows, window = run_mix(den, cfg, args, device, shared, rate, args.mix, rank, world, args.model, policy)
             rows_all, window = dp.gather_stream_stats(rows, window, dist)
             if rank == 0:
                 ddl = REF_DEADLINES_S[args.model]
                 lat = [l for _r, l in rows_all]
                 ok = sum(1 for r, l in rows_all if l <= ddl[int(r)])
                 span = window[1] - window[0]
-                legs.append({"offered_req_per_s_per_gpu": rate, "requests": len(rows_all), "slo_rate": ok / len(rows_all), "avg_latency_s": float(np.mean(lat)),
+                legs.append({"offered_req_per_s_per_gpu": rate, "policy": policy, "requests": len(rows_all), "slo_rate": ok / len(rows_all), "avg_latency_s": float(np.mean(lat)),
                              "p50_latency_s": float(np.percentile(lat, 50)), "p90_latency_s": float(np.percentile(lat, 90)),
                              "goodput_req_per_s": ok / span, "throughput_req_per_s": len(rows_all) / span,
                              "p50_by_resolution_s": {str(rr): float(np.percentile([l for r, l in rows_all if int(r) == rr], 50)) for rr in (512, 768, 1024)
@@ -736,8 +811,10 @@ def main():
             result["mixed_stream"] = {"legs": legs, "trace": "synthetic, shape of exp/<model>/qps_*.csv: resolutions uniform over 512/768/1024, steps 30-50 by the "
                                                               "traces' histogram, exponential arrivals seed 10086", "deadlines_s": REF_DEADLINES_S[args.model],
                                       "max_batch": args.mix_max_batch, "is_sliced": True, "patch_size": 256,
-                                      "policy": "FCFS mixed batching (policy/FCFS_Mixed.py); the resolutions of a step run in ONE launch sequence "
-                                                "(grouped launches)" if args.model == "sdxl" else "FCFS mixed batching; resolutions of a step as concurrent launch sequences"}
+                                      "policies": {"fcfs_mixed": "the reference worker scheduler's FCFS_Mixed decisions, cycle by cycle (policy/FCFS_Mixed.py:25-76; mirror "
+                                                                 "sduss_amd/dp.py FcfsMixed pinned by tests/golden/ref_fcfs_mixed.json): batches drain before waiting requests join",
+                                                   "continuous": "a request joins the running batch as soon as a slot is free (FCFS admission)"},
+                                      "launches": "the resolutions of a step run in ONE launch sequence (grouped launches)"}
 
     # ---- configs[3] leg: one request row-split over --pp ranks (patch parallelism), every rank takes part ----
     if args.pp and dist is not None and args.model == "sdxl":
@@ -750,12 +827,9 @@ def main():
         dist.barrier()
 
     # ---- configs[4] as written: SDXL and SD3.5 requests interleaved in one stream, both denoisers resident (every rank) ----
-    sd3_built = None
-    if args.model == "sdxl" and args.res == 1024 and args.mix > 0 and not args.no_two_model and not args.no_sd3:
+    if want_two_model and sd3_built is not None:
         try:
-            cfg3, net3, den3, P3 = build_model("sd3", device)
-            del P3
-            sd3_built = (cfg3, net3, den3)
+            cfg3, net3, den3 = sd3_built
             rows2, win2 = run_two_model({"sdxl": (den, cfg), "sd3": (den3, cfg3)}, args, device, 1.0, args.mix, rank, world)
             rows2, win2 = dp.gather_stream_stats(rows2, win2, dist)
             if rank == 0:
@@ -774,18 +848,14 @@ def main():
             result["stages_either_side"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- configs[2]: SD3.5-medium 1024^2 28-step on this GPU, the same timed-step protocol (rank 0 of a one-GPU run only) ----
-    if rank == 0 and world == 1 and args.model == "sdxl" and args.res == 1024 and not args.no_sd3:
+    if want_sd3_block and sd3_built is not None:
         try:
             del step, den, net, reqs
             torch.cuda.empty_cache()
             m3 = MODELS["sd3"]
             STEPS_PER_IMAGE = m3["steps"]
-            if sd3_built is not None:
-                cfg3, net3, den3 = sd3_built
-                sd3_built = None
-            else:
-                cfg3, net3, den3, P3 = build_model("sd3", device)
-                del P3
+            cfg3, net3, den3 = sd3_built
+            sd3_built = None
             reqs3 = make_batch(den3, cfg3, args.batch, 1024, device, {})
             s3, step3 = timed_steps(den3, reqs3, "1024", args, None, device, False)
             fin3 = all(torch.isfinite(r.latents.float()).all().item() for r in reqs3)
@@ -803,12 +873,26 @@ def main():
                                        "p50_latency_s": float(np.percentile(lat3, 50)), "p90_latency_s": float(np.percentile(lat3, 90)),
                                        "goodput_req_per_s": ok3 / (win3[1] - win3[0]), "throughput_req_per_s": len(rows3) / (win3[1] - win3[0]),
                                        "policy": "FCFS mixed batching, is_sliced=True / patch 256, the resolutions of a step in ONE launch sequence"}
+            if sd3_parity is not None:
+                hip_row, th, box, k3 = sd3_parity
+                th.join()
+                if "want" in box:
+                    err = hip_row - box["want"]
+                    l2, mx = float(err.norm() / box["want"].norm()), float(err.abs().max() / box["want"].abs().max())
+                    blk["parity_check"] = {"what": f"row {k3} (conditional row of the last request) of the HIP forward of this block's own batch of {2 * args.batch} at its "
+                                                   "first step vs the fp32 oracle on the same weights and inputs (oracle computed by a host thread beside the GPU legs)",
+                                           "rel_l2": l2, "max_err_frac_of_range": mx, "bound_rel_l2": 0.03, "bound_max": 0.05, "ok": bool(l2 <= 0.03 and mx <= 0.05)}
+                else:
+                    blk["parity_check"] = {"error": box.get("error", "no result")}
             result["sd3"] = blk
             del step3, den3, net3, reqs3
             torch.cuda.empty_cache()
         except Exception as e:                                  # never fatal for the headline line
             result["sd3"] = {"error": f"{type(e).__name__}: {e}"}
         STEPS_PER_IMAGE = mdl["steps"]
+        pc3 = result.get("sd3", {}).get("parity_check") if isinstance(result.get("sd3"), dict) else None
+        if pc3 and pc3.get("ok") is False:
+            raise SystemExit(f"bench.py: parity check of the SD3.5 batch failed: {pc3}")
 
     # ---- CPU baseline leg (+ the parity check of the headline batch's row) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -296,9 +296,36 @@ def test_sdxl_base_forward_1024_headline_batch8_rows(full_width_sdxl, sdxl_1024_
     assert (got[3].float() - got[0].float()).abs().max() > 0.1 * got[0].float().abs().max()
 
 
+def test_sdxl_base_mixed_forward_512_768_1024_one_sequence(full_width_sdxl):
+    """The configs[4] launch shapes (bench.py `mixed_stream`): ONE request each at 512 / 768 / 1024 px through mx_unet_forward_mixed at SDXL-base
+    width, is_sliced=True / patch 256 as the mixed policies force -- every group against its per-resolution forward (two bf16 evaluations with
+    differently grouped fp32 sums) and the 512 px group against the oracle's LITERAL PATCH PIPELINE on the weights as the device holds them (four
+    halo'd 256-px patches, patch-averaged GroupNorm statistics, regrouped self-attention)."""
+    from oracle import patch_ref
+    ocfg, _P, held, net = full_width_sdxl
+    spec = [(1, 64), (1, 96), (1, 128)]
+    ins = [list(ref.make_inputs(ocfg, b, hw, seed=30 + i)) for i, (b, hw) in enumerate(spec)]
+    for i, x in enumerate(ins):
+        x[1] = torch.full_like(x[1], 801.0 - 200.0 * i)
+    cat = lambda k: torch.cat([x[k] for x in ins]).cuda()
+    xs = [x[0].cuda().to(torch.bfloat16) for x in ins]
+    got = net.forward_mixed(xs, cat(1), cat(2), cat(3), cat(4), gn_patch=32)
+    for i, (b, hw) in enumerate(spec):
+        s_, t_, e_, te_, ti_ = ins[i]
+        alone = net.forward_one(xs[i], t_.cuda(), e_.cuda(), te_.cuda(), ti_.cuda(), gn_patch=32)
+        _check_forward(got[i], alone.float().cpu(), f"SDXL-base mixed 512/768/1024, group {hw * 8} px vs its own sequence", max_rel=0.05, l2_rel=0.03)
+    s_, t_, e_, te_, ti_ = ins[0]
+    with torch.inference_mode():
+        want = patch_ref.unet_forward_sliced(held, ocfg, {"512": s_}, t_, e_, te_, ti_, patch_size=256)["512"]
+    _check_forward(got[0], want, "SDXL-base mixed 512/768/1024, 512 px group vs the literal patch pipeline (weights as held)", max_rel=0.05, l2_rel=0.03)
+
+
 def test_sd35_medium_forward_1024(cuda_device):
-    """SD3.5-medium (24 joint blocks, 13 dual) on 128 x 128 latents with 333 text tokens: BASELINE configs[2] at batch 1 (the fp32 CPU oracle
-    of this forward costs 75 s per sample; batches > 1 are covered at medium width in tests/test_mmdit_gpu.py)."""
+    """SD3.5-medium (24 joint blocks, 13 dual) on 128 x 128 latents with 333 text tokens: BASELINE configs[2].  The fp32 CPU oracle of this
+    forward costs 75 s per sample, so ONE oracle sample serves two comparisons: the batch-1 forward, and -- round 4 -- ROW 7 OF THE HEADLINE
+    BATCH OF 8 (4 requests under CFG: the launch shapes bench.py's `sd3` block times, 256 x 256 tiles for every image-stream GEMM and the 64-row
+    joint attention), whose other rows carry different latents / timesteps / embeddings so that a row mix-up cannot pass; row 0 of the batch of 8
+    is compared with the batch-1 HIP forward of its own inputs (two bf16 evaluations with different tile selections)."""
     from sduss_amd.config import MMDiTConfig
     from sduss_amd.transformer_sd3 import MxSD3Transformer
     ocfg = sd3_mmdit_ref.MMDiTConfig.sd35_medium()
@@ -309,3 +336,13 @@ def test_sd35_medium_forward_1024(cuda_device):
     net = MxSD3Transformer(MMDiTConfig.sd35_medium(), P, device="cuda:0")
     got = net.forward_one(lat.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), p.cuda())
     _check_forward(got, want, "SD3.5-medium 1024^2 forward, batch 1")
+    lat8, t8, e8, p8 = sd3_mmdit_ref.make_inputs(ocfg, 8, 128, ctx_len=333, seed=4242)
+    t8 = torch.tensor([901.0, 41.0, 741.0, 521.0, 301.0, 81.0, 621.0, 0.0])
+    lat8[7], t8[7], e8[7], p8[7] = lat[0], t[0], e[0], p[0]
+    dev = lambda x: x.cuda().to(torch.bfloat16) if x.dtype == torch.float32 and x.dim() > 1 else x.cuda()
+    got8 = net.forward_one(dev(lat8), t8.cuda(), dev(e8), dev(p8))
+    assert torch.isfinite(got8.float()).all()
+    _check_forward(got8[7:8], want, "SD3.5-medium 1024^2 headline batch 8, row 7")
+    got0 = net.forward_one(dev(lat8[:1]), t8[:1].cuda(), dev(e8[:1]), dev(p8[:1]))
+    _check_forward(got8[0:1], got0.float().cpu(), "SD3.5-medium 1024^2 headline batch 8, row 0 vs its batch-1 forward", max_rel=0.04, l2_rel=0.02)
+    assert (got8[3].float() - got8[7].float()).abs().max() > 0.1 * got8[7].float().abs().max()
