@@ -653,6 +653,14 @@ def sd3_parity_start(net3, reqs3, P3):
 
     def work():
         try:
+            # keep the oracle's worker threads (a pool of its own, created by this thread's first parallel region and inheriting its affinity)
+            # on the upper half of the host's CPUs: the main thread keeps feeding the GPU legs from the lower half, whose latencies are reported
+            try:
+                cpus = sorted(os.sched_getaffinity(0))
+                if len(cpus) >= 16:
+                    os.sched_setaffinity(0, set(cpus[len(cpus) // 2:]))
+            except (AttributeError, OSError):
+                pass
             with torch.inference_mode():
                 box["want"] = mref.mmdit_forward(P32, mref.MMDiTConfig.sd35_medium(), *row)
         except Exception as e:                                  # noqa: BLE001

@@ -581,11 +581,38 @@ typedef struct mx_block_cache {
   const int32_t* slots;
   const unsigned char* slot_valid;
   int n_slots;
+  /* mx_unet_forward_cached_mixed (the patch unit): the latent size the state rows are laid out for (every group's H, W <= these; multiples of
+   * gn_patch), and, out, the patches that asked / the patches seen over the blocks of the last forward */
+  int max_h, max_w;
+  unsigned long long patches_asked, patches_total;
 } mx_block_cache;
 size_t mx_unet_block_cache_bytes(const mx_unet* u, int batch, int H, int W);
 int mx_unet_forward_cached(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps,
                            const void* encoder_hidden_states, const void* text_embeds, const float* time_ids, void* out,
                            int batch, int H, int W, int ctx_len, int gn_patch, void* workspace, size_t workspace_bytes, mx_block_cache* cache);
+/* The cache AT THE REFERENCE'S OWN UNIT -- the 256-px patch -- over a mixed-resolution batch in ONE launch sequence (round 4).  The reference's
+ * cache only works with is_sliced=True (its unsliced update_and_return receives all rows with a partial mask), which is what its mixed policies
+ * force (policy/FCFS_Mixed.py:69-70); every cache is keyed "<request id>-<h>-<w>" (modules/utils.py:37,60; unet.py:163).  Semantics reproduced:
+ *   - per block ONE decision for the patches of all samples of all groups: predict(ctx, block, is_up, n_patches, n_feat, timesteps[n_patches],
+ *     mse[n_patches * n_feat], run_out[n_patches]) -- rows in the reference's order (group, sample, patch row, patch column), mse = mean over the
+ *     patch's pixels and channels of (input - cached input)^2, for the up blocks also of each skip tensor (oldest first); MX_MSE_UNCACHED for a
+ *     request without cached tensors (slot_valid 0), which always runs;
+ *   - a block none of whose patches asks is skipped: every output (hidden state, the down blocks' skip tensors) comes from the state;
+ *   - in a running block the ops that own a CacheManager in the reference -- resnet conv1 / conv2, the down / upsampler conv, attn1's core +
+ *     to_out, the whole attn2 -- are COMPUTED FOR THE ASKING PATCHES ONLY (3x3 convs on a compact batch of halo'd patches gathered with the
+ *     reference's halo / corner rule, per-token work on the compact rows, self-attention of the asking queries against all keys of their latent)
+ *     and every other patch takes that op's own cached output; GroupNorm (statistics, halos, SiLU), the LayerNorms, proj_in / proj_out, the
+ *     q | k | v projection, the feed-forward, the 1x1 shortcut, the time-embedding add and the residual adds run on all rows, on the fresh tensors
+ *     (resnet.py:390-460, 280-378; transformer.py:32-128, 167-290; attention.py:59-232; cache_manager.py:84-99).
+ * State: one row per request (slots / slot_valid / n_slots as above, required), rows laid out for max_h x max_w latents;
+ * mx_unet_patch_cache_bytes(u, n_slots, max_h, max_w, gn_patch) bytes.  Needs gn_patch > 0 with every group's H, W multiples of it.  The
+ * workspace is larger than mx_unet_workspace_bytes_mixed (compact patch batches): mx_unet_workspace_bytes_cached_mixed.  Not graph-captured
+ * (one host decision per block).  Oracle: oracle/cache_patch_ref.py; tests/test_block_cache_gpu.py. */
+size_t mx_unet_patch_cache_bytes(const mx_unet* u, int n_slots, int max_h, int max_w, int gn_patch);
+size_t mx_unet_workspace_bytes_cached_mixed(const mx_unet* u, const mx_unet_group* groups, int n_groups, int ctx_len, int gn_patch);
+int mx_unet_forward_cached_mixed(mx_unet* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                                 const void* encoder_hidden_states, const void* text_embeds, const float* time_ids, int ctx_len, int gn_patch,
+                                 void* workspace, size_t workspace_bytes, mx_block_cache* cache);
 /* The same for the SD3 / SD3.5 transformer: one cache point per joint block (SD3Transformer.py:54-57, 151, 172, 219-228 with
  * cache_manager.py:163-191): the feature row is [block index, timestep, mse of the image stream]; a reused block restores both the image and
  * the context stream it produced.  The reference forces a run after TWO reuses here (cache_manager.py:184). */

@@ -236,3 +236,115 @@ class BlockSkipCache:
     @staticmethod
     def blocks_of(mask: int) -> Sequence[int]:
         return [i for i in range(64) if mask >> i & 1]
+
+
+class PatchSkipCache:
+    """The cache at the reference's own unit, the 256-px PATCH, over a mixed-resolution batch in ONE launch sequence: host half of
+    ``mx_unet_forward_cached_mixed`` (include/mxdenoise.h).  What the reference does with ESYMRED_USE_CACHE=TRUE and is_sliced=True -- the only mode
+    in which its cache works, and the one its mixed policies force: every CacheManager dictionary is keyed ``"<request id>-<h>-<w>"``
+    (modules/utils.py:37,60), get_mask decides per patch (cache_manager.py:101-161) and a patch that reused a block four times in a row is
+    forced to run it.  The library compares, gathers the asking patches, computes them and merges; this class owns the state tensor (one row per
+    sample id, i.e. per request and CFG half), the per-patch reuse counters and the predictor callback (one call per block for the patches of
+    all samples of all resolutions)."""
+
+    def __init__(self, down, up=None, forced_after: int = FORCED_RUN_AFTER, max_latent: int = 128):
+        wrap = lambda p: CompiledForest(p) if hasattr(p, "estimators_") and hasattr(p, "n_features_in_") else p
+        self.down, self.up = wrap(down), wrap(up if up is not None else down)
+        self.forced_after = forced_after
+        self.max_latent = max_latent
+        self.state: Optional[torch.Tensor] = None
+        self.desc = _lib.BlockCacheC()
+        self._cb = _lib.SKIP_PREDICT_FN(self._predict)
+        self.desc.predict = self._cb
+        self._slot_of, self._cap, self._patch, self._pending = {}, 0, None, None
+        self._keys = []                                      # patch keys of the forward in flight, in the library's row order
+        self.previous = {}                                   # block -> {patch key: consecutive reuses}
+        self.decisions, self.features, self.history = [], [], []
+        self.record_features = False
+        self.error: Optional[BaseException] = None
+        self.patches_asked = self.patches_total = 0
+
+    def _predict(self, _ctx, block, is_up, n, nf, timesteps, mse, run_out):
+        try:
+            ts = np.ctypeslib.as_array(timesteps, shape=(n,)).astype(np.float64)
+            m = np.ctypeslib.as_array(mse, shape=(n, nf)).astype(np.float64)
+            feats = np.concatenate([np.full((n, 1), float(block)), ts[:, None], m], axis=1)
+            if self.record_features:
+                self.features.append(feats.copy())
+            keys = self._keys
+            assert len(keys) == n
+            uncached = m[:, 0] >= MSE_UNCACHED * 0.5
+            counts = self.previous.get(block, {})
+            prev = np.array([0 if uncached[i] else counts.get(keys[i], 0) for i in range(n)], dtype=np.int64)     # cache_manager.py:128,150
+            raw = np.asarray((self.up if is_up else self.down).predict(feats))
+            run, new_prev = decide(raw, prev, self.forced_after)
+            run = run | uncached                              # nothing cached: nothing to reuse
+            new_prev = np.where(uncached, 0, new_prev)
+            self.previous[block] = {keys[i]: int(new_prev[i]) for i in range(n)}
+            self.decisions.append((int(block), run.copy()))
+            for i in range(n):
+                run_out[i] = 1 if run[i] else 0
+            return 0
+        except BaseException as e:                           # never unwind through the C frame
+            self.error = e
+            return 1
+
+    def bind(self, model, shapes: Sequence, row_ids: Sequence, gn_patch: int):
+        """shapes: per group (batch, H, W) in the library's group order; row_ids: one hashable id per sample in row order (all groups).  Returns
+        the descriptor for mx_unet_forward_cached_mixed; commits the request -> row table in after_forward()."""
+        row_ids = list(row_ids)
+        n = sum(b for b, _h, _w in shapes)
+        assert len(row_ids) == n and len(set(row_ids)) == n, "one distinct id per sample"
+        if self._pending is not None:                         # the previous forward failed part-way
+            self.invalidate()
+        if self._patch != gn_patch:
+            self._patch, self._slot_of, self._cap, self.previous = gn_patch, {}, 0, {}
+        ml = max([self.max_latent] + [max(h, w) for _b, h, w in shapes])
+        ml = (ml + gn_patch - 1) // gn_patch * gn_patch
+        if n > self._cap or ml != self.max_latent or self.state is None:
+            self.max_latent = ml
+            self._cap = max(2 * n, 8)
+            need = model._lib.mx_unet_patch_cache_bytes(model._handle, self._cap, ml, ml, gn_patch)
+            if need == 0:
+                raise _lib.MxError("mx_unet_patch_cache_bytes: " + model._lib.mx_last_error().decode())
+            self.state = None
+            self.state = torch.empty(need, dtype=torch.uint8, device=model.device)
+            self._slot_of, self.previous = {}, {}
+        keep = {k: v for k, v in self._slot_of.items() if k in set(row_ids)}       # ids that left are forgotten (cache_manager.py:131,153)
+        free = sorted(set(range(self._cap)) - set(keep.values()))
+        valid = []
+        for rid in row_ids:
+            if rid in keep:
+                valid.append(1)
+            else:
+                keep[rid] = free.pop(0)
+                valid.append(0)
+        self._pending = keep
+        keys, i = [], 0
+        for b, h, w in shapes:                                # the library's patch order: group, sample, patch row, patch column
+            for _ in range(b):
+                keys += [f"{row_ids[i]}-{py}-{px}" for py in range(h // gn_patch) for px in range(w // gn_patch)]
+                i += 1
+        self._keys = keys
+        alive = set(keys)
+        for blk, counts in list(self.previous.items()):
+            self.previous[blk] = {k: v for k, v in counts.items() if k in alive}
+        self._slots_arr = (C.c_int32 * n)(*[keep[r] for r in row_ids])
+        self._valid_arr = (C.c_ubyte * n)(*valid)
+        d = self.desc
+        d.state, d.state_bytes = self.state.data_ptr(), self.state.numel()
+        d.slots = C.cast(self._slots_arr, C.POINTER(C.c_int32))
+        d.slot_valid = C.cast(self._valid_arr, C.POINTER(C.c_ubyte))
+        d.n_slots, d.max_h, d.max_w = self._cap, self.max_latent, self.max_latent
+        self.decisions, self.error = [], None
+        return C.byref(self.desc)
+
+    def after_forward(self):
+        if self._pending is not None:
+            self._slot_of, self._pending = self._pending, None
+        self.history.append(int(self.desc.blocks_run))
+        self.patches_asked += int(self.desc.patches_asked)
+        self.patches_total += int(self.desc.patches_total)
+
+    def invalidate(self):
+        self._slot_of, self._pending, self.previous = {}, None, {}

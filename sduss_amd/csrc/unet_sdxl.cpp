@@ -27,6 +27,7 @@
 #include "common.h"
 #include "graph_cache.h"
 #include "pp_exchange.h"
+#include "patch_cache.h"
 
 namespace mx {
 int launch_prep_latent(hipStream_t s, const void* in, int dtype, void* out, int B, int Cin, int HW, int CP);
@@ -114,6 +115,121 @@ struct Plan {
     if (hipMemcpyAsync(t, region, per_sample_bytes * B, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("block cache: copy out of the state failed");
     return true;
   }
+  // ---- block cache at the reference's own unit, the PATCH (mx_unet_forward_cached_mixed; cache_manager.py with is_sliced=True) ----
+  // Every cached op of a block (resnet conv1 / conv2, the down / upsampler conv, attn1.to_out, attn2.to_out: the modules that own a CacheManager,
+  // resnet.py:283,339,386-387; attention.py:57,118) keeps its output per patch in a STATE tensor with one row per request; under a partial
+  // mask the asking patches are computed -- convs on a compact batch of halo'd patches, per-token work on the compact rows -- and written to
+  // their places in the state, and the op's output is the state, for asking and not-asking patches alike.  Everything else of a running block
+  // (GroupNorm with its statistics and halos, LayerNorms, proj_in / proj_out, the q / k / v projections of attn1, the feed-forward, the 1x1
+  // shortcut, the residual adds) runs on all rows, as in the reference.
+  bool pc = false;
+  int pc_p0 = 0, pc_np = 0, pc_nask = 0, pc_maxh = 0, pc_maxw = 0, pc_slots = 0;
+  bool pc_partial = false;          // the running block: some patch of the batch does not ask
+  std::vector<mx::PcSample> pc_samp;
+  std::vector<mx::PcPatch> pc_all, pc_ask;
+  std::vector<int> pc_ask_first;    // per sample: index of its first asking patch in pc_ask (B + 1 entries)
+  std::vector<int> pc_group_of;     // per sample: its resolution group
+  mx::PcSample* pc_dsamp = nullptr; mx::PcPatch* pc_dall = nullptr; mx::PcPatch* pc_dask = nullptr; double* pc_dpart = nullptr;
+  unsigned long long pc_asked = 0, pc_total = 0;
+  static size_t pc_np_max(int slots, int maxh, int maxw, int p0) { return (size_t)slots * (maxh / p0) * (maxw / p0); }
+  size_t pc_head_bytes(int slots, int maxh, int maxw, int p0) const {     // comparison partial sums | sample table | all patches | asking patches
+    const size_t np = pc_np_max(slots, maxh, maxw, p0);
+    return (((size_t)(u->cfg.layers_per_block + 2) * np * p0 * sizeof(double) + slots * sizeof(mx::PcSample) + 2 * np * sizeof(mx::PcPatch)) + 255) & ~(size_t)255;
+  }
+  long pc_row_elems(int level, int C) const { return (long)(pc_maxh >> level) * (pc_maxw >> level) * C; }
+  long pc_max_image(int level, int C) const { long m = 0; for (int g = 0; g < ng; ++g) m = std::max(m, (long)(gH[g] >> level) * (gW[g] >> level) * C); return m; }
+  char* pc_region(int level, int C) {
+    char* r = bc_top;
+    bc_top += ((size_t)pc_row_elems(level, C) * pc_slots * 2 + 255) & ~(size_t)255;
+    if (!dry && (size_t)(bc_top - (char*)bc->state) > bc->state_bytes) fail("patch cache: state buffer too small (mx_unet_patch_cache_bytes)");
+    return r;
+  }
+  bool pc_store(const bf16_t* t, char* reg, int level, int C) {
+    if (!ok()) return false;
+    if (quiet()) return true;
+    if (mx::launch_pc_image_copy(stream, (void*)t, reg, pc_dsamp, B, level, C, pc_row_elems(level, C), 0, nullptr, 0, nullptr, pc_max_image(level, C))) return fail(mx_last_error());
+    return true;
+  }
+  // t = state (+ vec[b][c]) (+ residual); residual may be t itself
+  bool pc_load(bf16_t* t, char* reg, int level, int C, const float* vec = nullptr, int ldvec = 0, const bf16_t* residual = nullptr, bool force = false) {
+    if (!ok()) return false;
+    if (dry || (mute && !force)) return true;
+    if (mx::launch_pc_image_copy(stream, t, reg, pc_dsamp, B, level, C, pc_row_elems(level, C), 1, vec, ldvec, residual, pc_max_image(level, C))) return fail(mx_last_error());
+    return true;
+  }
+  const mx::PcPatch* pc_list() const { return pc_partial ? pc_dask : pc_dall; }
+  int pc_count() const { return pc_partial ? pc_nask : pc_np; }
+  // rows of the asking patches of a token-major tensor (row stride ld, C columns taken) <-> compact [n_ask * p^2, C]
+  bool pc_gather_rows(const bf16_t* src, int ld, int C, bf16_t* dst, int level) {
+    if (!ok()) return false;
+    if (quiet()) return true;
+    if (mx::launch_pc_gather(stream, src, ld, C, dst, pc_list(), pc_count(), pc_dsamp, level, pc_p0 >> level, 0, 0, 0)) return fail(mx_last_error());
+    return true;
+  }
+  bool pc_scatter_rows(const bf16_t* src, int C, char* reg, int level) {
+    if (!ok()) return false;
+    if (quiet()) return true;
+    const int p = pc_p0 >> level;
+    if (mx::launch_pc_scatter(stream, src, p, 0, C, reg, pc_row_elems(level, C), pc_list(), pc_count(), pc_dsamp, level, p)) return fail(mx_last_error());
+    return true;
+  }
+  // A 3x3 conv whose output every patch caches.  `corner`: the corner_patch argument of the whole-image form (all patches ask: the ordinary
+  // launch, then a copy into the state).  Partial mask: gather the asking patches with their halos (stride 2: one extra outer ring of zeros, so
+  // that the pad-1 stride-2 launch's output o + 1 has the taps of the reference's pad-0 output o), ONE conv over the compact batch, scatter the
+  // interiors into the state.  The op's output = state (+ time-embedding row) (+ residual) for every patch.
+  bool pc_conv(const bf16_t* x, int h, int wd, int Cin, const std::string& prefix, bf16_t* out, int Cout, int stride, int up, int corner, int level,
+               const float* vec, int ldvec, const bf16_t* residual) {
+    const int lo = level + (stride == 2 ? 1 : 0) - up;
+    const int p_in = (pc_p0 >> level) << up, p_out = pc_p0 >> lo;
+    const int halo_lo = stride == 2 ? 2 : 1, halo_hi = stride == 2 ? 0 : 1;
+    const int P = p_in + halo_lo + halo_hi, Po = stride == 2 ? (P + 1) / 2 : P;
+    char* reg = pc_region(lo, Cout);
+    const size_t mk = ar.mark();
+    bf16_t* cin = alloc<bf16_t>((size_t)pc_np * P * P * Cin);
+    bf16_t* cout = alloc<bf16_t>((size_t)pc_np * Po * Po * Cout);
+    if (!pc_partial) {
+      conv(x, h, wd, Cin, prefix, cout, Cout, stride, up, corner);
+      pc_store(cout, reg, lo, Cout);
+    } else {
+      const void* wt = wb(prefix + ".weight", (size_t)Cout * 9 * Cin); const float* bs = wf(prefix + ".bias", Cout);
+      if (ok() && !quiet()) {
+        if (mx::launch_pc_gather(stream, x, Cin, Cin, cin, pc_dask, pc_nask, pc_dsamp, level, p_in, halo_lo, halo_hi, up)) fail(mx_last_error());
+        mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+        d.a = cin; d.w = wt; d.bias = bs; d.c = cout; d.ldc = Cout; d.B = pc_nask; d.Hin = P; d.Win = P; d.Cin = Cin; d.Hout = Po; d.Wout = Po;
+        d.stride = stride; d.M = pc_nask * Po * Po; d.N = Cout; d.K = 9 * Cin; d.rows_per_batch = Po * Po; d.ldr = Cout;
+        gemm(d, true);
+        if (ok() && mx::launch_pc_scatter(stream, cout, Po, 1, Cout, reg, pc_row_elems(lo, Cout), pc_dask, pc_nask, pc_dsamp, lo, p_out)) fail(mx_last_error());
+      }
+    }
+    ar.release(mk);
+    return pc_load(out, reg, lo, Cout, vec, ldvec, residual);
+  }
+  // attention of the compact query rows of every sample with asking patches against that sample's own keys: problems of one sample each
+  bool pc_attention(const bf16_t* qc, const bf16_t* kbase, int ldk, long k_sample_stride, const bf16_t* vtbase, const long* vt_sample_off, const int* ldvt_s,
+                    long vt_bstride_fixed, bf16_t* oc, int C, int heads, int level, const int* Lk_s) {
+    if (!ok()) return false;
+    if (quiet()) return true;
+    const int pp = (pc_p0 >> level) * (pc_p0 >> level);
+    std::vector<mx_attn_problem> pr;
+    for (int b = 0; b < B; ++b) {
+      const int na = pc_ask_first[b + 1] - pc_ask_first[b];
+      if (!na) continue;
+      mx_attn_problem q; std::memset(&q, 0, sizeof(q));
+      const long r0 = (long)pc_ask_first[b] * pp;
+      q.q = qc + r0 * C; q.o = oc + r0 * C;
+      q.k = kbase + (k_sample_stride >= 0 ? (long)b * k_sample_stride : (pc_samp[b].row0 >> (2 * level)) * (long)ldk);
+      q.vt = vtbase + vt_sample_off[b]; q.ldvt = ldvt_s[b];
+      q.vt_batch_stride = vt_bstride_fixed > 0 ? vt_bstride_fixed : (int64_t)C * ldvt_s[b];
+      q.B = 1; q.Lq = na * pp; q.Lk = Lk_s[b];
+      pr.push_back(q);
+    }
+    for (size_t i = 0; i < pr.size(); i += MX_MAX_SEGS) {
+      const int n = (int)std::min<size_t>(MX_MAX_SEGS, pr.size() - i);
+      if (mx_attention_prescaled_grouped(stream, pr.data() + i, n, C, ldk, C, heads)) return fail(std::string("attention: ") + mx_last_error());
+    }
+    return true;
+  }
+
   unsigned blocks_run = 0;
   std::vector<float> h_timesteps; // host copy of the timesteps for the predictor
   bool lookup = false;      // dry pass that still resolves every weight (mx_unet_validate)
@@ -366,6 +482,26 @@ struct Plan {
       dump(p, out, (size_t)M * Cout);
       return out;
     }
+    if (pc) {          // patch-unit cache: conv1 / conv2 per patch from the op's state, everything else on all rows (resnet.py:390-460 with a mask)
+      bf16_t* n1 = alloc<bf16_t>((size_t)M * Cin);
+      groupnorm(x, n1, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, patch, x2, C1);
+      bf16_t* h1 = alloc<bf16_t>((size_t)M * Cout);
+      pc_conv(n1, h, wd, Cin, p + ".conv1", h1, Cout, 1, 0, patch, level, temb_all ? temb_all + temb_off : nullptr, temb_total, nullptr);
+      temb_off += Cout;
+      bf16_t* n2 = alloc<bf16_t>((size_t)M * Cout);
+      groupnorm(h1, n2, p + ".norm2", h, wd, Cout, u->cfg.norm_eps, true, patch);
+      const bf16_t* sc = x;
+      if (Cin != Cout) {
+        bf16_t* s2 = alloc<bf16_t>((size_t)M * Cout);
+        if (x2) linear(x, C1, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin, nullptr, 0, 0, 0.f, x2, C2);
+        else linear(x, Cin, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", s2, Cout, M, Cout, Cin);
+        sc = s2;
+      }
+      pc_conv(n2, h, wd, Cout, p + ".conv2", out, Cout, 1, 0, patch, level, nullptr, 0, sc);
+      ar.release(m);
+      dump(p, out, (size_t)M * Cout);
+      return out;
+    }
     bf16_t* n1 = alloc<bf16_t>((size_t)M * Cin);
     groupnorm(x, n1, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, patch, x2, C1);
     bf16_t* h1 = alloc<bf16_t>((size_t)M * Cout);
@@ -455,6 +591,9 @@ struct Plan {
       mx_gemm_desc d3 = lin_desc(y, ff, 4 * C, 8 * C, MX_EPI_GEGLU, 0.f);
       pass1 = mx_gemm_ln_prefers_pass(&d1) != 0; pass2 = mx_gemm_ln_prefers_pass(&d2) != 0; pass3 = mx_gemm_ln_prefers_pass(&d3) != 0;
     }
+    if (pc) pass1 = pass2 = pass3 = true;   // the hidden state of a masked layer is produced by the state-merge kernel, which leaves no row statistics
+    bf16_t* pqc = nullptr; bf16_t* paoc = nullptr; bf16_t* ptc = nullptr;     // patch-unit cache: compact queries / attention output / projection output
+    if (pc) { pqc = alloc<bf16_t>((size_t)M * C); paoc = alloc<bf16_t>((size_t)M * C); ptc = alloc<bf16_t>((size_t)M * C); }
     auto normalise = [&]() {      // ln = (y - mean) * rstd, no affine (it lives in the folded weights)
       if (ok() && !quiet() && mx_layernorm(stream, y, ln, nullptr, nullptr, M, C, u->cfg.layer_norm_eps)) fail(std::string("layernorm: ") + mx_last_error());
     };
@@ -472,6 +611,74 @@ struct Plan {
     if (!kvp && ok()) fail("no cross-attention K/V buffer for width " + std::to_string(C));
     for (int k = 0; k < layers && ok(); ++k) {
       const std::string b = p + ".transformer_blocks." + std::to_string(k);
+      if (pc) {
+        // PatchBasicTransformerBlock under a per-patch mask (transformer.py:167-290): the LayerNorms, the q | k | v projection of attn1 and the
+        // feed-forward run on all rows; the self-attention core + to_out and the whole cross-attention run for the asking patches and the
+        // others take the op's cached output (attention.py:59-110, 121-232); then the residual adds
+        const int pp2 = (pc_p0 >> level) * (pc_p0 >> level);
+        const int Mc = pc_count() * pp2;
+        std::vector<long> vt_off(B); std::vector<int> ldvt_s(B), Lk_s(B);
+        for (int g = 0; g < ng; ++g) for (int i = 0; i < gB[g]; ++i) { const int bb = gb0[g] + i; vt_off[bb] = gvt0[g] + (long)i * C * gldvt[g]; ldvt_s[bb] = gldvt[g]; Lk_s[bb] = gL[g]; }
+        auto self_attention_all = [&]() {
+          if (ng > 1) {
+            mx_attn_problem pr[MX_MAX_SEGS];
+            for (int g = 0; g < ng; ++g) {
+              pr[g].q = qk + gr0[g] * 2 * C; pr[g].k = qk + gr0[g] * 2 * C + C; pr[g].vt = vt + gvt0[g]; pr[g].o = ao + gr0[g] * C;
+              pr[g].vt_batch_stride = (int64_t)C * gldvt[g]; pr[g].B = gB[g]; pr[g].Lq = gL[g]; pr[g].Lk = gL[g]; pr[g].ldvt = gldvt[g];
+            }
+            attention_grouped(pr, 2 * C, 2 * C, C, heads);
+          } else attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
+        };
+        normalise();
+        { mx_gemm_desc d = qkv_desc(b, ln); wf(b + ".attn1.to_qkv.colsum", 3 * C); gemm(d, false); }
+        char* reg1 = pc_region(level, C);
+        if (!pc_partial) {
+          self_attention_all();
+          linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", ptc, C, M, C, C);
+          pc_store(ptc, reg1, level, C);
+        } else {
+          pc_gather_rows(qk, 2 * C, C, pqc, level);
+          pc_attention(pqc, qk + C, 2 * C, -1, vt, vt_off.data(), ldvt_s.data(), 0, paoc, C, heads, level, Lk_s.data());
+          linear(paoc, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", ptc, C, Mc, C, C);
+          pc_scatter_rows(ptc, C, reg1, level);
+        }
+        pc_load(y, reg1, level, C, nullptr, 0, y);
+        normalise();
+        char* reg2 = pc_region(level, C);
+        const int li = ok() ? kvp->next++ : 0;
+        if (!pc_partial) {
+          linear(ln, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f));
+          if (ok()) {
+            if (ng > 1) {
+              mx_attn_problem pr[MX_MAX_SEGS];
+              for (int g = 0; g < ng; ++g) {
+                pr[g].q = q2 + gr0[g] * C; pr[g].k = kvp->k + (size_t)li * C + (size_t)gb0[g] * ctx_len * kvp->ldk;
+                pr[g].vt = kvp->vt + (size_t)li * C * kvp->ldvt + (size_t)gb0[g] * kvp->vt_bstride; pr[g].o = ao + gr0[g] * C;
+                pr[g].vt_batch_stride = kvp->vt_bstride; pr[g].B = gB[g]; pr[g].Lq = gL[g]; pr[g].Lk = ctx_len; pr[g].ldvt = kvp->ldvt;
+              }
+              attention_grouped(pr, C, kvp->ldk, C, heads);
+            } else attention(q2, C, kvp->k + (size_t)li * C, kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, kvp->ldvt, kvp->vt_bstride, ao, C, heads, L, ctx_len);
+          }
+          linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", ptc, C, M, C, C);
+          pc_store(ptc, reg2, level, C);
+        } else {
+          pc_gather_rows(ln, C, C, pqc, level);
+          linear(pqc, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, Mc, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f));
+          if (ok()) {
+            std::vector<long> cvt_off(B); std::vector<int> cld(B, kvp->ldvt), clk(B, ctx_len);
+            for (int bb = 0; bb < B; ++bb) cvt_off[bb] = (long)bb * kvp->vt_bstride;
+            pc_attention(q2, kvp->k + (size_t)li * C, kvp->ldk, (long)ctx_len * kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, cvt_off.data(), cld.data(),
+                         kvp->vt_bstride, paoc, C, heads, level, clk.data());
+          }
+          linear(paoc, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", ptc, C, Mc, C, C);
+          pc_scatter_rows(ptc, C, reg2, level);
+        }
+        pc_load(y, reg2, level, C, nullptr, 0, y);
+        normalise();
+        linear(ln, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU);
+        linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C);
+        continue;
+      }
       // self-attention (norm1 in the fused q / k / v projection)
       {
         if (pass1) normalise();
@@ -596,7 +803,7 @@ struct Plan {
     // ---- conv_in (unet.py:344) ----
     int h = H, wd = W;                    // the first group's image at the current level; ch / cw hold every group's
     for (int g = 0; g < ng; ++g) { ch[g] = gH[g]; cw[g] = gW[g]; }
-    if (ng > 1 && (is_pp() || bc)) fail("a mixed-resolution batch runs neither patch-parallel nor through the block cache");
+    if (ng > 1 && (is_pp() || (bc && !pc))) fail("a mixed-resolution batch runs neither patch-parallel nor through the per-sample block cache");
     bf16_t* x0 = alloc<bf16_t>((size_t)rows() * kConvInPad);
     for (int g = 0; g < ng && ok() && !dry; ++g)
       if (mx::launch_prep_latent(stream, g_lat[g], io_dtype, x0 + row0(g) * kConvInPad, gB[g], c.in_channels, ch[g] * cw[g], kConvInPad)) fail(mx_last_error());
@@ -610,9 +817,10 @@ struct Plan {
     conv(x0, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0);  // patches are cut from the true latent: no corner rule (unet.py:123-158)
     dump("conv_in", x, (size_t)rows() * C0);
 
-    struct Skip { bf16_t* t; int C; int h, wd; };
+    struct Skip { bf16_t* t; int C; int h, wd; int level; };
     std::vector<Skip> skips;
-    skips.push_back({x, C0, h, wd});
+    skips.push_back({x, C0, h, wd, 0});
+    int lvl = 0;                          // level of x (patch-unit cache: the level a state tensor is laid out for)
     int Ccur = C0;
     // The seven blocks the reference wraps with a CacheManager (unet_2d_blocks.py): each body advances x / h / wd / Ccur / skips.
     auto down_block = [&](int i) {                              // unet.py:371-405
@@ -625,7 +833,7 @@ struct Plan {
           const std::string ap = "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j);
           x = transformer(ap, x, h, wd, Cout, c.num_heads[i], c.transformer_layers[i], i);
         }
-        skips.push_back({x, Cout, h, wd});
+        skips.push_back({x, Cout, h, wd, i});
       }
       if (i != nlev - 1) {
         const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0";
@@ -640,13 +848,16 @@ struct Plan {
           halo_exchange(xp, h, wd, Cout);
           conv(xp, h, wd, Cout, dp + ".conv", d, Cout, 2, 0, 0, nullptr, 0, nullptr, 1);
           ar.release(mk);
-        } else
+        } else if (pc)
+        pc_conv(x, h, wd, Cout, dp + ".conv", d, Cout, 2, 0, level_patch(i), i, nullptr, 0, nullptr);   // PatchDownsample2D with a mask (resnet.py:341-378)
+        else
         conv(x, h, wd, Cout, dp + ".conv", d, Cout, 2, 0, level_patch(i));   // resnet.py:364-371
         h /= 2; wd /= 2;
         for (int g = 0; g < ng; ++g) { ch[g] = (ch[g] + 1) / 2; cw[g] = (cw[g] + 1) / 2; }
         x = d;
+        lvl = i + 1;
         dump(dp, x, (size_t)rows() * Cout);
-        skips.push_back({x, Cout, h, wd});
+        skips.push_back({x, Cout, h, wd, i + 1});
       }
     };
     auto mid_block = [&]() {                                    // unet.py:419-445
@@ -678,11 +889,14 @@ struct Plan {
           halo_exchange(xp, h, wd, Cout);
           conv(xp, h, wd, Cout, upn + ".conv", d, Cout, 1, 1, 0, nullptr, 0, nullptr, 1);
           ar.release(mk);
-        } else
+        } else if (pc)
+        pc_conv(x, h, wd, Cout, upn + ".conv", d, Cout, 1, 1, level_patch(level - 1), level, nullptr, 0, nullptr);   // PatchUpsample2D with a mask (resnet.py:280-339)
+        else
         conv(x, h, wd, Cout, upn + ".conv", d, Cout, 1, 1, level_patch(level - 1));  // resnet.py:316, 327-333
         h *= 2; wd *= 2;
         for (int g = 0; g < ng; ++g) { ch[g] *= 2; cw[g] *= 2; }
         x = d;
+        lvl = level - 1;
         dump(upn, x, (size_t)rows() * Cout);
       }
     };
@@ -690,9 +904,84 @@ struct Plan {
     // Block-skip cache (mx_unet_forward_cached; include/mxdenoise.h): inputs = the tensors the predictor's features come from, body = the
     // block.  A reused block still walks its plan (mute) so that the arena, the K / V cursors and the time-embedding offset advance as if it
     // had run; its outputs are then filled from the cache.
-    struct Ten { bf16_t* p; size_t per_sample; };
+    struct Ten { bf16_t* p; size_t per_sample; int C = 0; int level = 0; };
+    // The same at the reference's unit, the PATCH (pc; mx_unet_forward_cached_mixed): features, decision and merge per patch, ONE host decision
+    // per block for the patches of every sample of every resolution group, the block's ops computing the asking patches only (Plan::pc_conv,
+    // the masked transformer layer).
+    auto run_block_pc = [&](int idx, bool is_up, const std::vector<Ten>& ins, const std::function<void()>& body) {
+      const int nf = (int)ins.size();
+      std::vector<char*> in_cache(nf);
+      for (int f = 0; f < nf; ++f) in_cache[f] = pc_region(ins[f].level, ins[f].C);
+      auto outputs = [&](size_t n0) {
+        std::vector<Ten> outs;
+        if (!is_up) for (size_t k = std::min(n0, skips.size()); k < skips.size(); ++k) outs.push_back({skips[k].t, 0, skips[k].C, skips[k].level});
+        if (outs.empty() || outs.back().p != x) outs.push_back({x, 0, Ccur, lvl});
+        return outs;
+      };
+      if (dry) {
+        const size_t n0 = skips.size();
+        body();
+        for (auto& o : outputs(n0)) pc_region(o.level, o.C);
+        return;
+      }
+      if (!ok()) return;
+      std::vector<float> mse((size_t)pc_np * nf, MX_MSE_UNCACHED);
+      if (bc_any_valid) {
+        size_t off = 0;
+        std::vector<size_t> offs(nf);
+        for (int f = 0; f < nf && ok(); ++f) {
+          const int pl = pc_p0 >> ins[f].level;
+          offs[f] = off;
+          if (mx::launch_pc_patch_sq_diff(stream, ins[f].p, in_cache[f], pc_row_elems(ins[f].level, ins[f].C), ins[f].C, pc_dall, pc_np, pc_dsamp, ins[f].level, pl,
+                                          pc_dpart + off)) fail(mx_last_error());
+          off += (size_t)pc_np * pl;
+        }
+        std::vector<double> hp(off);
+        if (ok() && (hipMemcpyAsync(hp.data(), pc_dpart, off * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                     hipStreamSynchronize(stream) != hipSuccess)) fail("patch cache: reading the input differences failed");
+        for (int f = 0; f < nf; ++f) {
+          const int pl = pc_p0 >> ins[f].level;
+          for (int j = 0; j < pc_np; ++j) {
+            if (!bc_valid[pc_all[j].b]) continue;                  // nothing cached for this request: the marker stays (cache_manager.py:110,139)
+            double t = 0.0;
+            for (int r = 0; r < pl; ++r) t += hp[offs[f] + (size_t)j * pl + r];
+            mse[(size_t)j * nf + f] = (float)(t / ((double)pl * pl * ins[f].C));
+          }
+        }
+      }
+      if (!ok()) return;
+      std::vector<unsigned char> run(pc_np, 1);
+      std::vector<float> tpp(pc_np);
+      for (int j = 0; j < pc_np; ++j) tpp[j] = h_timesteps[pc_all[j].b];
+      if (bc->predict(bc->ctx, idx, is_up ? 1 : 0, pc_np, nf, tpp.data(), mse.data(), run.data())) { fail("patch cache: the predictor failed"); return; }
+      pc_ask.clear(); pc_ask_first.assign(B + 1, 0);
+      for (int j = 0; j < pc_np; ++j) {
+        if (!bc_valid[pc_all[j].b]) run[j] = 1;                    // a patch without cached tensors has nothing to reuse (uninitialised rows in the reference)
+        if (run[j]) { pc_ask.push_back(pc_all[j]); pc_ask_first[pc_all[j].b + 1]++; }
+      }
+      for (int b = 0; b < B; ++b) pc_ask_first[b + 1] += pc_ask_first[b];
+      pc_nask = (int)pc_ask.size();
+      pc_partial = pc_nask < pc_np;
+      const bool any = pc_nask > 0;
+      pc_total += (unsigned long long)pc_np; pc_asked += (unsigned long long)pc_nask;
+      if (any && pc_partial && hipMemcpyAsync(pc_dask, pc_ask.data(), pc_ask.size() * sizeof(mx::PcPatch), hipMemcpyHostToDevice, stream) != hipSuccess) {
+        fail("patch cache: sending the list of asking patches failed"); return;
+      }
+      for (int f = 0; f < nf && ok(); ++f) pc_store(ins[f].p, in_cache[f], ins[f].level, ins[f].C);   // the cached input is always the latest one (:133,153)
+      const size_t n0 = skips.size();
+      mute = !any;
+      body();
+      mute = false;
+      for (auto& o : outputs(n0)) {
+        char* oc = pc_region(o.level, o.C);
+        if (!ok()) return;
+        if (any ? !pc_store(o.p, oc, o.level, o.C) : !pc_load(o.p, oc, o.level, o.C)) return;
+      }
+      if (any) blocks_run |= 1u << idx;
+    };
     auto run_block = [&](int idx, bool is_up, const std::vector<Ten>& ins, const std::function<void()>& body) {
       if (!bc) { body(); return; }
+      if (pc) { run_block_pc(idx, is_up, ins, body); return; }
       const int nf = (int)ins.size();
       const size_t R = (size_t)bc_rows;
       auto region = [&](size_t per_sample) { char* r = bc_top; bc_top += (per_sample * R * 2 + 255) & ~(size_t)255; return r; };
@@ -778,20 +1067,21 @@ struct Plan {
       if (any) blocks_run |= 1u << idx;
     };
     auto up_inputs = [&](int n) {
-      std::vector<Ten> v{{x, (size_t)h * wd * Ccur}};
+      std::vector<Ten> v{{x, (size_t)h * wd * Ccur, Ccur, lvl}};
       // column order of the reference's feature row: mse(x), then res_hidden_states_tuple[0 .. n-1] = the block's skips OLDEST first, the
       // first-consumed one last (cache_manager.py:110-121; unet_2d_blocks.py:250-257 takes res_hidden_states_tuple[-1] first)
       const int have = std::min<int>(n, (int)skips.size());
-      for (int k = 0; k < have; ++k) { const Skip& sk = skips[skips.size() - have + k]; v.push_back({sk.t, (size_t)sk.h * sk.wd * sk.C}); }
+      for (int k = 0; k < have; ++k) { const Skip& sk = skips[skips.size() - have + k]; v.push_back({sk.t, (size_t)sk.h * sk.wd * sk.C, sk.C, sk.level}); }
       return v;
     };
     int block = 0;
-    if (bc) {
+    if (bc && !pc) {
       if (bc_rows < B) bc_rows = B;
       bc_top = (dry ? (char*)(uintptr_t)0x1000 : (char*)bc->state) + bc_scratch_bytes(c.layers_per_block, bc_rows);
     }
-    for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, false, {{x, (size_t)h * wd * Ccur}}, [&] { down_block(i); });
-    if (ok()) { run_block(block, false, {{x, (size_t)h * wd * Ccur}}, [&] { mid_block(); }); ++block; }
+    if (pc) bc_top = (dry ? (char*)(uintptr_t)0x1000 : (char*)bc->state) + pc_head_bytes(pc_slots, pc_maxh, pc_maxw, pc_p0);
+    for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, false, {{x, (size_t)h * wd * Ccur, Ccur, lvl}}, [&] { down_block(i); });
+    if (ok()) { run_block(block, false, {{x, (size_t)h * wd * Ccur, Ccur, lvl}}, [&] { mid_block(); }); ++block; }
     for (int i = 0; i < nlev && ok(); ++i, ++block) run_block(block, true, up_inputs(c.layers_per_block + 1), [&] { up_block(i); });
     // ---- out (unet.py:508-517) ----
     {
@@ -1094,6 +1384,118 @@ extern "C" int mx_unet_forward_cached(mx_unet* u, void* stream, const void* late
   cache->blocks_run = p.blocks_run; cache->blocks_run_hi = 0;
   if (!okr) { cache->cached_valid = 0; mx::set_error(p.err); return 1; }
   cache->cached_valid = 1; cache->cached_key = cache->batch_key; cache->cached_batch = batch; cache->cached_h = H; cache->cached_w = W;
+  return 0;
+}
+
+
+/* ---- block-skip cache at the reference's unit, the patch, over a mixed-resolution batch in ONE launch sequence (include/mxdenoise.h) ---- */
+namespace {
+int pc_setup(Plan& p, mx_unet* u, const mx_unet_group* groups, int n_groups, int ctx_len, int gn_patch, const mx_block_cache* cache, bool dry) {
+  MX_CHECK(u != nullptr, "unet: null handle");
+  MX_CHECK(groups && n_groups >= 1 && n_groups <= MX_MAX_SEGS, "unet_forward_cached_mixed: 1..MX_MAX_SEGS resolution groups");
+  MX_CHECK(gn_patch > 0 && (gn_patch >> (u->cfg.n_levels - 1)) >= 2, "unet_forward_cached_mixed: the patch unit needs is_sliced (gn_patch > 0, >= 2 pixels at the deepest level)");
+  MX_CHECK(cache && cache->n_slots > 0 && cache->max_h > 0 && cache->max_w > 0 && cache->max_h % gn_patch == 0 && cache->max_w % gn_patch == 0,
+           "unet_forward_cached_mixed: cache->n_slots, max_h, max_w (multiples of gn_patch) are required");
+  MX_CHECK(ctx_len > 0, "unet: bad shape");
+  p.u = u; p.ctx_len = ctx_len; p.gn_patch = gn_patch; p.dry = dry;
+  p.ng = n_groups; p.B = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    MX_CHECK(groups[g].batch > 0 && groups[g].H > 0 && groups[g].W > 0 && groups[g].H % gn_patch == 0 && groups[g].W % gn_patch == 0,
+             "unet_forward_cached_mixed: every group's H, W must be multiples of gn_patch");
+    MX_CHECK(groups[g].H <= cache->max_h && groups[g].W <= cache->max_w, "unet_forward_cached_mixed: a group is larger than the state rows (max_h, max_w)");
+    MX_CHECK(dry || (groups[g].latents && groups[g].out), "unet: null group operand");
+    p.gB[g] = groups[g].batch; p.gH[g] = groups[g].H; p.gW[g] = groups[g].W; p.gb0[g] = p.B; p.g_lat[g] = groups[g].latents; p.g_out[g] = groups[g].out;
+    p.B += groups[g].batch;
+  }
+  p.H = groups[0].H; p.W = groups[0].W;
+  MX_CHECK(p.B <= cache->n_slots, "unet_forward_cached_mixed: more samples than state rows (n_slots)");
+  p.pc = true; p.pc_p0 = gn_patch; p.pc_maxh = cache->max_h; p.pc_maxw = cache->max_w; p.pc_slots = cache->n_slots;
+  p.pc_samp.clear(); p.pc_all.clear();
+  long long row0 = 0;
+  for (int g = 0; g < n_groups; ++g)
+    for (int i = 0; i < p.gB[g]; ++i) {
+      const int b = p.gb0[g] + i;
+      mx::PcSample s; s.row0 = row0; s.h = p.gH[g]; s.w = p.gW[g]; s.slot = (!dry && cache->slots) ? cache->slots[b] : b; s.npx = p.gW[g] / gn_patch;
+      p.pc_samp.push_back(s);
+      for (int py = 0; py < p.gH[g] / gn_patch; ++py)
+        for (int px = 0; px < p.gW[g] / gn_patch; ++px) p.pc_all.push_back(mx::PcPatch{b, py, px, 0});
+      row0 += (long long)p.gH[g] * p.gW[g];
+    }
+  p.pc_np = (int)p.pc_all.size();
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t mx_unet_patch_cache_bytes(const mx_unet* u, int n_slots, int max_h, int max_w, int gn_patch) {
+  if (!u || n_slots <= 0 || max_h <= 0 || max_w <= 0 || gn_patch <= 0 || max_h % gn_patch || max_w % gn_patch) { mx::set_error("patch_cache_bytes: bad arguments"); return 0; }
+  Plan p;
+  mx_block_cache sizing{};
+  sizing.n_slots = n_slots; sizing.max_h = max_h; sizing.max_w = max_w;
+  mx_unet_group g{nullptr, nullptr, n_slots, max_h, max_w};
+  if (pc_setup(p, const_cast<mx_unet*>(u), &g, 1, 64, gn_patch, &sizing, true)) return 0;
+  p.stream = nullptr; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
+  p.bc = &sizing;
+  if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
+  return (size_t)(p.bc_top - (char*)(uintptr_t)0x1000) + 256;
+}
+
+extern "C" size_t mx_unet_workspace_bytes_cached_mixed(const mx_unet* u, const mx_unet_group* groups, int n_groups, int ctx_len, int gn_patch) {
+  Plan p;
+  mx_block_cache sizing{};
+  sizing.n_slots = 0; sizing.max_h = 0; sizing.max_w = 0;
+  if (groups) for (int g = 0; g < n_groups && g < MX_MAX_SEGS; ++g) {
+    sizing.n_slots += groups[g].batch; sizing.max_h = std::max(sizing.max_h, groups[g].H); sizing.max_w = std::max(sizing.max_w, groups[g].W);
+  }
+  if (pc_setup(p, const_cast<mx_unet*>(u), groups, n_groups, ctx_len, gn_patch, &sizing, true)) return 0;
+  p.stream = nullptr; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
+  p.bc = &sizing;
+  if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
+  return p.ar.peak + 256;
+}
+
+extern "C" int mx_unet_forward_cached_mixed(mx_unet* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                                            const void* ehs, const void* text_embeds, const float* time_ids, int ctx_len, int gn_patch, void* workspace,
+                                            size_t workspace_bytes, mx_block_cache* cache) {
+  MX_CHECK(cache && cache->predict && cache->state && cache->slots && cache->slot_valid, "unet_forward_cached_mixed: cache with predict, state, slots and slot_valid is required");
+  MX_CHECK(((uintptr_t)cache->state & 255) == 0, "unet_forward_cached_mixed: cache->state must be 256-byte aligned");
+  Plan p;
+  if (pc_setup(p, u, groups, n_groups, ctx_len, gn_patch, cache, false)) return 1;
+  MX_CHECK(timesteps && ehs && text_embeds && time_ids && workspace, "unet: null operand");
+  MX_CHECK(u->blob != nullptr, "unet: weights not set");
+  MX_CHECK(io_dtype == MX_F32 || io_dtype == MX_F16 || io_dtype == MX_BF16, "unet: bad io dtype");
+  const int B = p.B;
+  std::vector<char> seen(cache->n_slots, 0);
+  p.bc_valid.assign(B, 0);
+  p.bc_all_valid = true; p.bc_any_valid = false;
+  for (int b = 0; b < B; ++b) {
+    MX_CHECK(cache->slots[b] >= 0 && cache->slots[b] < cache->n_slots && !seen[cache->slots[b]], "unet_forward_cached_mixed: slots must be distinct and inside [0, n_slots)");
+    seen[cache->slots[b]] = 1;
+    p.bc_valid[b] = cache->slot_valid[b] ? 1 : 0;
+    p.bc_all_valid = p.bc_all_valid && p.bc_valid[b]; p.bc_any_valid = p.bc_any_valid || p.bc_valid[b];
+  }
+  p.stream = (hipStream_t)stream;
+  p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = false;
+  p.bc = cache;
+  const size_t head = p.pc_head_bytes(p.pc_slots, p.pc_maxh, p.pc_maxw, p.pc_p0);
+  MX_CHECK(head <= cache->state_bytes, "unet_forward_cached_mixed: state buffer too small");
+  const size_t npm = Plan::pc_np_max(p.pc_slots, p.pc_maxh, p.pc_maxw, p.pc_p0);
+  char* hp = (char*)cache->state;
+  p.pc_dpart = (double*)hp; hp += (size_t)(u->cfg.layers_per_block + 2) * npm * p.pc_p0 * sizeof(double);
+  p.pc_dsamp = (mx::PcSample*)hp; hp += (size_t)p.pc_slots * sizeof(mx::PcSample);
+  p.pc_dall = (mx::PcPatch*)hp; hp += npm * sizeof(mx::PcPatch);
+  p.pc_dask = (mx::PcPatch*)hp;
+  p.h_timesteps.resize(B);
+  if (hipMemcpyAsync(p.pc_dsamp, p.pc_samp.data(), (size_t)B * sizeof(mx::PcSample), hipMemcpyHostToDevice, p.stream) != hipSuccess ||
+      hipMemcpyAsync(p.pc_dall, p.pc_all.data(), (size_t)p.pc_np * sizeof(mx::PcPatch), hipMemcpyHostToDevice, p.stream) != hipSuccess ||
+      hipMemcpyAsync(p.h_timesteps.data(), timesteps, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, p.stream) != hipSuccess ||
+      hipStreamSynchronize(p.stream) != hipSuccess) {
+    mx::set_error("unet_forward_cached_mixed: moving the tables failed");
+    return 1;
+  }
+  const bool okr = p.run(groups[0].latents, io_dtype, timesteps, ehs, text_embeds, time_ids, groups[0].out);
+  cache->blocks_run = p.blocks_run; cache->blocks_run_hi = 0;
+  cache->patches_asked = p.pc_asked; cache->patches_total = p.pc_total;
+  if (!okr) { mx::set_error(p.err); return 1; }
   return 0;
 }
 

@@ -114,7 +114,8 @@ class BlockCacheC(C.Structure):
     _fields_ = [("predict", SKIP_PREDICT_FN), ("ctx", C.c_void_p), ("state", C.c_void_p), ("state_bytes", C.c_size_t),
                 ("batch_key", C.c_uint64), ("cached_key", C.c_uint64), ("cached_valid", C.c_int), ("cached_batch", C.c_int),
                 ("cached_h", C.c_int), ("cached_w", C.c_int), ("blocks_run", C.c_uint), ("blocks_run_hi", C.c_uint), ("observe", SKIP_OBSERVE_FN),
-                ("slots", C.POINTER(C.c_int32)), ("slot_valid", C.POINTER(C.c_ubyte)), ("n_slots", C.c_int)]
+                ("slots", C.POINTER(C.c_int32)), ("slot_valid", C.POINTER(C.c_ubyte)), ("n_slots", C.c_int),
+                ("max_h", C.c_int), ("max_w", C.c_int), ("patches_asked", C.c_ulonglong), ("patches_total", C.c_ulonglong)]
 
 
 class CLIPConfigC(C.Structure):
@@ -181,6 +182,9 @@ SYMBOLS = {
     "mx_unet_pp_state_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "mx_unet_forward_pp_stale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "mx_unet_block_cache_bytes": (_sz, [_vp, _i, _i, _i]),
+    "mx_unet_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "mx_unet_workspace_bytes_cached_mixed": (_sz, [_vp, C.POINTER(UNetGroup), _i, _i, _i]),
+    "mx_unet_forward_cached_mixed": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "mx_unet_forward_cached": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mx_mmdit_block_cache_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_mmdit_forward_cached": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

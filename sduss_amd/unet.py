@@ -209,6 +209,53 @@ class MxUNet:
         cache.after_forward()
         return out
 
+    def forward_mixed_cached(self, cache, samples: List[torch.Tensor], row_ids, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                             text_embeds: torch.Tensor, time_ids: torch.Tensor, gn_patch: int) -> List[torch.Tensor]:
+        """forward_mixed through the block-skip cache at the reference's unit, the patch (block_cache.PatchSkipCache; mx_unet_forward_cached_mixed):
+        ONE launch sequence over the latents of every resolution, one host decision per block for all their patches.  ``row_ids``: one id per
+        sample in row order (request id + CFG half)."""
+        assert 1 <= len(samples) <= _lib.MAX_SEGS and gn_patch > 0
+        samples = [x.contiguous() for x in samples]
+        dt = samples[0].dtype
+        assert all(x.is_cuda and x.ndim == 4 and x.dtype == dt for x in samples)
+        btot = sum(x.shape[0] for x in samples)
+        ctx_len = encoder_hidden_states.shape[1]
+        ts = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+        ts = (ts.expand(btot) if ts.numel() == 1 else ts).contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        te = text_embeds.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        ti = time_ids.to(device=self.device, dtype=torch.float32).contiguous()
+        assert ts.shape[0] == btot and ehs.shape[0] == btot and te.shape[0] == btot and ti.shape == (btot, 6)
+        outs = [torch.empty((x.shape[0], self.cfg.out_channels, x.shape[2], x.shape[3]), dtype=dt, device=self.device) for x in samples]
+        groups = (_lib.UNetGroup * len(samples))()
+        for g, (x, o) in enumerate(zip(samples, outs)):
+            groups[g].latents, groups[g].out = x.data_ptr(), o.data_ptr()
+            groups[g].batch, groups[g].H, groups[g].W = x.shape[0], x.shape[2], x.shape[3]
+        shapes = tuple((x.shape[0], x.shape[2], x.shape[3]) for x in samples)
+        key = ("mixed_cached", shapes, ctx_len, gn_patch)
+        need = self._ws_need.get(key)
+        if need is None:
+            need = self._ws_need[key] = self._lib.mx_unet_workspace_bytes_cached_mixed(self._handle, groups, len(samples), ctx_len, gn_patch)
+        if need == 0:
+            raise _lib.MxError("mx_unet_workspace_bytes_cached_mixed: " + self._lib.mx_last_error().decode())
+        stream = _lib.current_stream()
+        sk = int(stream or 0)
+        ws = self._ws_by_stream.get(sk)
+        if ws is None or ws.numel() < need:
+            self._ws_by_stream[sk] = None
+            ws = self._ws_by_stream[sk] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        desc = cache.bind(self, shapes, row_ids, gn_patch)
+        rc = self._lib.mx_unet_forward_cached_mixed(self._handle, stream, groups, len(samples), _lib.torch_dtype_code(dt), ts.data_ptr(), ehs.data_ptr(),
+                                                    te.data_ptr(), ti.data_ptr(), ctx_len, gn_patch, ws.data_ptr(), ws.numel(), desc)
+        if rc:
+            err = cache.error
+            cache.invalidate()
+            if err is not None:
+                raise err
+        _lib.check(rc, "mx_unet_forward_cached_mixed")
+        cache.after_forward()
+        return outs
+
     def forward(self, sample: Dict[str, torch.Tensor], timestep, encoder_hidden_states: torch.Tensor,
                 class_labels=None, timestep_cond=None, attention_mask=None, cross_attention_kwargs=None,
                 added_cond_kwargs: Optional[dict] = None, down_block_additional_residuals=None,
@@ -227,6 +274,18 @@ class MxUNet:
         keys = [k for k in sample if sample[k] is not None and sample[k].shape[0] > 0]
         if not is_sliced:
             keys = keys[:1]  # the reference's unsliced branch runs the first resolution only (unet.py:268-272)
+        if is_sliced and getattr(self, "_block_caches", None) is not None and len(keys) <= _lib.MAX_SEGS and patch_size is not None \
+                and all(int(k) % patch_size == 0 and int(k) > patch_size for k in keys):
+            # ESYMRED_USE_CACHE=TRUE with is_sliced=True: the cache at its reference unit, the patch; the resolutions in ONE launch sequence
+            ids = input_indices or {}
+            assert all(k in ids and len(ids[k]) > 0 and sample[k].shape[0] % len(ids[k]) == 0 for k in keys), \
+                "the block-skip cache keys its state by input_indices[resolution] (cache_manager.py:105)"
+            row_ids = [r for k in keys for r in _row_ids(ids[k], sample[k].shape[0])]
+            if self._patch_cache is None:
+                self._patch_cache = self._new_patch_cache()
+            res = self.forward_mixed_cached(self._patch_cache, [sample[k] for k in keys], row_ids, timestep, encoder_hidden_states, text_embeds, time_ids,
+                                            gn_patch=patch_size // 8)
+            return (dict(zip(keys, res)),)
         if is_sliced and len(keys) > 1 and len(keys) <= _lib.MAX_SEGS and getattr(self, "_block_caches", None) is None and self.mixed_one_sequence:
             # the resolutions of a mixed batch as ONE launch sequence (the reference: one patch batch, unet.py:242-260)
             assert patch_size is not None and all(int(k) % patch_size == 0 for k in keys)
@@ -260,13 +319,16 @@ class MxUNet:
     def enable_block_cache(self, down, up=None, forced_after: Optional[int] = None, observe: bool = False) -> None:
         """Route forward() through the block-skip cache, one state per resolution key: what ESYMRED_USE_CACHE=TRUE does to the
         reference's model (cache_manager.py:46-50).  `down` / `up`: objects with .predict(features) (block_cache.py)."""
-        from .block_cache import BlockSkipCache, FORCED_RUN_AFTER
+        from .block_cache import BlockSkipCache, FORCED_RUN_AFTER, PatchSkipCache
         fa = FORCED_RUN_AFTER if forced_after is None else forced_after
         self._new_block_cache = lambda: BlockSkipCache(down, up, forced_after=fa, observe=observe)
+        self._new_patch_cache = lambda: PatchSkipCache(down, up, forced_after=fa)      # is_sliced=True: the patch unit, all resolutions in one sequence
         self._block_caches = {}
+        self._patch_cache = None
 
     def disable_block_cache(self) -> None:
         self._block_caches = None
+        self._patch_cache = None
 
     __call__ = forward
 

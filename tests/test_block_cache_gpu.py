@@ -505,3 +505,111 @@ def test_cached_forward_against_the_oracle_of_the_cached_forward(tiny):
         assert np.array_equal(unc_h, unc_o), f"feature row {n}: uncached markers differ"
         # the differences are taken between bf16 activations here and fp32 ones in the oracle: 10 % of each value (+ a floor for ~0 differences)
         assert np.allclose(fh[:, 2:][~unc_h], fo[:, 2:][~unc_o], rtol=0.10, atol=2e-4), f"feature row {n} (block {int(fh[0, 0])}): {fh[:, 2:]} vs {fo[:, 2:]}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# the cache at the reference's own unit, the PATCH, over a mixed-resolution batch in one launch sequence (mx_unet_forward_cached_mixed)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class SeededMasks:
+    """answers that depend only on the call number and the number of rows (never on the feature values, except the uncached marker): the same
+    decisions for the HIP path and for the oracle, including whole-block skips"""
+
+    def __init__(self, seed, p=0.5):
+        self.seed, self.p, self.calls, self.rows = seed, p, 0, []
+
+    def predict(self, f):
+        f = np.asarray(f)
+        self.rows.append(f.copy())
+        self.calls += 1
+        rng = np.random.RandomState(self.seed + self.calls)
+        out = (rng.rand(len(f)) < self.p).astype(np.int64)
+        if self.calls % 9 == 0:
+            out[:] = 0                                      # nobody asks: the block is skipped as a whole (unless a forced run interferes)
+        out[f[:, 2] > 1e18] = 1                             # nothing cached: the reference's forests answer "run" on the MAX marker
+        return out
+
+
+def test_patch_unit_cached_forward_all_asking_equals_the_mixed_forward(tiny):
+    """with a predictor that always answers "run" the patch-unit entry computes the sliced mixed forward: every cached op takes its whole-image
+    launch and the state only adds copies -- equal to mx_unet_forward_mixed up to the extra bf16 rounding where the time embedding and the
+    residual are added after the op's output was stored (the reference caches conv1 / conv2 / to_out BEFORE those adds)"""
+    ocfg, net = tiny
+    ins = [ref.make_inputs(ocfg, b, hw, seed=70 + i) for i, (b, hw) in enumerate([(1, 16), (2, 32)])]
+    cat = lambda k: torch.cat([x[k] for x in ins]).cuda()
+    xs = [x[0].cuda().to(torch.bfloat16) for x in ins]
+    want = net.forward_mixed(xs, cat(1), cat(2), cat(3), cat(4), gn_patch=8)
+    net.enable_block_cache(Always(1))
+    try:
+        for _ in range(2):
+            got = net.forward({"128": xs[0], "256": xs[1]}, cat(1), cat(2), added_cond_kwargs={"text_embeds": cat(3), "time_ids": cat(4)},
+                              is_sliced=True, patch_size=64, input_indices={"128": ["a"], "256": ["b", "c"]})[0]
+        pcache = net._patch_cache
+        assert pcache.history == [0x7f, 0x7f] and pcache.patches_asked == pcache.patches_total == 2 * 7 * (4 + 2 * 16)
+    finally:
+        net.disable_block_cache()
+    for k, w in zip(("128", "256"), want):
+        l2 = float((got[k].float() - w.float()).norm() / w.float().norm())
+        assert l2 <= 0.01, f"{k}: rel L2 {l2}"
+
+
+def test_patch_unit_cached_forward_against_its_oracle(tiny):
+    """mx_unet_forward_cached_mixed against oracle/cache_patch_ref.CachedSlicedUNetRef -- the reference's cache at its own unit (is_sliced=True:
+    dictionaries keyed per 256-px patch; here 64-px patches of 128 / 256 px latents, i.e. 4 and 16 patches per latent) restated literally on the
+    patch pipeline: per-patch decisions, the convolutions and the two attention sub-blocks computed for the asking patches only with every other
+    patch taking the op's own cached output, GroupNorm statistics / halos / LayerNorms / feed-forward on the fresh tensors of ALL patches.  Seven
+    steps while the latents move, two resolutions in ONE launch sequence, random per-patch masks (the same for both sides), whole-block skips, a
+    request leaving and one joining, the forced run after four reuses.  Checked per step: every request's output, the per-patch masks, the set
+    of blocks that ran, and the per-patch feature rows."""
+    from oracle import cache_patch_ref
+    from sduss_amd.block_cache import MSE_UNCACHED
+    ocfg, net = tiny
+    P = ref.init_params(ocfg)
+    hip_pred, ora_pred = SeededMasks(11), SeededMasks(11)
+    ora = cache_patch_ref.CachedSlicedUNetRef(P, ocfg, ora_pred)
+    base = {k: ref.make_inputs(ocfg, 1, hw, seed=80 + i) for i, (k, hw) in enumerate([("a", 16), ("b", 32), ("c", 32), ("d", 32), ("e", 16)])}
+    comp = [{"128": ["a"], "256": ["b", "c"]}] * 3 + [{"128": ["a", "e"], "256": ["c", "d"]}] * 4
+    g = torch.Generator().manual_seed(19)
+    worst = 0.0
+    net.enable_block_cache(hip_pred)
+    try:
+        for s_, ids in enumerate(comp):
+            samples, rows = {}, []
+            for res in ids:
+                per = []
+                for k in ids[res]:
+                    smp, t, e, te, ti = base[k]
+                    smp = (smp + 0.06 * s_ * torch.randn(smp.shape, generator=g)).to(torch.bfloat16).float()
+                    per.append(smp)
+                    rows.append((torch.full((1,), 801.0 - 40.0 * s_), e, te, ti))
+                samples[res] = torch.cat(per)
+            cat = [torch.cat([r[j] for r in rows]) for j in range(4)]
+            row_ids = {res: [f"{k}#0" for k in ids[res]] for res in ids}         # what MxUNet.forward derives from input_indices (one CFG half here)
+            with torch.inference_mode():
+                want = ora.forward(row_ids, samples, cat[0], cat[1], cat[2], cat[3], 64)
+            got = net.forward({r: samples[r].cuda().to(torch.bfloat16) for r in samples}, cat[0].cuda(), cat[1].cuda(),
+                              added_cond_kwargs={"text_embeds": cat[2].cuda(), "time_ids": cat[3].cuda()}, is_sliced=True, patch_size=64,
+                              input_indices=ids)[0]
+            pcache = net._patch_cache
+            assert pcache.history[-1] == ora.blocks_run[-1], f"step {s_}: blocks run {pcache.history[-1]:#x} vs the oracle's {ora.blocks_run[-1]:#x}"
+            assert len(pcache.decisions) == len(ora.masks[-1]) == 7
+            for (blk, mh), mo in zip(pcache.decisions, ora.masks[-1]):
+                assert np.array_equal(mh, mo), f"step {s_}, block {blk}: per-patch masks differ"
+            for res in ids:
+                for i, k in enumerate(ids[res]):
+                    gi, wi = got[res][i].float().cpu(), want[res][i]
+                    l2 = float((gi - wi).norm() / wi.norm())
+                    worst = max(worst, l2)
+                    assert l2 <= 0.03 and float((gi - wi).abs().max()) <= 0.06 * float(wi.abs().max()), f"step {s_}, request {k} ({res} px): rel L2 {l2:.4f}"
+        frac = pcache.patches_asked / pcache.patches_total
+        print(f"patch-unit cached forward vs its oracle over {len(comp)} steps: worst rel L2 {worst:.4f}; blocks run {[hex(h) for h in pcache.history]}; "
+              f"{pcache.patches_asked} of {pcache.patches_total} patch-blocks asked ({frac:.2f})")
+        assert any(h != 0x7f for h in pcache.history[1:]) and 0.3 < frac < 0.9
+        feats_o = [f for step in ora.features for f in step]
+        assert len(hip_pred.rows) == len(feats_o)
+        for n, (fh, fo) in enumerate(zip(hip_pred.rows, feats_o)):
+            assert fh.shape == fo.shape and np.array_equal(fh[:, 0], fo[:, 0]) and np.allclose(fh[:, 1], fo[:, 1])
+            unc_h, unc_o = fh[:, 2:] >= MSE_UNCACHED * 0.5, fo[:, 2:] >= 1e18
+            assert np.array_equal(unc_h, unc_o), f"feature row {n}: uncached markers differ"
+            assert np.allclose(fh[:, 2:][~unc_h], fo[:, 2:][~unc_o], rtol=0.12, atol=3e-4), f"feature rows {n} (block {int(fh[0, 0])}) differ"
+    finally:
+        net.disable_block_cache()

@@ -772,3 +772,34 @@ def test_slo_tables_for_mi355x_have_the_reference_formats():
             assert len(rows) == 8 and all(b > a > 0 for a, b in zip(rows, rows[1:])), (model, res, rows)
             unet = [float(l.split(",")[1]) for l in open(path).read().strip().splitlines()[1:]]
             assert abs(unet[0] - den[str(res)]) < 0.02 * den[str(res)] + 1e-3         # batch-1 row == the STANDALONE entry
+
+
+def test_patch_unit_cache_sizing_walks_on_host(tiny):
+    """mx_unet_patch_cache_bytes / mx_unet_workspace_bytes_cached_mixed walk the step plan in its patch-unit cache mode with no launches
+    (the mixed-resolution batch of the GPU test: one 128 px and two 256 px requests, 64-px patches): the state holds every cached op's tensor
+    per request row -- far more than the per-sample block cache -- and the workspace holds the compact patch batches."""
+    from sduss_amd import config, lib
+    l = lib.load()
+    pcfg = config.UNetConfig.tiny()
+    cc = lib.UNetConfigC()
+    cc.in_channels, cc.out_channels, cc.n_levels, cc.layers_per_block = 4, 4, 3, 2
+    for i, v in enumerate(pcfg.block_out_channels):
+        cc.block_out_channels[i] = v; cc.down_has_attn[i] = int(pcfg.down_has_attn[i])
+        cc.transformer_layers[i] = pcfg.transformer_layers_per_block[i]; cc.num_heads[i] = pcfg.num_heads[i]
+    cc.cross_attention_dim, cc.addition_time_embed_dim = pcfg.cross_attention_dim, pcfg.addition_time_embed_dim
+    cc.projection_class_embeddings_input_dim, cc.norm_num_groups = pcfg.projection_class_embeddings_input_dim, 32
+    h = l.mx_unet_create(C.byref(cc))
+    assert h
+    state = l.mx_unet_patch_cache_bytes(h, 8, 32, 32, 8)
+    assert state > 0, l.mx_last_error()
+    assert state > l.mx_unet_block_cache_bytes(h, 8, 32, 32)
+    assert l.mx_unet_patch_cache_bytes(h, 16, 32, 32, 8) > 1.9 * state - (1 << 20)       # linear in the request rows
+    assert l.mx_unet_patch_cache_bytes(h, 8, 32, 32, 5) == 0                               # rows must be whole patches
+    groups = (lib.UNetGroup * 2)()
+    groups[0].batch, groups[0].H, groups[0].W = 1, 16, 16
+    groups[1].batch, groups[1].H, groups[1].W = 2, 32, 32
+    ws = l.mx_unet_workspace_bytes_cached_mixed(h, groups, 2, 77, 8)
+    assert ws > 0, l.mx_last_error()
+    assert ws >= l.mx_unet_workspace_bytes_mixed(h, groups, 2, 77)
+    assert l.mx_unet_workspace_bytes_cached_mixed(h, groups, 2, 77, 0) == 0 and b"is_sliced" in l.mx_last_error()
+    l.mx_unet_destroy(h)
