@@ -621,6 +621,21 @@ int mx_mmdit_forward_cached(mx_mmdit* u, void* stream, const void* latents, int 
                             const void* encoder_hidden_states, const void* pooled_projections, void* out, int batch, int H, int W,
                             int ctx_len, void* workspace, size_t workspace_bytes, mx_block_cache* cache);
 
+/* The MMDiT cache at the reference's unit over a mixed batch in ONE launch sequence (round 4).  The unit is the token CHUNK: the sliced branch cuts
+ * every latent into (res / patch)^2 equal token ranges keyed "<request id>-<k>" (modules/utils.py:86-122); `patch` is that patch edge in LATENT
+ * pixels (patch_size / 8 of the reference's call).  Per joint block ONE predict call for the chunks of all samples of all groups (rows: group,
+ * sample, chunk; n_feat 1; forced run after two reuses is the host's, cache_manager.py:163-191); a block none of whose chunks asks takes the image
+ * and the text stream from the state (SD3Transformer.py:151-228).  In a running block every op runs on all tokens except the attention
+ * (attention.py:296-372, 407-415): a resolution group with no asking chunk skips its joint attention and takes attn.output's cached to_out result
+ * (image tokens) and attn.encoder_output's cached to_add_out result (text tokens); a group with any asking chunk computes it whole.  The image-only
+ * attn2 of the dual blocks does the same, and a group whose asking ratio is <= 1/16 renews its asking chunks only (:303-325).  State: one row per
+ * request (slots / slot_valid / n_slots / max_h / max_w as for mx_unet_forward_cached_mixed).  Oracle: oracle/cache_patch_ref.CachedSlicedMMDiTRef. */
+size_t mx_mmdit_patch_cache_bytes(const mx_mmdit* u, int n_slots, int max_h, int max_w, int patch, int ctx_len);
+size_t mx_mmdit_workspace_bytes_cached_mixed(const mx_mmdit* u, const mx_unet_group* groups, int n_groups, int ctx_len, int patch);
+int mx_mmdit_forward_cached_mixed(mx_mmdit* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                                  const void* encoder_hidden_states, const void* pooled_projections, int ctx_len, int patch, void* workspace,
+                                  size_t workspace_bytes, mx_block_cache* cache);
+
 /* ------------------------------------------------------------------------------------------
  * The element-wise steps either side of the model call.
  * ------------------------------------------------------------------------------------------ */

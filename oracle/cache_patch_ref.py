@@ -226,3 +226,192 @@ class CachedSlicedUNetRef:
         x = F.conv2d(x, P["conv_out.weight"], P["conv_out.bias"])
         self.blocks_run.append(ran)
         return pr.concat_sample(patch_size, x, latent_offset)
+
+
+# =========================================================================================================================================
+# SD3 / SD3.5 MMDiT: the same cache around the joint blocks (SD3Transformer.py:140-228; transformer.py:299-388; attention.py:241-424)
+# =========================================================================================================================================
+class CachedSlicedMMDiTRef:
+    """``PatchSD3Transformer2DModel.forward(..., is_sliced=True)`` with ESYMRED_USE_CACHE=TRUE, restated on whole token sequences (the sliced
+    branch only re-chunks the token axis: every latent is cut into (res // patch_size)^2 equal TOKEN RANGES keyed "<request id>-<k>",
+    modules/utils.py:86-122; oracle/sd3_mmdit_ref.split_sample_sd3 is pinned against it):
+
+    * per joint block ``state_mask = state_input[i].get_sd3_mask(chunk keys, hidden chunks, i, timestep per chunk)`` -- per chunk the mean squared
+      difference to the cached input chunk, predictor, forced run after TWO reuses (cache_manager.py:163-191); the block runs when any chunk of
+      the batch asks, else the image stream comes from ``state_output[i]`` and the text stream from ``encoder_output[i]`` (SD3Transformer.py:151-228);
+    * inside a running block everything runs on all tokens EXCEPT the attention (attention.py:296-372): a RESOLUTION none of whose chunks asks
+      skips its joint attention -- its image tokens take ``attn.output``'s cached ``to_out`` result and its text tokens ``attn.encoder_output``'s
+      cached ``to_add_out`` result -- while a resolution with any asking chunk is computed whole (``mask[start:end] = True``); the image-only
+      ``attn2`` of the dual blocks does the same, except that a resolution whose asking ratio is <= 1/16 computes the asking chunks' queries only
+      (against all keys of their latent) and keeps the cache for its other chunks (:303-325)."""
+
+    def __init__(self, P, cfg, predictor, forced_after: int = 2):
+        from . import sd3_mmdit_ref as m
+        self.m = m
+        self.P = {k: v.to(torch.float32) for k, v in P.items()}
+        self.cfg = cfg
+        self.io = [BlockIO(predictor, forced_after) for _ in range(cfg.num_layers)]
+        self.enc_out = [None] * cfg.num_layers
+        self.ops: Dict[str, OpCache] = {}
+        self.masks, self.features, self.blocks_run = [], [], []
+
+    def op(self, name):
+        return self.ops.setdefault(name, OpCache())
+
+    def _attention(self, name, xin, cin, groups, keys, enc_keys, mask, last):
+        """xin: per group [n, L, d]; cin [sum n, Lt, d] or None (attn2).  Returns (image attention output per group, context output or None)."""
+        m, P, cfg = self.m, self.P, self.cfg
+        mask = mask.copy()
+        enc_mask = np.zeros(len(enc_keys), dtype=bool)
+        skip = False
+        new_rows, new_enc = [], []
+        ci = 0                                            # chunk cursor
+        si = 0                                            # sample cursor
+        for g, (n, nc) in enumerate(groups):
+            start, end = ci, ci + n * nc
+            x = xin[g]
+            L = x.shape[1]
+            if mask[start:end].sum() == 0:
+                skip = True
+            else:
+                ratio = mask[start:end].sum() / (end - start)
+                c = cin[si:si + n] if cin is not None else None
+                xo, co = m.joint_attention(P, name, x, c, cfg, last if cin is not None else True)
+                chunks = xo.reshape(n * nc, L // nc, -1)
+                if cin is None and ratio <= 1 / 16:       # attention.py:303-325: the asking chunks' queries only, the cache for the rest
+                    skip = True
+                    new_rows.append(chunks[torch.from_numpy(mask[start:end])])
+                else:
+                    mask[start:end] = True
+                    new_rows.append(chunks)
+                    if cin is not None:
+                        enc_mask[si:si + n] = True
+                        if co is not None:
+                            new_enc.append(co)
+            ci, si = end, si + n
+        new = torch.cat(new_rows) if new_rows else torch.zeros(0)
+        if not skip:                                      # update_and_return(..., skip=False): the cache is simply replaced
+            self.op(name + ".out").cache = {k: new[i] for i, k in enumerate(keys)}
+            out = new
+        else:
+            out = self.op(name + ".out").update_and_return(keys, new, mask)
+        co_all = None
+        if cin is not None and not last:
+            newe = torch.cat(new_enc) if new_enc else torch.zeros(0)
+            if not skip:
+                self.op(name + ".enc").cache = {k: newe[i] for i, k in enumerate(enc_keys)}
+                co_all = newe
+            else:
+                co_all = self.op(name + ".enc").update_and_return(enc_keys, newe, enc_mask)
+        # back to per-group [n, L, d]
+        outs, ci = [], 0
+        for g, (n, nc) in enumerate(groups):
+            outs.append(out[ci:ci + n * nc].reshape(n, -1, out.shape[-1]))
+            ci += n * nc
+        return outs, co_all
+
+    def _block(self, i, b, xs, ctx, temb_g, temb, groups, keys, enc_keys, mask, last, dual):
+        m, P, cfg = self.m, self.P, self.cfg
+        eps = cfg.norm_eps
+        F_ = F
+        mods = [F_.linear(F_.silu(t), P[f"{b}.norm1.linear.weight"], P[f"{b}.norm1.linear.bias"]) for t in temb_g]
+        xin, x2in, gates = [], [], []
+        for x, mod in zip(xs, mods):
+            nx = m._ln(x, eps)
+            if dual:
+                sh, sc, gate, sh_mlp, sc_mlp, g_mlp, sh2, sc2, gate2 = mod.chunk(9, dim=1)
+                x2in.append(nx * (1 + sc2[:, None]) + sh2[:, None])
+            else:
+                sh, sc, gate, sh_mlp, sc_mlp, g_mlp = mod.chunk(6, dim=1)
+                gate2 = None
+            xin.append(nx * (1 + sc[:, None]) + sh[:, None])
+            gates.append((gate, sh_mlp, sc_mlp, g_mlp, gate2))
+        cmod = F_.linear(F_.silu(temb), P[f"{b}.norm1_context.linear.weight"], P[f"{b}.norm1_context.linear.bias"])
+        if last:
+            c_sc, c_sh = cmod.chunk(2, dim=1)
+        else:
+            c_sh, c_sc, c_gate, c_sh_mlp, c_sc_mlp, c_g_mlp = cmod.chunk(6, dim=1)
+        cin = m._ln(ctx, eps) * (1 + c_sc[:, None]) + c_sh[:, None]
+        ao, co = self._attention(f"{b}.attn", xin, cin, groups, keys, enc_keys, mask, last)
+        xs = [x + g_[0][:, None] * a for x, g_, a in zip(xs, gates, ao)]
+        if dual:
+            ao2, _ = self._attention(f"{b}.attn2", x2in, None, groups, keys, enc_keys, mask, True)
+            xs = [x + g_[4][:, None] * a for x, g_, a in zip(xs, gates, ao2)]
+        out = []
+        for x, g_ in zip(xs, gates):
+            nh = m._ln(x, eps) * (1 + g_[2][:, None]) + g_[1][:, None]
+            out.append(x + g_[3][:, None] * m._ff(P, f"{b}.ff", nh))
+        if last:
+            return out, None
+        ctx = ctx + c_gate[:, None] * co
+        nc_ = m._ln(ctx, eps) * (1 + c_sc_mlp[:, None]) + c_sh_mlp[:, None]
+        ctx = ctx + c_g_mlp[:, None] * m._ff(P, f"{b}.ff_context", nc_)
+        return out, ctx
+
+    def forward(self, ids: Dict[str, List[str]], latents: Dict[str, torch.Tensor], timestep, encoder_hidden_states, pooled, patch_size: int):
+        m, P, cfg = self.m, self.P, self.cfg
+        ps, d = cfg.patch_size, cfg.dim
+        t = F.linear(m.timestep_embedding(timestep, 256), P["time_text_embed.timestep_embedder.linear_1.weight"], P["time_text_embed.timestep_embedder.linear_1.bias"])
+        t = F.linear(F.silu(t), P["time_text_embed.timestep_embedder.linear_2.weight"], P["time_text_embed.timestep_embedder.linear_2.bias"])
+        pp = F.linear(pooled.to(torch.float32), P["time_text_embed.text_embedder.linear_1.weight"], P["time_text_embed.text_embedder.linear_1.bias"])
+        pp = F.linear(F.silu(pp), P["time_text_embed.text_embedder.linear_2.weight"], P["time_text_embed.text_embedder.linear_2.bias"])
+        temb = t + pp
+        xs, groups, keys, enc_keys, temb_g, tpp, shapes = [], [], [], [], [], [], []
+        row = 0
+        for res, lat in latents.items():
+            n, _c, hh, ww = lat.shape
+            h, w = hh // ps, ww // ps
+            x = F.conv2d(lat.to(torch.float32), P["pos_embed.proj.weight"], P["pos_embed.proj.bias"], stride=ps).flatten(2).transpose(1, 2)
+            mm = cfg.pos_embed_max_size
+            top, left = (mm - h) // 2, (mm - w) // 2
+            x = x + P["pos_embed.pos_embed"].reshape(1, mm, mm, d)[:, top:top + h, left:left + w].reshape(1, h * w, d)
+            nc = (int(res) // patch_size) ** 2
+            xs.append(x); groups.append((n, nc)); shapes.append((n, hh, ww))
+            temb_g.append(temb[row:row + n])
+            for i in range(n):
+                enc_keys.append(ids[res][i])
+                keys += [f"{ids[res][i]}-{k}" for k in range(nc)]
+                tpp += [float(timestep[row + i])] * nc
+            row += n
+        ctx = F.linear(encoder_hidden_states.to(torch.float32), P["context_embedder.weight"], P["context_embedder.bias"])
+        self.masks.append([]); self.features.append([])
+        ran = 0
+        for i in range(cfg.num_layers):
+            b = f"transformer_blocks.{i}"
+            last, dual = i == cfg.num_layers - 1, i in cfg.dual_attention_layers
+            io = self.io[i]
+            per_chunk = [c for x, (n, nc) in zip(xs, groups) for c in x.reshape(n * nc, x.shape[1] // nc, d)]
+            mse = [float(((c - io.cin[k][0]) ** 2).mean()) if k in io.cin else 0.0 for c, k in zip(per_chunk, keys)]
+            mask, feat = io.mgr.get_mask(keys, mse, i, tpp, None)
+            io.cin = {k: [c.clone()] for c, k in zip(per_chunk, keys)}
+            self.masks[-1].append(mask.copy()); self.features[-1].append(feat)
+            if mask.sum() > 0:
+                xs_new, ctx_new = self._block(i, b, xs, ctx, temb_g, temb, groups, keys, enc_keys, mask, last, dual)
+                ran |= 1 << i
+                per_new = [c for x, (n, nc) in zip(xs_new, groups) for c in x.reshape(n * nc, x.shape[1] // nc, d)]
+                io.cout = {k: [c.clone()] for c, k in zip(per_new, keys)}
+                xs = xs_new
+                if not last:
+                    ctx = ctx_new
+                    self.enc_out[i] = {k: ctx_new[j].clone() for j, k in enumerate(enc_keys)}
+            else:
+                flat = [io.cout[k][0] for k in keys]
+                xs, ci = [], 0
+                for (n, nc) in groups:
+                    xs.append(torch.stack(flat[ci:ci + n * nc]).reshape(n, -1, d)); ci += n * nc
+                if not last:
+                    # SD3Transformer.py:219-226 keeps ONE tensor (the text stream of the block's last run, whatever batch that was: it cannot follow a
+                    # batch whose composition changed); restated per request, as every other cache of the path is keyed
+                    ctx = torch.stack([self.enc_out[i][k] for k in enc_keys])
+        self.blocks_run.append(ran)
+        outs, row = {}, 0
+        for (res, lat), x, (n, hh, ww) in zip(latents.items(), xs, shapes):
+            tg = temb[row:row + n]
+            sc, sh = F.linear(F.silu(tg), P["norm_out.linear.weight"], P["norm_out.linear.bias"]).chunk(2, dim=1)
+            y = m._ln(x, cfg.norm_eps) * (1 + sc[:, None]) + sh[:, None]
+            y = F.linear(y, P["proj_out.weight"], P["proj_out.bias"])
+            h, w = hh // ps, ww // ps
+            y = y.reshape(n, h, w, ps, ps, cfg.out_channels)
+            outs[res] = torch.einsum("nhwpqc->nchpwq", y).reshape(n, cfg.out_channels, h * ps, w * ps)
+            row += n
+        return outs

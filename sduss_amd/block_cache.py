@@ -247,7 +247,10 @@ class PatchSkipCache:
     sample id, i.e. per request and CFG half), the per-patch reuse counters and the predictor callback (one call per block for the patches of
     all samples of all resolutions)."""
 
-    def __init__(self, down, up=None, forced_after: int = FORCED_RUN_AFTER, max_latent: int = 128):
+    def __init__(self, down, up=None, forced_after: int = FORCED_RUN_AFTER, max_latent: int = 128, mmdit_ctx_len: Optional[int] = None):
+        """mmdit_ctx_len: set for the SD3 / SD3.5 transformer (mx_mmdit_forward_cached_mixed): the unit is then the token chunk
+        "<request id>-<k>" (modules/utils.py:86-122), one cache point per joint block, forced run after two reuses (pass forced_after=2)."""
+        self.mmdit_ctx_len = mmdit_ctx_len
         wrap = lambda p: CompiledForest(p) if hasattr(p, "estimators_") and hasattr(p, "n_features_in_") else p
         self.down, self.up = wrap(down), wrap(up if up is not None else down)
         self.forced_after = forced_after
@@ -304,9 +307,12 @@ class PatchSkipCache:
         if n > self._cap or ml != self.max_latent or self.state is None:
             self.max_latent = ml
             self._cap = max(2 * n, 8)
-            need = model._lib.mx_unet_patch_cache_bytes(model._handle, self._cap, ml, ml, gn_patch)
+            if self.mmdit_ctx_len is None:
+                need = model._lib.mx_unet_patch_cache_bytes(model._handle, self._cap, ml, ml, gn_patch)
+            else:
+                need = model._lib.mx_mmdit_patch_cache_bytes(model._handle, self._cap, ml, ml, gn_patch, self.mmdit_ctx_len)
             if need == 0:
-                raise _lib.MxError("mx_unet_patch_cache_bytes: " + model._lib.mx_last_error().decode())
+                raise _lib.MxError("patch_cache_bytes: " + model._lib.mx_last_error().decode())
             self.state = None
             self.state = torch.empty(need, dtype=torch.uint8, device=model.device)
             self._slot_of, self.previous = {}, {}
@@ -323,7 +329,10 @@ class PatchSkipCache:
         keys, i = [], 0
         for b, h, w in shapes:                                # the library's patch order: group, sample, patch row, patch column
             for _ in range(b):
-                keys += [f"{row_ids[i]}-{py}-{px}" for py in range(h // gn_patch) for px in range(w // gn_patch)]
+                if self.mmdit_ctx_len is None:
+                    keys += [f"{row_ids[i]}-{py}-{px}" for py in range(h // gn_patch) for px in range(w // gn_patch)]
+                else:
+                    keys += [f"{row_ids[i]}-{k}" for k in range((h // gn_patch) * (w // gn_patch))]
                 i += 1
         self._keys = keys
         alive = set(keys)
@@ -342,7 +351,7 @@ class PatchSkipCache:
     def after_forward(self):
         if self._pending is not None:
             self._slot_of, self._pending = self._pending, None
-        self.history.append(int(self.desc.blocks_run))
+        self.history.append(int(self.desc.blocks_run) | int(self.desc.blocks_run_hi) << 32)
         self.patches_asked += int(self.desc.patches_asked)
         self.patches_total += int(self.desc.patches_total)
 

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "graph_cache.h"
 #include "pp_exchange.h"
+#include "patch_cache.h"
 
 namespace mx {
 int launch_patchify(hipStream_t s, const void* in, int dtype, void* out, int B, int C, int H, int W, int ps);
@@ -77,11 +78,13 @@ struct Plan {
   void set_single(int batch, int h, int w, const void* lat, void* out) { ng = 1; gB[0] = batch; gH[0] = h; gW[0] = w; gb0[0] = 0; g_lat[0] = lat; g_out[0] = out; B = batch; H = h; W = w; }
   typedef std::function<void(int, mx_gemm_seg&)> SegFill;      // fills problem g of a grouped GEMM
   mx_gemm_seg seg_buf[MX_MAX_SEGS];
+  const bool* act = nullptr;        // cached mixed batch: the grouped launch covers these resolution groups only (nullptr: all)
   void attach(mx_gemm_desc& d, const SegFill& fill) {
     if (ng <= 1 || !fill) return;
     std::memset(seg_buf, 0, sizeof(seg_buf));
-    for (int g = 0; g < ng; ++g) fill(g, seg_buf[g]);
-    d.segs = seg_buf; d.n_segs = ng;
+    int n = 0;
+    for (int g = 0; g < ng; ++g) if (!act || act[g]) fill(g, seg_buf[n++]);
+    d.segs = seg_buf; d.n_segs = n;
   }
   bool dry, lookup = false;
   bool mute = false;               // block-skip cache: the block is reused, nothing of it is launched
@@ -100,6 +103,24 @@ struct Plan {
     if (quiet()) return true;
     if (hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("patch-parallel: K / V assembly copy failed");
     return true;
+  }
+  // ---- the cache at the reference's unit over a mixed batch in ONE launch sequence (mx_mmdit_forward_cached_mixed) ----
+  // The unit is the token CHUNK: every latent is cut into (res // patch)^2 equal token ranges keyed "<request id>-<k>" (modules/utils.py:86-122).
+  // Per joint block ONE decision for the chunks of all samples of all groups (get_sd3_mask, cache_manager.py:163-191); a block none of whose
+  // chunks asks takes both streams from the state; in a running block everything runs on all tokens except the attention: a resolution group
+  // with no asking chunk skips it and takes attn.output / attn.encoder_output's cached results, a group with any asking chunk computes it whole
+  // (attention.py:296-372; attn2 of the dual blocks: asking ratio <= 1/16 -> only the asking chunks are renewed, :303-325).
+  bool pcm = false;
+  int pcm_patch = 0, pcm_slots = 0, pcm_maxh = 0, pcm_maxw = 0, pcm_nc = 0;
+  std::vector<mx::PcSample> pcm_img, pcm_ctx;
+  std::vector<mx::PcRange> pcm_chunks;
+  std::vector<int> pcm_chunk_b, pcm_chunk_g;
+  mx::PcSample* pcm_dimg = nullptr; mx::PcSample* pcm_dctx = nullptr; mx::PcRange* pcm_dchunks = nullptr; mx::PcRange* pcm_dtmp = nullptr; double* pcm_dpart = nullptr;
+  unsigned long long pcm_asked = 0, pcm_total = 0;
+  size_t pcm_ncmax() const { return (size_t)pcm_slots * (pcm_maxh / pcm_patch) * (pcm_maxw / pcm_patch); }
+  size_t pcm_head_bytes() const {
+    const size_t nc = pcm_ncmax();
+    return ((nc * 64 * sizeof(double) + 2 * (size_t)pcm_slots * sizeof(mx::PcSample) + 4 * nc * sizeof(mx::PcRange)) + 255) & ~(size_t)255;
   }
   mx_block_cache* bc = nullptr;    // mx_mmdit_forward_cached
   size_t bc_bytes = 0;             // state bytes the plan needs (also the dry answer of mx_mmdit_block_cache_bytes)
@@ -236,7 +257,7 @@ struct Plan {
       r0[g] = rows_i; jr0[g] = rows_j; vj0[g] = el_vj; vi0[g] = el_vi;
       rows_i += (long)gB[g] * gL[g]; rows_j += (long)gB[g] * gLj[g]; el_vj += (long)gB[g] * d * gldj[g]; el_vi += (long)gB[g] * d * gldi[g];
     }
-    if (ng > 1 && (is_pp() || bc)) return fail("mmdit: a mixed-resolution batch runs neither patch-parallel nor through the block cache");
+    if (ng > 1 && (is_pp() || (bc && !pcm))) return fail("mmdit: a mixed-resolution batch runs neither patch-parallel nor through the per-sample block cache");
     const int MI = (int)rows_i, MT = B * Lt;
     // patch-parallel: L counts this rank's image tokens; the keys of the joint attention are all ranks' image tokens, then the text tokens
     const int world = px.world;
@@ -306,6 +327,9 @@ struct Plan {
     bf16_t* o_i = alloc<bf16_t>((size_t)MI * d);
     bf16_t* ff = alloc<bf16_t>((size_t)MI * 4 * d);
     bf16_t* ffc = alloc<bf16_t>((size_t)MT * 4 * d);
+    bf16_t* pcm_ti = pcm ? alloc<bf16_t>((size_t)MI * d) : nullptr;          // cached mixed batch: to_out / to_add_out results before the gate
+    bf16_t* pcm_tc = pcm ? alloc<bf16_t>((size_t)MT * d) : nullptr;
+    char* pcm_top = pcm ? (dry ? (char*)(uintptr_t)0x1000 : (char*)bc->state) + pcm_head_bytes() : nullptr;
     // patch-parallel: only the image tokens' K rows and V^T columns travel (what distrifuser gathers, modules/pp/attn.py:222-233): they are packed
     // into contiguous send buffers first -- the QKV epilogue writes q|k interleaved and V^T rows padded, with the text tokens behind the image ones
     bf16_t *k_send = nullptr, *v_send = nullptr, *k_g = nullptr, *v_g = nullptr, *k_all = nullptr, *vt_all = nullptr;
@@ -397,6 +421,139 @@ struct Plan {
     for (int i = 0; i < c.num_layers && ok(); ++i) {
       const std::string b = "transformer_blocks." + std::to_string(i);
       const bool dual = c.dual_attention[i] != 0, last = i == c.num_layers - 1;
+      if (pcm) {
+        const long Lmax = (long)(pcm_maxh / ps) * (pcm_maxw / ps);
+        const long row_i = Lmax * d, row_c = (long)Lt * d;
+        auto region = [&](long row_elems) { char* r = pcm_top; pcm_top += ((size_t)row_elems * pcm_slots * 2 + 255) & ~(size_t)255; return r; };
+        char* r_in = region(row_i); char* r_out = region(row_i); char* r_octx = last ? nullptr : region(row_c);
+        char* r_a = region(row_i); char* r_ae = last ? nullptr : region(row_c); char* r_a2 = dual ? region(row_i) : nullptr;
+        if (dry) continue;
+        if ((size_t)(pcm_top - (char*)bc->state) > bc->state_bytes) { fail("mmdit patch cache: state buffer too small (mx_mmdit_patch_cache_bytes)"); break; }
+        long maxL = 0; for (int g = 0; g < ng; ++g) maxL = std::max<long>(maxL, gL[g]);
+        auto img_copy = [&](void* t, char* reg, int to_batch, const float* vec, const void* res, int gate) {
+          if (ok() && mx::launch_pc_image_copy(stream, t, reg, pcm_dimg, B, 0, d, row_i, to_batch, vec, ntot, res, maxL * d, gate)) fail(mx_last_error()); };
+        auto ctx_copy = [&](void* t, char* reg, int to_batch, const float* vec, const void* res, int gate) {
+          if (ok() && mx::launch_pc_image_copy(stream, t, reg, pcm_dctx, B, 0, d, row_c, to_batch, vec, ntot, res, (long)Lt * d, gate)) fail(mx_last_error()); };
+        // ---- decision, per chunk ----
+        const int NC = pcm_nc;
+        std::vector<float> mse(NC, MX_MSE_UNCACHED);
+        if (bc_any_valid) {
+          std::vector<double> hp((size_t)NC * 64);
+          if (mx::launch_pc_range_sq_diff(stream, x, r_in, row_i, d, pcm_dchunks, NC, pcm_dpart)) { fail(mx_last_error()); break; }
+          if (hipMemcpyAsync(hp.data(), pcm_dpart, hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+              hipStreamSynchronize(stream) != hipSuccess) { fail("mmdit patch cache: reading the input differences failed"); break; }
+          for (int j = 0; j < NC; ++j) {
+            if (!bc_valid[pcm_chunk_b[j]]) continue;
+            double t = 0.0;
+            for (int k = 0; k < 64; ++k) t += hp[(size_t)j * 64 + k];
+            mse[j] = (float)(t / ((double)pcm_chunks[j].rows * d));
+          }
+        }
+        std::vector<unsigned char> run(NC, 1);
+        std::vector<float> tpp(NC);
+        for (int j = 0; j < NC; ++j) tpp[j] = h_timesteps[pcm_chunk_b[j]];
+        if (bc->predict(bc->ctx, i, 0, NC, 1, tpp.data(), mse.data(), run.data())) { fail("mmdit patch cache: the predictor failed"); break; }
+        bool gany[MX_MAX_SEGS] = {false, false, false, false};
+        int gask[MX_MAX_SEGS] = {0, 0, 0, 0}, gtot[MX_MAX_SEGS] = {0, 0, 0, 0};
+        bool any = false;
+        for (int j = 0; j < NC; ++j) {
+          if (!bc_valid[pcm_chunk_b[j]]) run[j] = 1;
+          const int g = pcm_chunk_g[j];
+          ++gtot[g];
+          if (run[j]) { gany[g] = true; any = true; ++gask[g]; ++pcm_asked; }
+          ++pcm_total;
+        }
+        img_copy(x, r_in, 0, nullptr, nullptr, 0);                           // the cached input is always the latest one (cache_manager.py:183)
+        if (!any) {                                                           // SD3Transformer.py:219-228: both streams from the block's caches
+          img_copy(x, r_out, 1, nullptr, nullptr, 0);
+          if (!last) ctx_copy(ctx, r_octx, 1, nullptr, nullptr, 0);
+          continue;
+        }
+        blocks_run |= 1ull << i;
+        const float* mi = mod + off_img[i];
+        const float* mc = mod + off_ctx[i];
+        // ranges of the samples of the active groups (image rows / text rows), uploaded per use
+        auto upload = [&](const std::vector<mx::PcRange>& v, int slot) -> const mx::PcRange* {
+          mx::PcRange* dst = pcm_dtmp + (size_t)slot * pcm_ncmax();
+          if (ok() && !v.empty() && hipMemcpyAsync(dst, v.data(), v.size() * sizeof(mx::PcRange), hipMemcpyHostToDevice, stream) != hipSuccess)
+            fail("mmdit patch cache: sending a range table failed");
+          return dst;
+        };
+        std::vector<mx::PcRange> act_img, act_ctx;
+        for (int g = 0; g < ng; ++g) if (gany[g]) for (int k = 0; k < gB[g]; ++k) {
+          const int bb = gb0[g] + k;
+          act_img.push_back(mx::PcRange{pcm_img[bb].row0, gL[g], pcm_img[bb].slot, 0});
+          act_ctx.push_back(mx::PcRange{(long long)bb * Lt, Lt, pcm_img[bb].slot, 0});
+        }
+        const mx::PcRange* d_act_img = upload(act_img, 0);
+        const mx::PcRange* d_act_ctx = upload(act_ctx, 1);
+        lnmod(x, xin, dual ? x2in : nullptr, mi + d, mi, dual ? mi + 7 * d : nullptr, dual ? mi + 6 * d : nullptr, ntot, MI, d, L, true);
+        if (last) lnmod(ctx, cin, nullptr, mc, mc + d, nullptr, nullptr, ntot, MT, d, Lt);
+        else lnmod(ctx, cin, nullptr, mc + d, mc, nullptr, nullptr, ntot, MT, d, Lt);
+        // the q | k | v projections of both streams: all groups (the reference projects every chunk, attention.py:257-285)
+        qkv(xin, b + ".attn.to_qkv", b + ".attn.norm_q.weight", b + ".attn.norm_k.weight", qk_j, vt_j, ldvt_j, MI, d, L, Lj, 0, [&](int g, mx_gemm_seg& q) {
+          q.a = xin + r0[g] * d; q.c = qk_j + jr0[g] * 2 * d; q.vt = vt_j + vj0[g]; q.M = gB[g] * gL[g]; q.rows_per_batch = gL[g]; q.ldvt = gldj[g];
+          q.c_batch_rows = gLj[g]; q.c_row_off = 0; });
+        qkv(cin, b + ".attn.add_qkv", b + ".attn.norm_added_q.weight", b + ".attn.norm_added_k.weight", qk_j, vt_j, ldvt_j, MT, d, Lt, Lj, L, [&](int g, mx_gemm_seg& q) {
+          q.a = cin + (long)gb0[g] * Lt * d; q.c = qk_j + jr0[g] * 2 * d; q.vt = vt_j + vj0[g]; q.M = gB[g] * Lt; q.rows_per_batch = Lt; q.ldvt = gldj[g];
+          q.c_batch_rows = gLj[g]; q.c_row_off = gL[g]; });
+        auto attention_active = [&](bf16_t* qk, bf16_t* vt, bf16_t* o, const long* row0s, const long* vt0s, const int* Ls, const int* lds) {
+          mx_attn_problem pr[MX_MAX_SEGS];
+          int n = 0;
+          for (int g = 0; g < ng; ++g) if (gany[g]) {
+            pr[n].q = qk + row0s[g] * 2 * d; pr[n].k = qk + row0s[g] * 2 * d + d; pr[n].vt = vt + vt0s[g]; pr[n].o = o + row0s[g] * d;
+            pr[n].vt_batch_stride = (int64_t)d * lds[g]; pr[n].B = gB[g]; pr[n].Lq = Ls[g]; pr[n].Lk = Ls[g]; pr[n].ldvt = lds[g];
+            ++n;
+          }
+          if (ok() && n && mx_attention_prescaled_grouped(stream, pr, n, 2 * d, 2 * d, d, heads)) fail(std::string("attention: ") + mx_last_error());
+        };
+        attention_active(qk_j, vt_j, o_j, jr0, vj0, gLj, gldj);
+        act = gany;
+        // to_out of the active groups' image rows, no gate / residual: what attn.output caches (attention.py:407-415)
+        linear(o_j, d, b + ".attn.to_out.0", pcm_ti, d, MI, d, d, 0, nullptr, 0, nullptr, 0, L, Lj, 0, [&](int g, mx_gemm_seg& q) {
+          q.a = o_j + jr0[g] * d; q.c = pcm_ti + r0[g] * d; q.M = gB[g] * gL[g]; q.rows_per_batch = gL[g]; q.a_batch_rows = gLj[g]; q.a_row_off = 0; });
+        act = nullptr;
+        if (ok() && mx::launch_pc_range_copy(stream, pcm_ti, r_a, row_i, d, d_act_img, (int)act_img.size(), 0, maxL * d)) fail(mx_last_error());
+        img_copy(x, r_a, 1, mi + 2 * d, x, 1);                                 // x += gate_msa * attn.output (fresh or cached)   (transformer.py:344-345)
+        if (dual) {
+          qkv(x2in, b + ".attn2.to_qkv", b + ".attn2.norm_q.weight", b + ".attn2.norm_k.weight", qk_i, vt_i, ldvt_i, MI, d, L, 0, 0, [&](int g, mx_gemm_seg& q) {
+            q.a = x2in + r0[g] * d; q.c = qk_i + r0[g] * 2 * d; q.vt = vt_i + vi0[g]; q.M = gB[g] * gL[g]; q.rows_per_batch = gL[g]; q.ldvt = gldi[g]; });
+          attention_active(qk_i, vt_i, o_i, r0, vi0, gL, gldi);
+          act = gany;
+          linear(o_i, d, b + ".attn2.to_out.0", pcm_ti, d, MI, d, d, 0, nullptr, 0, nullptr, 0, L, 0, 0, [&](int g, mx_gemm_seg& q) {
+            q.a = o_i + r0[g] * d; q.c = pcm_ti + r0[g] * d; q.M = gB[g] * gL[g]; q.rows_per_batch = gL[g]; });
+          act = nullptr;
+          // a group whose asking ratio is <= 1/16 renews its asking chunks only (attention.py:303-325); the others renew every chunk
+          std::vector<mx::PcRange> rng2;
+          for (int g = 0; g < ng; ++g) if (gany[g]) {
+            const bool sparse = gask[g] * 16 <= gtot[g];
+            if (!sparse) { for (int k = 0; k < gB[g]; ++k) { const int bb = gb0[g] + k; rng2.push_back(mx::PcRange{pcm_img[bb].row0, gL[g], pcm_img[bb].slot, 0}); } }
+            else for (int j = 0; j < NC; ++j) if (pcm_chunk_g[j] == g && run[j]) rng2.push_back(pcm_chunks[j]);
+          }
+          const mx::PcRange* d_rng2 = upload(rng2, 2);
+          if (ok() && mx::launch_pc_range_copy(stream, pcm_ti, r_a2, row_i, d, d_rng2, (int)rng2.size(), 0, maxL * d)) fail(mx_last_error());
+          img_copy(x, r_a2, 1, mi + 8 * d, x, 1);
+        }
+        lnmod(x, xin, nullptr, mi + 4 * d, mi + 3 * d, nullptr, nullptr, ntot, MI, d, L, true);
+        linear(xin, d, b + ".ff.net.0.proj", ff, 4 * d, MI, 4 * d, d, MX_EPI_GELU_TANH);
+        linear(ff, 4 * d, b + ".ff.net.2", x, d, MI, d, 4 * d, 0, x, d, mi + 5 * d, ntot, L, 0, 0, [&](int g, mx_gemm_seg& q) {
+          q.a = ff + r0[g] * 4 * d; q.c = x + r0[g] * d; q.residual = x + r0[g] * d; q.gate = mi + 5 * d + (long)gb0[g] * ntot; q.M = gB[g] * gL[g];
+          q.rows_per_batch = gL[g]; });
+        if (!last) {
+          act = gany;
+          linear(o_j, d, b + ".attn.to_add_out", pcm_tc, d, MT, d, d, 0, nullptr, 0, nullptr, 0, Lt, Lj, L, [&](int g, mx_gemm_seg& q) {
+            q.a = o_j + jr0[g] * d; q.c = pcm_tc + (long)gb0[g] * Lt * d; q.M = gB[g] * Lt; q.rows_per_batch = Lt; q.a_batch_rows = gLj[g]; q.a_row_off = gL[g]; });
+          act = nullptr;
+          if (ok() && mx::launch_pc_range_copy(stream, pcm_tc, r_ae, row_c, d, d_act_ctx, (int)act_ctx.size(), 0, (long)Lt * d)) fail(mx_last_error());
+          ctx_copy(ctx, r_ae, 1, mc + 2 * d, ctx, 1);                          // ctx += c_gate_msa * attn.encoder_output (fresh or cached)
+          lnmod(ctx, cin, nullptr, mc + 4 * d, mc + 3 * d, nullptr, nullptr, ntot, MT, d, Lt);
+          linear(cin, d, b + ".ff_context.net.0.proj", ffc, 4 * d, MT, 4 * d, d, MX_EPI_GELU_TANH);
+          linear(ffc, 4 * d, b + ".ff_context.net.2", ctx, d, MT, d, 4 * d, 0, ctx, d, mc + 5 * d, ntot, Lt);
+        }
+        img_copy(x, r_out, 0, nullptr, nullptr, 0);
+        if (!last) ctx_copy(ctx, r_octx, 0, nullptr, nullptr, 0);
+        continue;
+      }
       const bool cached = bc != nullptr && !dry;
       const bool ran = cached ? decide(i) : true;
       if (!ok()) break;
@@ -469,6 +626,7 @@ struct Plan {
       mute = false;
       if (cached && ok()) after(i, ran, last);
     }
+    if (pcm) bc_bytes = (size_t)(pcm_top - (dry ? (char*)(uintptr_t)0x1000 : (char*)bc->state));
     // ---- norm_out (AdaLN-continuous) + proj_out + unpatchify (SD3Transformer.py:238-259) ----
     lnmod(x, xin, nullptr, mod + off_out, mod + off_out + d, nullptr, nullptr, ntot, MI, d, L, true);
     const int No = ps * ps * c.out_channels;
@@ -670,6 +828,122 @@ extern "C" int mx_mmdit_pp_comm_plan(const mx_mmdit* u, int batch, int H_local, 
   MX_CHECK(u && comm && comm->all_gather, "mmdit_pp_comm_plan: bad arguments");
   return forward_impl(const_cast<mx_mmdit*>(u), nullptr, nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr, batch, H_local, W, ctx_len, nullptr, 0,
                       nullptr, nullptr, 0, true, nullptr, false, comm);
+}
+
+/* ---- the cache at the reference's unit (token chunks) over a mixed batch in ONE launch sequence (include/mxdenoise.h) ---- */
+namespace {
+int pcm_setup(Plan& p, mx_mmdit* u, const mx_unet_group* groups, int n_groups, int ctx_len, int patch, const mx_block_cache* cache, bool dry) {
+  MX_CHECK(u != nullptr, "mmdit: null handle");
+  MX_CHECK(groups && n_groups >= 1 && n_groups <= MX_MAX_SEGS, "mmdit_forward_cached_mixed: 1..MX_MAX_SEGS resolution groups");
+  MX_CHECK(u->cfg.num_layers <= 64, "mmdit_forward_cached_mixed: at most 64 blocks");
+  const int ps = u->cfg.patch_size;
+  MX_CHECK(patch > 0 && patch % ps == 0, "mmdit_forward_cached_mixed: the chunk unit (latent pixels per patch edge) must be a multiple of patch_size");
+  MX_CHECK(cache && cache->n_slots > 0 && cache->max_h > 0 && cache->max_w > 0 && cache->max_h % patch == 0 && cache->max_w % patch == 0,
+           "mmdit_forward_cached_mixed: cache->n_slots, max_h, max_w (multiples of the patch) are required");
+  MX_CHECK(ctx_len > 0, "mmdit: bad shape");
+  p.u = u; p.Lt = ctx_len; p.dry = dry;
+  p.ng = n_groups; p.B = 0;
+  p.pcm = true; p.pcm_patch = patch; p.pcm_slots = cache->n_slots; p.pcm_maxh = cache->max_h; p.pcm_maxw = cache->max_w;
+  p.pcm_img.clear(); p.pcm_ctx.clear(); p.pcm_chunks.clear(); p.pcm_chunk_b.clear(); p.pcm_chunk_g.clear();
+  long long row0 = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    MX_CHECK(groups[g].batch > 0 && groups[g].H > 0 && groups[g].W > 0 && groups[g].H % patch == 0 && groups[g].W % patch == 0,
+             "mmdit_forward_cached_mixed: every group's H, W must be multiples of the patch");
+    MX_CHECK(groups[g].H <= cache->max_h && groups[g].W <= cache->max_w, "mmdit_forward_cached_mixed: a group is larger than the state rows (max_h, max_w)");
+    MX_CHECK(groups[g].H / ps <= u->cfg.pos_embed_max_size && groups[g].W / ps <= u->cfg.pos_embed_max_size, "mmdit: latent larger than the positional table");
+    MX_CHECK(dry || (groups[g].latents && groups[g].out), "mmdit: null group operand");
+    p.gB[g] = groups[g].batch; p.gH[g] = groups[g].H; p.gW[g] = groups[g].W; p.gb0[g] = p.B; p.g_lat[g] = groups[g].latents; p.g_out[g] = groups[g].out;
+    const int L = (groups[g].H / ps) * (groups[g].W / ps), nc = (groups[g].H / patch) * (groups[g].W / patch);
+    MX_CHECK(L % nc == 0, "mmdit_forward_cached_mixed: the tokens of a latent must split into equal chunks");
+    for (int k = 0; k < groups[g].batch; ++k) {
+      const int b = p.B + k;
+      const int slot = (!dry && cache->slots) ? cache->slots[b] : b;
+      p.pcm_img.push_back(mx::PcSample{row0, L, 1, slot, 1});
+      p.pcm_ctx.push_back(mx::PcSample{(long long)b * ctx_len, ctx_len, 1, slot, 1});
+      for (int j = 0; j < nc; ++j) {
+        p.pcm_chunks.push_back(mx::PcRange{row0 + (long long)j * (L / nc), L / nc, slot, j * (L / nc)});
+        p.pcm_chunk_b.push_back(b); p.pcm_chunk_g.push_back(g);
+      }
+      row0 += L;
+    }
+    p.B += groups[g].batch;
+  }
+  p.H = groups[0].H; p.W = groups[0].W;
+  p.pcm_nc = (int)p.pcm_chunks.size();
+  MX_CHECK(p.B <= cache->n_slots, "mmdit_forward_cached_mixed: more samples than state rows (n_slots)");
+  return 0;
+}
+size_t pcm_dry(const mx_mmdit* u, const mx_unet_group* groups, int n_groups, int ctx_len, int patch, const mx_block_cache* sizing, bool want_state) {
+  Plan p;
+  if (pcm_setup(p, const_cast<mx_mmdit*>(u), groups, n_groups, ctx_len, patch, sizing, true)) return 0;
+  p.stream = nullptr; p.ar.base = nullptr; p.ar.cap = 0; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = true;
+  p.bc = const_cast<mx_block_cache*>(sizing);
+  if (!p.run(nullptr, MX_BF16, nullptr, nullptr, nullptr, nullptr)) { mx::set_error(p.err); return 0; }
+  return want_state ? p.bc_bytes + 256 : p.ar.peak + 256;
+}
+}  // namespace
+
+extern "C" size_t mx_mmdit_patch_cache_bytes(const mx_mmdit* u, int n_slots, int max_h, int max_w, int patch, int ctx_len) {
+  if (!u || n_slots <= 0 || max_h <= 0 || max_w <= 0 || patch <= 0 || ctx_len <= 0) { mx::set_error("mmdit_patch_cache_bytes: bad arguments"); return 0; }
+  mx_block_cache sizing{};
+  sizing.n_slots = n_slots; sizing.max_h = max_h; sizing.max_w = max_w;
+  mx_unet_group g{nullptr, nullptr, n_slots, max_h, max_w};
+  return pcm_dry(u, &g, 1, ctx_len, patch, &sizing, true);
+}
+
+extern "C" size_t mx_mmdit_workspace_bytes_cached_mixed(const mx_mmdit* u, const mx_unet_group* groups, int n_groups, int ctx_len, int patch) {
+  mx_block_cache sizing{};
+  if (groups) for (int g = 0; g < n_groups && g < MX_MAX_SEGS; ++g) {
+    sizing.n_slots += groups[g].batch; sizing.max_h = std::max(sizing.max_h, groups[g].H); sizing.max_w = std::max(sizing.max_w, groups[g].W);
+  }
+  return pcm_dry(u, groups, n_groups, ctx_len, patch, &sizing, false);
+}
+
+extern "C" int mx_mmdit_forward_cached_mixed(mx_mmdit* u, void* stream, const mx_unet_group* groups, int n_groups, int io_dtype, const float* timesteps,
+                                             const void* ehs, const void* pooled, int ctx_len, int patch, void* workspace, size_t workspace_bytes,
+                                             mx_block_cache* cache) {
+  MX_CHECK(cache && cache->predict && cache->state && cache->slots && cache->slot_valid, "mmdit_forward_cached_mixed: cache with predict, state, slots and slot_valid is required");
+  MX_CHECK(((uintptr_t)cache->state & 255) == 0, "mmdit_forward_cached_mixed: cache->state must be 256-byte aligned");
+  Plan p;
+  if (pcm_setup(p, u, groups, n_groups, ctx_len, patch, cache, false)) return 1;
+  MX_CHECK(timesteps && ehs && pooled && workspace, "mmdit: null operand");
+  MX_CHECK(u->blob != nullptr, "mmdit: weights not set");
+  MX_CHECK(io_dtype == MX_F32 || io_dtype == MX_F16 || io_dtype == MX_BF16, "mmdit: bad io dtype");
+  const int B = p.B;
+  std::vector<char> seen(cache->n_slots, 0);
+  p.bc_valid.assign(B, 0);
+  p.bc_all_valid = true; p.bc_any_valid = false;
+  for (int b = 0; b < B; ++b) {
+    MX_CHECK(cache->slots[b] >= 0 && cache->slots[b] < cache->n_slots && !seen[cache->slots[b]], "mmdit_forward_cached_mixed: slots must be distinct and inside [0, n_slots)");
+    seen[cache->slots[b]] = 1;
+    p.bc_valid[b] = cache->slot_valid[b] ? 1 : 0;
+    p.bc_all_valid = p.bc_all_valid && p.bc_valid[b]; p.bc_any_valid = p.bc_any_valid || p.bc_valid[b];
+  }
+  p.stream = (hipStream_t)stream;
+  p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = false;
+  p.bc = cache;
+  MX_CHECK(p.pcm_head_bytes() <= cache->state_bytes, "mmdit_forward_cached_mixed: state buffer too small");
+  const size_t ncm = p.pcm_ncmax();
+  char* hp = (char*)cache->state;
+  p.pcm_dpart = (double*)hp; hp += ncm * 64 * sizeof(double);
+  p.pcm_dimg = (mx::PcSample*)hp; hp += (size_t)p.pcm_slots * sizeof(mx::PcSample);
+  p.pcm_dctx = (mx::PcSample*)hp; hp += (size_t)p.pcm_slots * sizeof(mx::PcSample);
+  p.pcm_dchunks = (mx::PcRange*)hp; hp += ncm * sizeof(mx::PcRange);
+  p.pcm_dtmp = (mx::PcRange*)hp;
+  p.h_timesteps.resize(B);
+  if (hipMemcpyAsync(p.pcm_dimg, p.pcm_img.data(), (size_t)B * sizeof(mx::PcSample), hipMemcpyHostToDevice, p.stream) != hipSuccess ||
+      hipMemcpyAsync(p.pcm_dctx, p.pcm_ctx.data(), (size_t)B * sizeof(mx::PcSample), hipMemcpyHostToDevice, p.stream) != hipSuccess ||
+      hipMemcpyAsync(p.pcm_dchunks, p.pcm_chunks.data(), (size_t)p.pcm_nc * sizeof(mx::PcRange), hipMemcpyHostToDevice, p.stream) != hipSuccess ||
+      hipMemcpyAsync(p.h_timesteps.data(), timesteps, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, p.stream) != hipSuccess ||
+      hipStreamSynchronize(p.stream) != hipSuccess) {
+    mx::set_error("mmdit_forward_cached_mixed: moving the tables failed");
+    return 1;
+  }
+  const bool okr = p.run(groups[0].latents, io_dtype, timesteps, ehs, pooled, groups[0].out);
+  cache->blocks_run = (unsigned)(p.blocks_run & 0xffffffffull); cache->blocks_run_hi = (unsigned)(p.blocks_run >> 32);
+  cache->patches_asked = p.pcm_asked; cache->patches_total = p.pcm_total;
+  if (!okr) { mx::set_error(p.err); return 1; }
+  return 0;
 }
 
 /* ---- block-skip cache (include/mxdenoise.h; SD3Transformer.py:151-228 with cache_manager.py:163-191) ---- */

@@ -20,9 +20,9 @@
 
 namespace mx {
 
-__global__ __launch_bounds__(256) void pc_image_copy_kernel(bf16_t* __restrict__ batch, bf16_t* __restrict__ state, const PcSample* __restrict__ samp, int level,
+__global__ __launch_bounds__(256) void pc_image_copy_kernel(bf16_t* batch, bf16_t* __restrict__ state, const PcSample* __restrict__ samp, int level,
                                                             int C, long state_row_elems, int to_batch, const float* __restrict__ vec, int ldvec,
-                                                            const bf16_t* __restrict__ residual) {
+                                                            const bf16_t* residual, int gate) {
   const PcSample s = samp[blockIdx.y];
   const long n = ((long)(s.h >> level) * (s.w >> level) * C) >> 3;        // 16-byte vectors of the image
   bf16_t* pb = batch + (s.row0 >> (2 * level)) * C;
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void pc_image_copy_kernel(bf16_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float lo = bf16lo_to_f32(x[e]), hi = bf16hi_to_f32(x[e]);
-        if (pv) { lo += pv[c0 + 2 * e]; hi += pv[c0 + 2 * e + 1]; }
+        if (pv && gate) { lo *= pv[c0 + 2 * e]; hi *= pv[c0 + 2 * e + 1]; }       // AdaLN-Zero gate (transformer.py:344-345): residual + gate * state
+        else if (pv) { lo += pv[c0 + 2 * e]; hi += pv[c0 + 2 * e + 1]; }
         if (pr) { lo += bf16lo_to_f32(r[e]); hi += bf16hi_to_f32(r[e]); }
         x[e] = pack_bf16x2(lo, hi);
       }
@@ -122,12 +123,61 @@ __global__ __launch_bounds__(256) void pc_patch_sq_diff_kernel(const bf16_t* __r
   if (threadIdx.x == 0) partial[(long)blockIdx.y * p + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// rows [row0, row0 + rows) of a token-major batch tensor <-> rows [srow0, srow0 + rows) of a request's state row (MMDiT: the chunks are token ranges)
+__global__ __launch_bounds__(256) void pc_range_copy_kernel(bf16_t* __restrict__ batch, bf16_t* __restrict__ state, long state_row_elems, int C,
+                                                            const PcRange* __restrict__ ranges, int to_batch) {
+  const PcRange r = ranges[blockIdx.y];
+  const long n = ((long)r.rows * C) >> 3;
+  u32x4* pb = reinterpret_cast<u32x4*>(batch + r.row0 * C);
+  u32x4* ps = reinterpret_cast<u32x4*>(state + (long)r.slot * state_row_elems + (long)r.srow0 * C);
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long)gridDim.x * 256) {
+    if (to_batch) pb[v] = ps[v]; else ps[v] = pb[v];
+  }
+}
+__global__ __launch_bounds__(256) void pc_range_sq_diff_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ state, long state_row_elems, int C,
+                                                               const PcRange* __restrict__ ranges, double* __restrict__ partial) {
+  const PcRange r = ranges[blockIdx.y];
+  const long n = ((long)r.rows * C) >> 3;
+  const long per = (n + 63) / 64, v0 = (long)blockIdx.x * per, v1 = v0 + per < n ? v0 + per : n;
+  const u32x4* pa = reinterpret_cast<const u32x4*>(x + r.row0 * C);
+  const u32x4* pb = reinterpret_cast<const u32x4*>(state + (long)r.slot * state_row_elems + (long)r.srow0 * C);
+  float acc = 0.f;
+  for (long v = v0 + threadIdx.x; v < v1; v += 256) {
+    const u32x4 a = pa[v], b = pb[v];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d0 = bf16lo_to_f32(a[e]) - bf16lo_to_f32(b[e]), d1 = bf16hi_to_f32(a[e]) - bf16hi_to_f32(b[e]);
+      acc += d0 * d0 + d1 * d1;
+    }
+  }
+  __shared__ double red[4];
+  double d = (double)acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long)blockIdx.y * 64 + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+int launch_pc_range_copy(hipStream_t st, void* batch, void* state, long state_row_elems, int C, const void* ranges, int n, int to_batch, long max_range_elems) {
+  MX_CHECK(C % 8 == 0 && n > 0, "pc_range_copy: bad shape");
+  const int gx = (int)std::max<long>(1, std::min<long>((max_range_elems / 8 + 255) / 256, 128));
+  hipLaunchKernelGGL(pc_range_copy_kernel, dim3(gx, n), dim3(256), 0, st, (bf16_t*)batch, (bf16_t*)state, state_row_elems, C, (const PcRange*)ranges, to_batch);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_pc_range_sq_diff(hipStream_t st, const void* x, const void* state, long state_row_elems, int C, const void* ranges, int n, double* partial) {
+  MX_CHECK(C % 8 == 0 && n > 0, "pc_range_sq_diff: bad shape");
+  hipLaunchKernelGGL(pc_range_sq_diff_kernel, dim3(64, n), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)state, state_row_elems, C, (const PcRange*)ranges, partial);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_pc_image_copy(hipStream_t st, void* batch, void* state, const void* samp, int B, int level, int C, long state_row_elems, int to_batch,
-                         const float* vec, int ldvec, const void* residual, long max_image_elems) {
+                         const float* vec, int ldvec, const void* residual, long max_image_elems, int gate) {
   MX_CHECK(C % 8 == 0 && B > 0, "pc_image_copy: C must be a multiple of 8");
   const int gx = (int)std::max<long>(1, std::min<long>((max_image_elems / 8 + 255) / 256, 128));
   hipLaunchKernelGGL(pc_image_copy_kernel, dim3(gx, B), dim3(256), 0, st, (bf16_t*)batch, (bf16_t*)state, (const PcSample*)samp, level, C, state_row_elems,
-                     to_batch, vec, ldvec, (const bf16_t*)residual);
+                     to_batch, vec, ldvec, (const bf16_t*)residual, gate);
   MX_LAUNCH_CHECK();
   return 0;
 }

@@ -183,6 +183,9 @@ SYMBOLS = {
     "mx_unet_forward_pp_stale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "mx_unet_block_cache_bytes": (_sz, [_vp, _i, _i, _i]),
     "mx_unet_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "mx_mmdit_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
+    "mx_mmdit_workspace_bytes_cached_mixed": (_sz, [_vp, C.POINTER(UNetGroup), _i, _i, _i]),
+    "mx_mmdit_forward_cached_mixed": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "mx_unet_workspace_bytes_cached_mixed": (_sz, [_vp, C.POINTER(UNetGroup), _i, _i, _i]),
     "mx_unet_forward_cached_mixed": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "mx_unet_forward_cached": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

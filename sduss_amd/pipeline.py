@@ -90,8 +90,13 @@ class SDXLDenoiser:
         (one 512-1024 px request fills about a quarter of the CUs) leaves room for the other sequences to run beside it.
         The caller's stream waits for all of them; ``self.concurrent_resolutions = False`` serialises them."""
         res_list = [r for r in sorted(worker_reqs.keys(), key=lambda r: int(r)) if worker_reqs[r]]       # :275-276
-        if (1 < len(res_list) <= self.unet.max_mixed_groups and self.unet.mixed_one_sequence and getattr(self.unet, "_block_caches", None) is None):
-            self._step_mixed(res_list, worker_reqs, do_classifier_free_guidance, is_sliced, patch_size)
+        cached_patch_unit = (getattr(self.unet, "_block_caches", None) is not None and is_sliced and 1 <= len(res_list) <= self.unet.max_mixed_groups
+                             and all(int(r) % patch_size == 0 and int(r) > patch_size for r in res_list))
+        if cached_patch_unit or (1 < len(res_list) <= self.unet.max_mixed_groups and self.unet.mixed_one_sequence
+                                 and getattr(self.unet, "_block_caches", None) is None):
+            # ONE launch sequence for all resolutions -- also with ESYMRED_USE_CACHE=TRUE (round 4: the cache at its reference unit, the patch,
+            # decides once per block for the patches of every resolution: MxUNet.forward -> forward_mixed_cached)
+            self._step_mixed(res_list, worker_reqs, do_classifier_free_guidance, is_sliced, patch_size, cached=cached_patch_unit)
             return
         if len(res_list) <= 1 or not self.concurrent_resolutions:
             for res in res_list:
@@ -132,7 +137,7 @@ class SDXLDenoiser:
         return e, lat, sig, sig_next, ts
 
     def _step_mixed(self, res_list: List[str], worker_reqs: Dict[str, List[Request]], do_classifier_free_guidance: bool, is_sliced: bool,
-                    patch_size: int) -> None:
+                    patch_size: int, cached: bool = False) -> None:
         """All resolutions of the batch in ONE launch sequence (MxUNet.forward_mixed): the reference runs them as one patch batch
         (:369-380 with the dict of all resolutions; modules/unet.py:242-260).  Conditioning rows: ascending resolution, [uncond..., cond...]
         inside each (:275-276, 327-339)."""
@@ -154,8 +159,14 @@ class SDXLDenoiser:
                 self._mixed_cond.clear()
             hit = self._mixed_cond[key] = ([p[2] for p in parts], cat)
         ehs, pooled, tids = hit[1]
-        noise = self.unet.forward_mixed([p[7] for p in parts], torch.cat([p[6] for p in parts]), ehs, pooled, tids,
-                                        gn_patch=(patch_size // 8 if is_sliced else 0))
+        if cached:        # the model slot's own entry: the dict of all resolutions with the request ids the caches are keyed by (:369-380)
+            out = self.unet.forward({p[0]: p[7] for p in parts}, torch.cat([p[6] for p in parts]), ehs, added_cond_kwargs={"text_embeds": pooled, "time_ids": tids},
+                                    return_dict=False, is_sliced=True, patch_size=patch_size,
+                                    input_indices={p[0]: [str(r.request_id) for r in p[1]] for p in parts})[0]
+            noise = [out[p[0]] for p in parts]
+        else:
+            noise = self.unet.forward_mixed([p[7] for p in parts], torch.cat([p[6] for p in parts]), ehs, pooled, tids,
+                                            gn_patch=(patch_size // 8 if is_sliced else 0))
         g = self.guidance_scale if do_classifier_free_guidance else 0.0
         for (res, reqs, _e, lat, sig, sig_next, _ts, _x), nz in zip(parts, noise):
             ops.cfg_euler_step_(nz, lat, sig, sig_next, g)              # :382-397

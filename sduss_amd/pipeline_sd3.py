@@ -72,8 +72,10 @@ class SD3Denoiser:
         SDXLDenoiser.denoising_step)."""
         res_list = [r for r in sorted(runner_reqs.keys(), key=lambda r: int(r)) if runner_reqs[r]]           # :240-241
         tr = self.transformer
-        if 1 < len(res_list) <= tr.max_mixed_groups and tr.mixed_one_sequence and getattr(tr, "_block_caches", None) is None:
-            self._step_mixed(res_list, runner_reqs, do_classifier_free_guidance)
+        cached_chunk_unit = (getattr(tr, "_block_caches", None) is not None and is_sliced and 1 <= len(res_list) <= tr.max_mixed_groups
+                             and all(int(r) % patch_size == 0 and int(r) > patch_size for r in res_list))
+        if cached_chunk_unit or (1 < len(res_list) <= tr.max_mixed_groups and tr.mixed_one_sequence and getattr(tr, "_block_caches", None) is None):
+            self._step_mixed(res_list, runner_reqs, do_classifier_free_guidance, cached_patch_size=patch_size if cached_chunk_unit else None)
             return
         if len(res_list) <= 1 or not self.concurrent_resolutions:
             for res in res_list:
@@ -96,7 +98,8 @@ class SD3Denoiser:
             for r in runner_reqs[res]:
                 r.latents.record_stream(cur)
 
-    def _step_mixed(self, res_list: List[str], runner_reqs: Dict[str, List[SD3Request]], do_classifier_free_guidance: bool) -> None:
+    def _step_mixed(self, res_list: List[str], runner_reqs: Dict[str, List[SD3Request]], do_classifier_free_guidance: bool,
+                    cached_patch_size: Optional[int] = None) -> None:
         """All resolutions of the batch in ONE launch sequence (MxSD3Transformer.forward_mixed): the reference hands the transformer the dict
         of all resolutions (:312-322) and re-chunks their tokens into one batch (SD3Transformer.py:86).  Rows: ascending resolution,
         [uncond..., cond...] inside each (:240-241, 281-292)."""
@@ -127,7 +130,13 @@ class SD3Denoiser:
                 self._mixed_cond.clear()
             hit = self._mixed_cond[key] = ([p[1] for p in parts], tuple(torch.cat([p[1].cond[k] for p in parts], dim=0) for k in range(2)))
         ehs, pooled = hit[1]
-        noise = self.transformer.forward_mixed([p[6] for p in parts], torch.cat([p[5] for p in parts]), ehs, pooled)
+        if cached_patch_size is not None:     # ESYMRED_USE_CACHE=TRUE: the slot's own entry with the request ids (round 4: the chunk unit, one sequence)
+            out = self.transformer.forward({res: p[6] for res, p in zip(res_list, parts)}, encoder_hidden_states=ehs, pooled_projections=pooled,
+                                           timestep=torch.cat([p[5] for p in parts]), return_dict=False, is_sliced=True, patch_size=cached_patch_size,
+                                           input_indices={res: [str(r.request_id) for r in p[0]] for res, p in zip(res_list, parts)})[0]
+            noise = [out[res] for res in res_list]
+        else:
+            noise = self.transformer.forward_mixed([p[6] for p in parts], torch.cat([p[5] for p in parts]), ehs, pooled)
         g = self.guidance_scale if do_classifier_free_guidance else 0.0
         for (reqs, _e, lat, sig, sig_next, _ts, _x), nz in zip(parts, noise):
             ops.cfg_flow_step_(nz, lat, sig, sig_next, g)

@@ -152,6 +152,51 @@ class MxSD3Transformer:
                                                     pp.data_ptr(), lt, ws.data_ptr(), ws.numel()), "mx_mmdit_forward_mixed")
         return outs
 
+    def forward_mixed_cached(self, cache, latents, row_ids, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor, pooled: torch.Tensor, patch: int):
+        """forward_mixed through the block-skip cache at the reference's unit, the token chunk (block_cache.PatchSkipCache with mmdit_ctx_len;
+        mx_mmdit_forward_cached_mixed): ONE launch sequence, one host decision per joint block for the chunks of every resolution.  ``patch``: the
+        patch edge in latent pixels (patch_size / 8 of the reference's call)."""
+        assert 1 <= len(latents) <= _lib.MAX_SEGS and patch > 0
+        latents = [x.contiguous() for x in latents]
+        dt = latents[0].dtype
+        btot = sum(x.shape[0] for x in latents)
+        lt = encoder_hidden_states.shape[1]
+        ts = timestep.to(device=self.device, dtype=torch.float32).reshape(-1)
+        ts = (ts.expand(btot) if ts.numel() == 1 else ts).contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        pp = pooled.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        assert ts.shape[0] == btot and ehs.shape[0] == btot and pp.shape == (btot, self.cfg.pooled_projection_dim)
+        outs = [torch.empty((x.shape[0], self.cfg.out_channels, x.shape[2], x.shape[3]), dtype=dt, device=self.device) for x in latents]
+        groups = (_lib.UNetGroup * len(latents))()
+        for g, (x, o) in enumerate(zip(latents, outs)):
+            groups[g].latents, groups[g].out = x.data_ptr(), o.data_ptr()
+            groups[g].batch, groups[g].H, groups[g].W = x.shape[0], x.shape[2], x.shape[3]
+        shapes = tuple((x.shape[0], x.shape[2], x.shape[3]) for x in latents)
+        key = ("mixed_cached", shapes, lt, patch)
+        need = self._ws_need.get(key)
+        if need is None:
+            need = self._ws_need[key] = self._lib.mx_mmdit_workspace_bytes_cached_mixed(self._handle, groups, len(latents), lt, patch)
+        if need == 0:
+            raise _lib.MxError("mx_mmdit_workspace_bytes_cached_mixed: " + self._lib.mx_last_error().decode())
+        stream = _lib.current_stream()
+        skey = int(stream or 0)
+        ws = self._ws_by_stream.get(skey)
+        if ws is None or ws.numel() < need:
+            self._ws_by_stream[skey] = None
+            ws = self._ws_by_stream[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        assert cache.mmdit_ctx_len == lt
+        desc = cache.bind(self, shapes, row_ids, patch)
+        rc = self._lib.mx_mmdit_forward_cached_mixed(self._handle, stream, groups, len(latents), _lib.torch_dtype_code(dt), ts.data_ptr(), ehs.data_ptr(),
+                                                     pp.data_ptr(), lt, patch, ws.data_ptr(), ws.numel(), desc)
+        if rc:
+            err = cache.error
+            cache.invalidate()
+            if err is not None:
+                raise err
+        _lib.check(rc, "mx_mmdit_forward_cached_mixed")
+        cache.after_forward()
+        return outs
+
     def forward(self, hidden_states: Dict[str, torch.Tensor], encoder_hidden_states: torch.Tensor = None,
                 pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None, block_controlnet_hidden_states=None,
                 joint_attention_kwargs=None, return_dict: bool = True, skip_layers=None, patch_size: int = None,
@@ -162,6 +207,19 @@ class MxSD3Transformer:
         keys = [k for k in hidden_states if hidden_states[k] is not None and hidden_states[k].shape[0] > 0]
         if not is_sliced:
             keys = keys[:1]   # the reference's unsliced branch runs the first resolution only (SD3Transformer.py:105-109)
+        if is_sliced and getattr(self, "_block_caches", None) is not None and len(keys) <= _lib.MAX_SEGS and patch_size is not None \
+                and all(int(k) % patch_size == 0 and int(k) > patch_size for k in keys):
+            # ESYMRED_USE_CACHE=TRUE with is_sliced=True: the cache at its reference unit, the token chunk; every resolution in ONE launch sequence
+            ids = input_indices or {}
+            assert all(k in ids and len(ids[k]) > 0 and hidden_states[k].shape[0] % len(ids[k]) == 0 for k in keys), \
+                "the block-skip cache keys its state by input_indices[resolution] (cache_manager.py:166)"
+            row_ids = [r for k in keys for r in _row_ids(ids[k], hidden_states[k].shape[0])]
+            lt = encoder_hidden_states.shape[1]
+            if self._patch_cache is None or self._patch_cache.mmdit_ctx_len != lt:
+                self._patch_cache = self._new_patch_cache(lt)
+            res = self.forward_mixed_cached(self._patch_cache, [hidden_states[k] for k in keys], row_ids, timestep, encoder_hidden_states, pooled_projections,
+                                            patch_size // 8)
+            return (dict(zip(keys, res)),)
         if is_sliced and 1 < len(keys) <= _lib.MAX_SEGS and getattr(self, "_block_caches", None) is None and self.mixed_one_sequence:
             res = self.forward_mixed([hidden_states[k] for k in keys], timestep, encoder_hidden_states, pooled_projections)
             return (dict(zip(keys, res)),)
@@ -186,12 +244,16 @@ class MxSD3Transformer:
     def enable_block_cache(self, predictor, forced_after: Optional[int] = None, observe: bool = False) -> None:
         """Route forward() through the block-skip cache, one state per resolution key (SD3Transformer.py:151-228 with
         ESYMRED_USE_CACHE=TRUE).  `predictor`: an object with .predict(features) (block_cache.py)."""
-        from .block_cache import BlockSkipCache, FORCED_RUN_AFTER_SD3
+        from .block_cache import BlockSkipCache, FORCED_RUN_AFTER_SD3, PatchSkipCache
         fa = FORCED_RUN_AFTER_SD3 if forced_after is None else forced_after
         self._new_block_cache = lambda: BlockSkipCache(predictor, forced_after=fa, observe=observe)
+        ml = min(128, self.cfg.pos_embed_max_size * self.cfg.patch_size)                                    # state rows: up to 1024 px (or the positional table)
+        self._new_patch_cache = lambda lt: PatchSkipCache(predictor, forced_after=fa, mmdit_ctx_len=lt, max_latent=ml)   # is_sliced=True: the chunk unit
         self._block_caches = {}
+        self._patch_cache = None
 
     def disable_block_cache(self) -> None:
         self._block_caches = None
+        self._patch_cache = None
 
     __call__ = forward
