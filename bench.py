@@ -97,6 +97,7 @@ def parse():
     ap.add_argument("--pp", type=int, default=None, help="configs[3] leg: ONE 1024^2 request row-split over this many ranks (distrifuser-style patch parallelism, "
                                                          "stale-asynchronous mode after its warm-up); default = --gpus when --gpus > 1 (0 = skip); must divide --gpus")
     ap.add_argument("--pp-steps", type=int, default=10, help="timed stale steps of the --pp leg (after the 5 synchronous warm-up steps, which are timed too)")
+    ap.add_argument("--no-cached-mix", action="store_true", help="skip the mixed-stream leg with the block-skip cache on")
     ap.add_argument("--no-two-model", action="store_true", help="skip the configs[4] leg with SDXL and SD3.5 requests interleaved in one stream")
     a = ap.parse_args()
     if a.mix is None:
@@ -815,8 +816,38 @@ def main():
                                                      if any(int(r) == rr for r, _ in rows_all)}})
             if dist is not None:
                 dist.barrier()
+        # the same stream with the block-skip cache ON (ESYMRED_USE_CACHE=TRUE at its reference unit, the 256-px patch; one launch sequence per step,
+        # one host decision per block).  Random-init weights: a quantile rule asks a fixed half of the patches -- the mechanism's cost, not its quality
+        cached_leg = None
+        if args.model == "sdxl" and not args.no_cached_mix:
+            try:
+                from sduss_amd.block_cache import QuantilePredictor
+                net.enable_block_cache(QuantilePredictor(0.5))
+                rows, window = run_mix(den, cfg, args, device, shared, 1.0, args.mix, rank, world, args.model, "continuous")
+                pc = net._patch_cache
+                frac = (pc.patches_asked / pc.patches_total) if pc is not None and pc.patches_total else None
+                skipped = (sum(bin(h ^ 0x7f).count("1") for h in pc.history) / (7.0 * len(pc.history))) if pc is not None and pc.history else None
+                net.disable_block_cache()
+                torch.cuda.empty_cache()
+                rows_all, window = dp.gather_stream_stats(rows, window, dist)
+                if rank == 0:
+                    lat = [l for _r, l in rows_all]
+                    ok = sum(1 for r, l in rows_all if l <= REF_DEADLINES_S[args.model][int(r)])
+                    span = window[1] - window[0]
+                    cached_leg = {"offered_req_per_s_per_gpu": 1.0, "policy": "continuous", "requests": len(rows_all), "slo_rate": ok / len(rows_all),
+                                  "p50_latency_s": float(np.percentile(lat, 50)), "p90_latency_s": float(np.percentile(lat, 90)),
+                                  "goodput_req_per_s": ok / span, "throughput_req_per_s": len(rows_all) / span,
+                                  "patch_blocks_asked_frac_rank0": frac, "blocks_skipped_frac_rank0": skipped,
+                                  "predictor": "QuantilePredictor(0.5): asks the half of the cached patches whose inputs moved most (random-init weights: timing "
+                                               "of the mechanism, approximate outputs by design; the exact path never consults the cache)"}
+            except Exception as e:                               # never fatal for the headline line
+                net.disable_block_cache()
+                if rank == 0:
+                    cached_leg = {"error": f"{type(e).__name__}: {e}"}
+            if dist is not None:
+                dist.barrier()
         if rank == 0:
-            result["mixed_stream"] = {"legs": legs, "trace": "synthetic, shape of exp/<model>/qps_*.csv: resolutions uniform over 512/768/1024, steps 30-50 by the "
+            result["mixed_stream"] = {"legs": legs, **({"block_cache_on": cached_leg} if cached_leg is not None else {}), "trace": "synthetic, shape of exp/<model>/qps_*.csv: resolutions uniform over 512/768/1024, steps 30-50 by the "
                                                               "traces' histogram, exponential arrivals seed 10086", "deadlines_s": REF_DEADLINES_S[args.model],
                                       "max_batch": args.mix_max_batch, "is_sliced": True, "patch_size": 256,
                                       "policies": {"fcfs_mixed": "the reference worker scheduler's FCFS_Mixed decisions, cycle by cycle (policy/FCFS_Mixed.py:25-76; mirror "

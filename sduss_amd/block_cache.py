@@ -38,6 +38,25 @@ class ThresholdPredictor:
         return (features[:, 2:].max(axis=1) > self.threshold).astype(np.int64)
 
 
+class QuantilePredictor:
+    """run the rows whose largest input difference lies above the ``q`` quantile of the call's cached rows (uncached rows run): a fixed asking
+    fraction of about 1 - q whatever the scale of the differences -- for timing the mechanism on random-init weights, where no fitted threshold
+    means anything (bench.py's cached mixed-stream leg, tools/block_cache_bench.py)."""
+
+    def __init__(self, q: float):
+        self.q = float(q)
+
+    def predict(self, features: np.ndarray) -> np.ndarray:
+        f = np.asarray(features, dtype=np.float64)
+        m = f[:, 2:].max(axis=1)
+        unc = m >= MSE_UNCACHED * 0.5
+        out = np.ones(len(f), dtype=np.int64)
+        if (~unc).any():
+            thr = np.quantile(m[~unc], self.q)
+            out[~unc] = (m[~unc] > thr).astype(np.int64)
+        return out
+
+
 class CompiledForest:
     """A fitted scikit-learn RandomForestClassifier (binary) flattened for mx_forest_predict: same answers as ``forest.predict`` without
     its per-call overhead (0.4 ms per call through joblib / validation -- 24 calls per SD3 step cost more than the blocks they save)."""

@@ -17,6 +17,7 @@ int launch_pc_gather(hipStream_t st, const void* src, int ld_src, int C, void* d
                      int halo_hi, int up);
 int launch_pc_scatter(hipStream_t st, const void* src, int Ps, int o0, int C, void* state, long state_row_elems, const void* list, int n, const void* samp,
                       int level, int p);
+int launch_pc_patch_store(hipStream_t st, const void* batch, void* state, long state_row_elems, int C, const void* list, int n, const void* samp, int level, int p);
 int launch_pc_patch_sq_diff(hipStream_t st, const void* x, const void* state, long state_row_elems, int C, const void* list, int n, const void* samp, int level,
                             int p, double* partial);
 }  // namespace mx

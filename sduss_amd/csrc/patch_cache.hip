@@ -94,6 +94,20 @@ __global__ __launch_bounds__(256) void pc_scatter_kernel(const bf16_t* __restric
   for (int i = threadIdx.x; i < n; i += 256) reinterpret_cast<u32x4*>(out)[i] = reinterpret_cast<const u32x4*>(in)[i];
 }
 
+// the listed patches of a whole-image batch tensor -> their places in the requests' state rows (a conv that was cheaper to run on the whole
+// images than on the compact halo'd patches still renews the asking patches only)
+__global__ __launch_bounds__(256) void pc_patch_store_kernel(const bf16_t* __restrict__ batch, bf16_t* __restrict__ state, long state_row_elems, int C,
+                                                             const PcPatch* __restrict__ list, const PcSample* __restrict__ samp, int level, int p) {
+  const PcPatch q = list[blockIdx.y];
+  const PcSample s = samp[q.b];
+  const int w = s.w >> level;
+  const long off = ((long)(q.py * p + blockIdx.x) * w + q.px * p) * C;
+  const u32x4* in = reinterpret_cast<const u32x4*>(batch + (s.row0 >> (2 * level)) * C + off);
+  u32x4* out = reinterpret_cast<u32x4*>(state + (long)s.slot * state_row_elems + off);
+  const int n = p * (C >> 3);
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = in[i];
+}
+
 // partial[patch][row] = sum over the patch's pixel row of (x - cached)^2; the host adds the p partials of a patch
 __global__ __launch_bounds__(256) void pc_patch_sq_diff_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ state, long state_row_elems, int C,
                                                                const PcPatch* __restrict__ list, const PcSample* __restrict__ samp, int level, int p,
@@ -193,6 +207,13 @@ int launch_pc_scatter(hipStream_t st, const void* src, int Ps, int o0, int C, vo
                       int level, int p) {
   MX_CHECK(C % 8 == 0 && n > 0 && p > 0 && o0 >= 0 && o0 + p <= Ps, "pc_scatter: bad shape");
   hipLaunchKernelGGL(pc_scatter_kernel, dim3(p, n), dim3(256), 0, st, (const bf16_t*)src, Ps, o0, C, (bf16_t*)state, state_row_elems, (const PcPatch*)list,
+                     (const PcSample*)samp, level, p);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_pc_patch_store(hipStream_t st, const void* batch, void* state, long state_row_elems, int C, const void* list, int n, const void* samp, int level, int p) {
+  MX_CHECK(C % 8 == 0 && n > 0 && p > 0, "pc_patch_store: bad shape");
+  hipLaunchKernelGGL(pc_patch_store_kernel, dim3(p, n), dim3(256), 0, st, (const bf16_t*)batch, (bf16_t*)state, state_row_elems, C, (const PcPatch*)list,
                      (const PcSample*)samp, level, p);
   MX_LAUNCH_CHECK();
   return 0;

@@ -97,6 +97,64 @@ def main_sd3():
         torch.cuda.empty_cache()
 
 
+class Fraction:
+    """ask a fixed fraction of the patches of every block, the same ones every step: the first round(f * n) rows of the call (so whole samples
+    drop out first, the way a predictor with per-request thresholds behaves), or, spread=True, every k-th patch (every sample keeps some asking
+    patches: what costs the per-sample attention problems their batching)"""
+    def __init__(self, f, spread=False):
+        self.f, self.spread = f, spread
+
+    def predict(self, feats):
+        feats = np.asarray(feats)
+        n = len(feats)
+        out = np.zeros(n, dtype=np.int64)
+        k = int(round(self.f * n))
+        if self.spread and k > 0:
+            out[np.unique(np.linspace(0, n - 1, k).round().astype(int))] = 1
+        else:
+            out[:k] = 1
+        out[feats[:, 2] > 1e18] = 1
+        return out
+
+
+def main_patch_unit():
+    """The cache at the reference's unit (mx_unet_forward_cached_mixed, is_sliced=True / patch 256): step time against the fraction of patches that
+    ask, SDXL-base.  `exact` = mx_unet_forward_mixed of the same batch (sliced, no cache, graph replay).  Every block runs with the given asking
+    fraction: the convolutions, attn1's core + to_out and the whole attn2 scale with it; GroupNorm, LayerNorms, q|k|v, the feed-forward and the
+    state copies do not (as in the reference)."""
+    from sduss_amd.block_cache import PatchSkipCache
+    dev = torch.device("cuda:0")
+    cfg = UNetConfig.sdxl_base()
+    net = MxUNet(cfg, synthetic_params(cfg, device=dev), device=dev)
+    print("patch-unit cache (is_sliced=True, patch 256 px): ms per forward against the asking fraction")
+    print(f"{'batch':>14s} {'exact':>8s} " + " ".join(f"{'f=' + str(f):>8s}" for f in (1.0, 0.75, 0.5, 0.25, 0.125, 0.0)) + "   (f = 0.5 spread over all samples)   state MiB")
+    for comp in (((2, 1024),), ((8, 1024),), ((2, 512), (2, 768), (2, 1024))):
+        g = torch.Generator(device=dev).manual_seed(3)
+        xs = [torch.randn(b, 4, px // 8, px // 8, device=dev, generator=g).to(torch.bfloat16) for b, px in comp]
+        btot = sum(b for b, _ in comp)
+        t = torch.full((btot,), 801.0, device=dev)
+        e = torch.randn(btot, 77, cfg.cross_attention_dim, device=dev, generator=g).to(torch.bfloat16)
+        te = torch.randn(btot, cfg.text_embed_dim, device=dev, generator=g).to(torch.bfloat16)
+        ti = torch.cat([torch.tensor([[px, px, 0, 0, px, px]], device=dev, dtype=torch.float32).repeat(b, 1) for b, px in comp])
+        ids = [f"r{i}" for i in range(btot)]
+        row = [timed(lambda: net.forward_mixed(xs, t, e, te, ti, gn_patch=32))]
+        for f, spread in ((1.0, False), (0.75, False), (0.5, False), (0.25, False), (0.125, False), (0.0, False), (0.5, True)):
+            pred = Fraction(1.0)
+            pc = PatchSkipCache(pred, forced_after=1 << 30)
+            net.forward_mixed_cached(pc, xs, ids, t, e, te, ti, gn_patch=32)
+            pred.f, pred.spread = f, spread
+            row.append(timed(lambda: net.forward_mixed_cached(pc, xs, ids, t, e, te, ti, gn_patch=32), n=6))
+            state = pc.state.numel() / 2 ** 20
+            del pc
+            torch.cuda.empty_cache()
+        name = "+".join(f"{b}x{px}" for b, px in comp)
+        print(f"{name:>14s} " + " ".join(f"{v:8.2f}" for v in row[:7]) + f"   {row[7]:8.2f}   {state:8.0f}", flush=True)
+
+
 if __name__ == "__main__":
-    main()
-    main_sd3()
+    if len(sys.argv) > 1 and sys.argv[1] == "patch":
+        main_patch_unit()
+    else:
+        main()
+        main_sd3()
+        main_patch_unit()
