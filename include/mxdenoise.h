@@ -101,6 +101,9 @@ enum {
  * per-batch structure and operand bases.  Output tiles never straddle two problems (a workgroup finds its problem from its tile index with
  * two compares and then runs the ordinary kernel body on it), nothing is padded in memory, and every output element sees exactly the
  * arithmetic of a separate launch with the same tile shape.  Pointer fields that the descriptor leaves NULL must be NULL here too. */
+/* At most MX_MAX_SEGS resolutions share one launch sequence (the reference serves 512 / 768 / 1024 px).  A batch with MORE distinct resolutions is
+ * not an error: the host mirrors (MxUNet.forward / SDXLDenoiser.denoising_step and the SD3 ones) then fall back to one launch sequence per
+ * resolution on concurrent streams -- same results, the mixed-batch speed-up is lost. */
 #define MX_MAX_SEGS 4
 typedef struct mx_gemm_seg {
   const void* a;          /* this problem's A rows (conv: its first image) */
@@ -184,6 +187,9 @@ typedef struct mx_gemm_desc {
    * descriptor's own a / c / residual / vt / rowbias / gate / ln_stats / stats_out only say WHICH operands exist (non-NULL), M is ignored. */
   const mx_gemm_seg* segs;
   int n_segs;
+  /* split-K (see mx_gemm_splitk): 0 = the library decides from the shape (a split is taken where its estimate beats the unsplit launch by 10 %),
+   * 1 = never, 2..4 = that many slices wherever the launch is eligible at all (a 128-row tiling, >= 8 K tiles per slice, no split A operand) */
+  int splitk;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -198,6 +204,11 @@ int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d);
  * (buffer of M * MX_STATS_PITCH(1) * 2 floats) */
 int mx_row_stats(void* stream, const void* x, int ldx, float* stats, int M, int C);
 int mx_conv3x3(void* stream, const mx_gemm_desc* d);   /* implicit GEMM, pad 1 */
+/* Slices the K range of d is dealt to (1 = no split).  Small launches -- fewer 128-row tiles than CUs and >= 16 K tiles: one request, light mixed
+ * batches -- run SPLIT-K: every output tile is computed by up to 4 workgroups over disjoint K ranges; each leaves its fp32 partial tile in a
+ * library-owned scratch (96 MB + counters per stream, allocated at a stream's first split launch, never during a capture) and takes a ticket;
+ * the last arriver adds the partials IN SLICE ORDER (bit-stable run to run) and runs the ordinary epilogue.  Shape-based and host-only. */
+int mx_gemm_splitk(const mx_gemm_desc* d, int conv);
 
 /* V^T key order.  The attention kernel feeds its softmax accumulator straight back to the matrix core as the
  * P operand, and that register layout interleaves keys in blocks of four (lane half h owns keys 4h..4h+3 and

@@ -49,6 +49,11 @@ struct GemmArgs {
   int ln_slabs;
   float ln_eps;
   float* stats_out;        // row statistics of the stored values, one slab per wave column panel; nullptr = off
+  // split-K (128-row tiles, small launches: gemm_bf16_v2.hip): the K tiles of an output tile are dealt to `splitk` workgroups; each leaves its
+  // fp32 partial tile in sk_ws and takes a ticket from sk_cnt[tile]; the last one sums the partials in slice order and runs the epilogue
+  int splitk;
+  float* sk_ws;
+  unsigned* sk_cnt;
   // grouped launch (mx_gemm_desc.segs): nseg problems along M, prob[i].tile0 = first m-tile of problem i, mt_total = all m-tiles; nseg == 0: M above
   int nseg, mt_total;
   GemmSeg prob[kMaxSegs];
@@ -155,6 +160,54 @@ __device__ __forceinline__ void gemm_ln_row(const GemmArgs& p, const int m, cons
   const float var = fmaxf(s2 * inv - mean * mean, 0.f);
   rstd = rsqrtf(var + p.ln_eps);
   rm = rstd * mean;
+}
+
+// ---- split-K hand-off (cdna guide, "Projection GEMM at M = 256" item 2 and Guideline 16): partial tiles travel through memory as write-through
+// (sc1) 16-byte stores and are read back with sc1 loads, so neither a release fence (an L2 write-back) nor an acquire is needed; the counter is an
+// agent-scope atomic. ----
+// Both directions go through buffer instructions with aux = 16 (sc1) -- __builtin_amdgcn_raw_buffer_store_b128 / _load_b128: the compiler
+// counts and waits for them itself.  (Two hand-written forms failed first: an inline-asm global_store_dwordx4 whose data registers the compiler
+// overwrote before the store had read them -- guide section 5.7 item 1, stores -- and inline-asm loads whose destinations were copied before
+// any hand-placed s_waitcnt.)
+typedef unsigned int u32x4_sk __attribute__((ext_vector_type(4)));
+// After the K loop of a split launch.  Returns true in the workgroup that must run the epilogue (acc then holds the sum over all slices, added in
+// slice order whichever workgroup arrives last: the result does not depend on timing).  `ticket_word`: one LDS word nobody else uses any more.
+template <int NI, int MI>
+__device__ __forceinline__ bool splitk_combine(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int tile, const int slice, const int tile_elems,
+                                               volatile int* ticket_word) {
+  const int tid = threadIdx.x;
+  // one descriptor over this TILE's slabs (wave-uniform base: tile comes from blockIdx); per-lane byte offsets in voffset
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(p.sk_ws + (long)tile * p.splitk * tile_elems, 0, p.splitk * tile_elems * 4, 0x00020000);
+  const int lane_off = tid * 16;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_sk, acc[i][j]), rsrc, (slice * tile_elems + (i * MI + j) * 2048) * 4 + lane_off, 0, 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores (and its past-the-end DMAs) ...
+  __syncthreads();                                       // ... before ONE lane signals for the workgroup
+  if (tid == 0) *ticket_word = (int)__hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int ticket = *ticket_word;
+  if (ticket != p.splitk - 1) return false;
+  if (tid == 0) __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the counter is zero again for the next launch
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.splitk; ++s) {                  // a whole partial tile in flight at a time (NI * MI 16-byte pieces per lane)
+    f32x4 v[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+        v[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (s * tile_elems + (i * MI + j) * 2048) * 4 + lane_off, 0, 16));
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] += v[i][j];
+  }
+  return true;
 }
 
 // row of the A operand / of the output for logical row m (joint-sequence remap, see mxdenoise.h)

@@ -22,6 +22,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 #include "../../include/mxdenoise.h"
 #include "gemm_args.h"
@@ -194,7 +197,7 @@ int launch_v4(hipStream_t s, const GemmArgs& a);
 // problem therefore prefers small tiles (more CUs fetch in parallel: one 1024 px request gives M = 2048), a chip-filling one
 // the tiling with the fewest rounds and the largest tile (fewest bytes per FLOP; the 256x256 kernel is further discounted by
 // its measured advantage).  rows == 0: use the generic 128-row kernel.
-struct TileChoice { int bn; int rows; };
+struct TileChoice { int bn; int rows; int splitk = 1; };
 // m-tiles of the launch for tiles of `rows` rows: the problems of a grouped launch are tiled one by one (no tile straddles two of them)
 static long m_tiles_of(const mx_gemm_desc* d, int rows) {
   if (d->n_segs <= 0) return cdiv(d->M, rows);
@@ -251,7 +254,69 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
     const double cost = (double)((tiles + ncu - 1) / ncu) * (rows + bn) * (bn == 256 ? v3_discount : 1.0);
     if (best.rows == 0 || cost < best_cost) { best = cands[c]; best_cost = cost; }
   }
+  // Small launches (the 128-row tiles: one request, light mixed batches) leave CUs idle and run a long serial K loop whose iteration cannot be
+  // shorter than the CU's LDS-DMA issue allows (0.55-0.8 us per 128 x 128 x 64 tile whatever the ring depth).  SPLIT-K deals the K tiles of an
+  // output tile to `splitk` workgroups (gemm_bf16_v2.hip, splitk_combine).  What it costs was measured (round 4, tools/exp/splitk_bench.py,
+  // profiles/r04_g_splitk_bench.txt): the fp32 partial tiles travel through memory -- slices x M x N x 4 bytes written through and read back
+  // -- so M 2048, N 1280 in two slices moves 42 MB and the combine takes ~10 us: K 1280 got SLOWER (16.4 -> 21.2 us), K 5120 5 % faster
+  // (43.3 -> 41.0), M 512 5 % faster.  The estimate below therefore charges that traffic at 4 TB/s and a split is taken only where it still
+  // wins by 10 %: long K at small M x N.
+  if (d->splitk != 1 && best.rows == 128 && !d->a2 && d->K / 64 >= 16) {
+    const int ncu = cu_count();
+    const int nk = d->K / 64;
+    double best_t = 0, unsplit_t = 0;
+    TileChoice pick = best;
+    const double mtot = (double)Mtot;
+    for (int c = 3; c < 5; ++c) {
+      const int bn = cands[c].bn;
+      if (d->N % bn != 0 || (geglu && bn == 160) || (qkv && (d->seg % 64 != 0 || d->seg % (bn / 2) != 0)) || ((d->flags & MX_EPI_RMSNORM) && bn == 160)) continue;
+      const long tiles = m_tiles_of(d, 128) * (d->N / bn);
+      for (int sk = 1; sk <= 4; ++sk) {
+        if (d->splitk > 1 && sk != 1 && sk != d->splitk) continue;            // a forced slice count (tests, A/B)
+        if (nk / sk < 8 || (sk > 1 && tiles * sk > 2L * ncu)) continue;
+        if (sk > 1 && tiles * sk * 128L * bn * 4 > (96L << 20)) continue;          // the partial tiles must fit the library's scratch
+        const double combine = sk > 1 ? 2.0 + (double)sk * mtot * d->N * 8.0 / 4.0e6 : 0.0;      // us: partial tiles out and back at ~4 TB/s
+        const double t = (double)((tiles * sk + ncu - 1) / ncu) * ((double)(nk / sk) * 0.57 * (128 + bn) / 256.0 + 5.0) + combine;
+        if (sk == 1 && bn == best.bn) unsplit_t = t;
+        if (best_t == 0 || t < best_t - 1e-9) { best_t = t; pick = TileChoice{bn, 128, sk}; }
+      }
+    }
+    if (pick.splitk > 1 && unsplit_t > 0 && best_t <= 0.9 * unsplit_t) best = pick;
+    if (d->splitk > 1) {                       // forced: the cheapest eligible tiling with that many slices
+      double ft = 0;
+      for (int c = 3; c < 5; ++c) {
+        const int bn = cands[c].bn, sk = d->splitk;
+        if (d->N % bn != 0 || (geglu && bn == 160) || (qkv && (d->seg % 64 != 0 || d->seg % (bn / 2) != 0)) || ((d->flags & MX_EPI_RMSNORM) && bn == 160)) continue;
+        const long tiles = m_tiles_of(d, 128) * (d->N / bn);
+        if (sk > 4 || nk / sk < 8 || tiles * sk * 128L * bn * 4 > (96L << 20)) continue;
+        const double t = (double)((tiles * sk + ncu - 1) / ncu) * ((double)(nk / sk) * 0.57 * (128 + bn) / 256.0 + 5.0);
+        if (ft == 0 || t < ft) { ft = t; best = TileChoice{bn, 128, sk}; }
+      }
+    }
+  }
   return best;
+}
+
+// scratch of the split-K launches: fp32 partial tiles and one arrival counter per output tile, per stream (launches of one stream are ordered;
+// concurrent streams -- the per-resolution sequences of a mixed batch -- must not share them).  Allocated at the first split launch of a stream;
+// never while that stream is being captured (the launch then runs unsplit on the same tiles).
+struct SplitKScratch { float* ws = nullptr; unsigned* cnt = nullptr; };
+static bool splitk_scratch(hipStream_t s, SplitKScratch& out) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, SplitKScratch> per_stream;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = per_stream.find(s);
+  if (it != per_stream.end()) { out = it->second; return out.ws != nullptr; }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+  SplitKScratch b;
+  if (hipMalloc(&b.ws, 96u << 20) != hipSuccess || hipMalloc(&b.cnt, 64u << 10) != hipSuccess || hipMemset(b.cnt, 0, 64u << 10) != hipSuccess) {
+    (void)hipGetLastError();
+    b = SplitKScratch{};
+  }
+  per_stream[s] = b;
+  out = b;
+  return b.ws != nullptr;
 }
 
 // slabs of row statistics the launch of d writes: one per wave column panel of the register-exchange epilogue (gemm_epilogue_regs);
@@ -261,6 +326,7 @@ static int stats_slabs_of(const mx_gemm_desc* d, bool conv, const TileChoice& tc
                                                         //  to a 256 / 128-row tile, see pick_tile)
   if (d->flags & (MX_EPI_GEGLU | MX_EPI_QKV | MX_EPI_OUT_F32)) return 0;
   if (d->a_batch_rows > 0 || d->c_batch_rows > 0) return 0;
+  for (int i = 0; i < d->n_segs; ++i) if (d->segs[i].a_batch_rows > 0 || d->segs[i].c_batch_rows > 0) return 0;
   const int panel = tc.bn / 2;                          // 4 x 2 waves of (16 MI) x (BN / 2)
   return d->N / panel;
 }
@@ -283,6 +349,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
       MX_CHECK(g.rows_per_batch > 0, "gemm: grouped launch: rows_per_batch required");
     if (g.a_batch_rows > 0) MX_CHECK(!conv && g.a_row_off >= 0 && g.a_row_off + g.rows_per_batch <= g.a_batch_rows, "gemm: grouped launch: bad input row remap");
     if (g.c_batch_rows > 0) MX_CHECK(g.c_row_off >= 0 && g.c_row_off + g.rows_per_batch <= g.c_batch_rows, "gemm: grouped launch: bad output row remap");
+    if (d->ln_stats || d->stats_out)           // (advisor, round 3: the per-problem remaps were not covered by the descriptor-level check)
+      MX_CHECK(g.a_batch_rows <= 0 && g.c_batch_rows <= 0, "gemm: grouped launch: the folded LayerNorm / stats_out exclude a problem's row remaps");
     if (d->flags & MX_EPI_QKV)
       MX_CHECK(g.M % g.rows_per_batch == 0 && g.ldvt >= MX_VT_LD(g.c_batch_rows > 0 ? g.c_batch_rows : g.rows_per_batch) && g.ldvt % 8 == 0,
                "gemm: grouped launch: QKV needs whole batches and ldvt >= MX_VT_LD(keys per batch)");
@@ -358,6 +426,11 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   if (d->residual) MX_CHECK(d->ldr >= d->N && d->ldr % 4 == 0, "gemm: bad ldr");
   const bool use128 = (d->N % 128 == 0);
   const TileChoice tc = pick_tile(d, conv);
+  a.splitk = 0; a.sk_ws = nullptr; a.sk_cnt = nullptr;
+  if (tc.splitk > 1) {
+    SplitKScratch sk;
+    if (splitk_scratch((hipStream_t)stream, sk) && m_tiles_of(d, 128) * (d->N / tc.bn) * 4 <= (64L << 10)) { a.splitk = tc.splitk; a.sk_ws = sk.ws; a.sk_cnt = sk.cnt; }
+  }
   const int v2bn = tc.bn;
   if (d->stats_out) {
     MX_CHECK(stats_slabs_of(d, conv, tc) > 0, "gemm: stats_out is not supported for this shape / epilogue (see mx_gemm_stats_slabs)");
@@ -456,3 +529,7 @@ extern "C" int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d) {
   return mx::pick_tile(&plain, false).bn == 256;
 }
 extern "C" int mx_conv3x3(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, true); }
+extern "C" int mx_gemm_splitk(const mx_gemm_desc* d, int conv) {
+  if (!d || mx::rows_of(d) <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  return mx::pick_tile(d, conv != 0).splitk;
+}

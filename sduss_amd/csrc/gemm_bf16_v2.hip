@@ -68,9 +68,15 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
   // this workgroup's output tile; in a grouped launch (gemm_args.h) also its problem: p is that problem from here on
   GemmArgs p = pk;
   int tm, tn;
-  gemm_tile_of_block(blockIdx.x, gemm_m_tiles(pk, BM2), pk.N / BN, pk.xcd_map, tm, tn);
+  // split-K: workgroups [s * tiles, (s + 1) * tiles) are slice s of every tile (tiles % 8 == 0 keeps a tile's slices on one XCD: speed only)
+  const int n_tiles = gemm_m_tiles(pk, BM2) * (pk.N / BN);
+  const int slice = pk.splitk > 1 ? (int)blockIdx.x / n_tiles : 0;
+  const int tile_id = (int)blockIdx.x - slice * n_tiles;
+  gemm_tile_of_block(tile_id, gemm_m_tiles(pk, BM2), pk.N / BN, pk.xcd_map, tm, tn);
   gemm_select_seg(p, pk, tm);
-  const int nk = p.K / BK2;
+  const int nk_all = p.K / BK2;
+  const int k_first = pk.splitk > 1 ? (int)((long)nk_all * slice / pk.splitk) : 0;
+  const int nk = pk.splitk > 1 ? (int)((long)nk_all * (slice + 1) / pk.splitk) - k_first : nk_all;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   const int cs = tid & 7;
   const int tiles_per_tap = CONV ? p.Cin / BK2 : 1;
@@ -136,15 +142,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
         }
       }
     }
-    if constexpr (CONV) conv_set_tap(0);
+    // (split-K: this workgroup's K range starts at K tile k_first -- tap k_first / tiles_per_tap, channel tile k_first % tiles_per_tap)
+    tap_next = CONV ? k_first / tiles_per_tap : 0; in_tap = CONV ? k_first - tap_next * tiles_per_tap : 0;
+    if constexpr (CONV) conv_set_tap(tap_next, in_tap * BK2 * 2);
+    else {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) xsrc[i] += (long)k_first * BK2 * 2;
+    }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       int q = i * 512 + tid;
       if (q >= WCH) q -= WCH;                 // BN=160: the last instruction re-fetches rows 0..31 (same bytes, same slot)
       const int row = q >> 3;
-      wsrc[i] = reinterpret_cast<const char*>(p.w) + ((long)(n0 + row) * p.K + swz2(row, cs) * 8) * 2;
+      wsrc[i] = reinterpret_cast<const char*>(p.w) + ((long)(n0 + row) * p.K + (long)k_first * BK2 + swz2(row, cs) * 8) * 2;
     }
-    tap_next = 0; in_tap = 0;
   };
   auto park_on_zero_page = [&]() __attribute__((always_inline)) {            // past the end of the stream: same instruction count, harmless bytes
 #pragma unroll
@@ -229,7 +240,15 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) ln_rstd[j] = 1.0f;
     if constexpr (!CONV) {
-      if (p.ln_stats != nullptr) gemm_ln_init<NI, MI>(p, acc, tm * BM2 + wm * 16 * MI, tn * BN + wn * (BN / 2), fr, fq, ln_rstd);
+      if (p.ln_stats != nullptr) {
+        gemm_ln_init<NI, MI>(p, acc, tm * BM2 + wm * 16 * MI, tn * BN + wn * (BN / 2), fr, fq, ln_rstd);
+        if (slice != 0) {                      // split-K: the -mean * colsum term enters the sum once, through slice 0
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
     }
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -273,6 +292,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
     }
 
     const int m0 = tm * BM2, n0 = tn * BN;
+    if (pk.splitk > 1) {                       // only the last-arriving slice of the tile goes on, with the sum of all slices
+      if (!splitk_combine<NI, MI>(pk, acc, tile_id, slice, BM2 * BN, reinterpret_cast<volatile int*>(smem))) return;
+    }
     // register-exchange epilogue (gemm_args.h): no LDS, no barrier; the past-the-end DMAs are drained before the workgroup retires
     static_assert(!GEGLU || (NI % 4 == 0 && !CONV), "the gated epilogue pairs whole 32-feature halves");
     gemm_epilogue_regs<NI, MI, GEGLU, true, true, true, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
@@ -284,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(const GemmArgs pk) {
 // ping-pong schedule of gemm_bf16_v5.hip (the lock-step 256-row instantiation it replaced: git history, A/B in profiles/r03_*gemm_bench*).
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows) {
   (void)rows;
-  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, 128)) * (a.N / bn);
+  const int tiles = (a.nseg > 0 ? a.mt_total : cdiv(a.M, 128)) * (a.N / bn) * (a.splitk > 1 ? a.splitk : 1);
   dim3 grid(tiles), block(512);
 #define MX_V2(BN_, CONV_, FEAT_, GEGLU_) hipLaunchKernelGGL((gemm_v2_kernel<BN_, 2, CONV_, FEAT_, GEGLU_>), grid, block, 0, s, a)
   const int feat = gemm_epi_features(a.flags);

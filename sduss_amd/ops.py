@@ -23,7 +23,7 @@ def _bf16(t):
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, silu: bool = False, geglu: bool = False,
          out_f32: bool = False, out_scale: float = 0.0, ln_stats: Optional[torch.Tensor] = None, ln_colsum: Optional[torch.Tensor] = None,
-         ln_eps: float = 1e-5, want_stats: bool = False):
+         ln_eps: float = 1e-5, want_stats: bool = False, splitk: int = 0):
     """C[M,N] = (A[M,K] W[N,K]^T + bias) * out_scale (+rowbias +residual, silu | geglu).  With ``geglu`` the weight/bias rows must be
     interleaved as weights._geglu_interleave does; the output is [M, N/2].
     ``ln_stats`` = (stats [M, pitch, 2], slabs) + ``ln_colsum`` [N]: LayerNorm folded into this GEMM (w, bias folded by
@@ -43,6 +43,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     d.ldr = residual.shape[1] if residual is not None else 0
     d.ldrb = rowbias.shape[1] if rowbias is not None else 0
     d.rows_per_batch, d.flags, d.out_scale = rows_per_batch, flags, out_scale
+    d.splitk = splitk                           # 0 auto, 1 never, 2..4 forced (mx_gemm_desc.splitk)
     if ln_stats is not None:
         st_, slabs_ = ln_stats
         assert st_.dtype == torch.float32 and ln_colsum.dtype == torch.float32 and st_.shape == (m, stats_pitch(slabs_), 2)
@@ -126,7 +127,7 @@ def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_b
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, up: int = 0,
-            corner_patch: int = 0, rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+            corner_patch: int = 0, rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, splitk: int = 0) -> torch.Tensor:
     """x NHWC bf16 [B,H,W,Cin]; w bf16 [Cout, 9*Cin] tap-major; returns NHWC bf16 [B,Ho,Wo,Cout]."""
     l = _lib.load()
     _bf16(x); _bf16(w)
@@ -141,6 +142,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stri
     d.ldrb = rowbias.shape[1] if rowbias is not None else 0
     d.rows_per_batch = ho * wo
     d.B, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.up, d.corner_patch = b, h, wd, cin, ho, wo, stride, up, corner_patch
+    d.splitk = splitk
     _lib.check(l.mx_conv3x3(_lib.current_stream(), C.byref(d)), "mx_conv3x3")
     return c
 

@@ -442,3 +442,88 @@ def test_gemm_split_a_operand(cuda_device, m, n, k1, k2):
     d.M, d.N, d.K, d.lda, d.ldc, d.lda2, d.k_split = m, n, k1 + k2, k1, n, k2, k1
     lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)), "mx_gemm split A")
     _close(out, torch.cat([a1, a2], dim=1) @ w.t() + bias, 2.0 ** -7, f"gemm split A {m}x{n}x({k1}+{k2})")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# split-K (small launches: 128-row tiles in several K slices, combined by the last arriver in slice order; gemm_bf16_v2.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _splitk_of(d, conv=0):
+    from sduss_amd import lib
+    return lib.load().mx_gemm_splitk(C.byref(d), conv)
+
+
+@pytest.mark.parametrize("m,n,k", [(2048, 1280, 1280), (2048, 1280, 5120), (1024, 640, 2560), (1856, 1280, 1280), (512, 1280, 1280)])
+def test_gemm_splitk_parity_and_run_to_run_stability(cuda_device, m, n, k):
+    """one-request shapes of the SDXL step (M = 2048 tokens x N 1280, K 1280 / 5120; a mixed 512 + 768 px level: M 1856): the launch is SPLIT
+    in two (forced through mx_gemm_desc.splitk), equals the fp32 reference within one bf16 rounding, and is bit-identical over repeated launches although the
+    workgroup that combines the slices changes from run to run (the partial tiles are always added in slice order)"""
+    from sduss_amd import lib, ops
+    g = torch.Generator().manual_seed(m + n + k)
+    a = _rt(torch.randn(m, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
+    b = torch.randn(n, generator=g); r = _rt(torch.randn(m, n, generator=g))
+    d = lib.GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldc, d.ldr = m, n, k, k, n, n
+    d.a = d.w = d.c = d.residual = 4096
+    d.splitk = 2                                # forced: the library's own choice splits only where the partial tiles' traffic pays (long K)
+    assert _splitk_of(d) == 2, "this shape is eligible for split-K"
+    want = a @ w.t() + b + r
+    ad, wd, bd, rd = _bf(a).cuda(), _bf(w).cuda(), b.cuda(), _bf(r).cuda()
+    first = ops.gemm(ad, wd, bd, residual=rd, splitk=2)
+    _close(first, want, 2.0 ** -7, f"split-K gemm {m}x{n}x{k}")
+    _close(ops.gemm(ad, wd, bd, residual=rd, splitk=1), want, 2.0 ** -7, f"unsplit gemm {m}x{n}x{k}")
+    for _ in range(6):
+        again = ops.gemm(ad, wd, bd, residual=rd, splitk=2)
+        assert torch.equal(again.view(torch.int16), first.view(torch.int16)), "split-K result changed from one launch to the next"
+
+
+def test_gemm_splitk_automatic_choice_is_shape_based(cuda_device):
+    """the library's own choice: long K at small M x N splits (ff.net.2 of one request), K 1280 does not (measured slower: the fp32 partial
+    tiles' round trip through memory costs more than the shorter K loop saves, profiles/r04_g_splitk_bench.txt)"""
+    from sduss_amd import lib
+    d = lib.GemmDesc()
+    d.a = d.w = d.c = 4096
+    d.M, d.N, d.K, d.lda, d.ldc = 2048, 1280, 5120, 5120, 1280
+    assert _splitk_of(d) == 2
+    d.K = d.lda = 1280
+    assert _splitk_of(d) == 1
+    d.M, d.K, d.lda = 8192, 5120, 5120
+    assert _splitk_of(d) == 1
+
+
+def test_gemm_splitk_with_folded_layernorm_and_stats(cuda_device):
+    """to_q of a single request: LayerNorm folded into a split launch (the -mean * colsum term enters through slice 0 only) that also produces
+    the row statistics of its output"""
+    from sduss_amd import ops
+    from sduss_amd.weights import fold_layernorm
+    g = torch.Generator().manual_seed(77)
+    m, c, n = 2048, 1280, 1280
+    x = _rt(torch.randn(m, c, generator=g) * (0.5 + 1.5 * torch.rand(m, 1, generator=g)) + 3.0 * torch.randn(m, 1, generator=g))
+    gamma, beta = 1.0 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    w = _rt(torch.randn(n, c, generator=g) * c ** -0.5); bias = 0.1 * torch.randn(n, generator=g)
+    want = F.layer_norm(x, (c,), gamma, beta, 1e-5) @ w.t() + bias
+    wf, colsum, bf_ = fold_layernorm(w, bias, gamma, beta)
+    st = ops.row_stats(_bf(x).cuda())
+    got, (stats, slabs) = ops.gemm(_bf(x).cuda(), wf.cuda(), bf_.cuda(), ln_stats=st, ln_colsum=colsum.cuda(), ln_eps=1e-5, want_stats=True, splitk=2)
+    _close(got, want, 2.0 ** -7, "split-K ln-folded linear")
+    s = stats[:, :slabs].sum(dim=1).cpu()
+    _close(s[:, 0], want.sum(dim=1), 2e-3, "row sums from the split launch's epilogue")
+
+
+def test_conv3x3_splitk(cuda_device):
+    """the 1280-channel conv of one request at the 32 x 32 level (M 2048, K 11520): split over the taps"""
+    from sduss_amd import lib, ops
+    g = torch.Generator().manual_seed(5)
+    b, hw, cin, cout = 2, 32, 1280, 1280
+    x = _rt(torch.randn(b, cin, hw, hw, generator=g)); w = _rt(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g)
+    d = lib.GemmDesc()
+    d.M, d.N, d.K, d.ldc = b * hw * hw, cout, 9 * cin, cout
+    d.a = d.w = d.c = 4096
+    d.B, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride = b, hw, hw, cin, hw, hw, 1
+    d.splitk = 3
+    assert _splitk_of(d, 1) == 3
+    want = F.conv2d(x, w, bias, padding=1)
+    got = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(w)).cuda(), bias.cuda(), splitk=3)
+    _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, "split-K conv3x3")
+    again = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(w)).cuda(), bias.cuda(), splitk=3)
+    assert torch.equal(again.view(torch.int16), got.view(torch.int16))
