@@ -187,7 +187,7 @@ typedef struct mx_gemm_desc {
    * descriptor's own a / c / residual / vt / rowbias / gate / ln_stats / stats_out only say WHICH operands exist (non-NULL), M is ignored. */
   const mx_gemm_seg* segs;
   int n_segs;
-  /* split-K (see mx_gemm_splitk): 0 = the library decides from the shape (a split is taken where its estimate beats the unsplit launch by 10 %),
+  /* split-K (see mx_gemm_splitk): 0 = the library decides from the shape (a split is taken where its estimate beats the unsplit launch by 25 %),
    * 1 = never, 2..4 = that many slices wherever the launch is eligible at all (a 128-row tiling, >= 8 K tiles per slice, no split A operand) */
   int splitk;
 } mx_gemm_desc;
@@ -545,16 +545,15 @@ int mx_t5_encode(mx_t5* t, void* stream, const int32_t* ids, void* out, int batc
  * first, the first-consumed one last, as res_hidden_states_tuple is ordered: cache_manager.py:110-121)] and answers
  * run / reuse per sample; a reused block's outputs (hidden state and, for the down blocks, the skip tensors) come from the cache.
  * Approximate by design and OFF on the exact path (mx_unet_forward never consults it).
- * Granularity: the SAMPLE (a request's CFG row) -- the reference's unit when each latent is one patch (is_sliced False, unet.py:261-272: the
- * caches are keyed by request id).  A block is skipped as a whole only when NO sample asks to run it (save_and_get_block_states:
- * mask.sum() == 0, cache_manager.py:60-67).  When it runs, the samples that did not ask keep their cached outputs (UNet; round 3): the
- * reference computes every op of a running block for the asking rows only and returns each op's cached output for the others
- * (update_and_return, cache_manager.py:84-99; resnet.py:157-172, 414-454; attention.py:73-76, 104, 224), which for non-interacting samples is
- * exactly "the block's outputs of a not-asking sample are its cached ones".  Here the block is evaluated for the whole batch and those rows
- * are restored from the state, so the RESULT is the reference's; the arithmetic of the not-asking rows is not saved.  Not reproduced: with
- * several patches per latent (is_sliced True) the reference's unit is the 256-px patch, and a stale patch also feeds its neighbours' halos,
- * GroupNorm statistics and attention keys; the MMDiT entry keeps whole-block reuse (its text stream attends over partly stale image keys in
- * the reference).  The cached state belongs to one batch composition: a different
+ * Granularity of THIS entry (mx_unet_forward_cached, one resolution): the SAMPLE (a request's CFG row).  A block is skipped as a whole only when
+ * NO sample asks to run it (save_and_get_block_states: mask.sum() == 0, cache_manager.py:60-67); when it runs, a sample that did not ask keeps the
+ * OUTPUTS the block produced for it at its last run (the block is evaluated for the whole batch and those rows are restored from the state).
+ * Round 4: this sample unit is this library's own reading, kept for callers that run unsliced -- the reference has no working unsliced cache (the
+ * unsliced branches of its attention hand update_and_return ALL rows together with a partial mask, attention.py:204-224, which cannot broadcast),
+ * and inside a running block it does not restore block outputs: GroupNorm, LayerNorms, projections, the feed-forward and the residual paths of a
+ * patch that did not ask are computed fresh and only its convolutions and attention sub-blocks reuse their own cached outputs.  That behaviour, at
+ * the reference's unit (the 256-px patch, is_sliced=True) and with the compute of the not-asking patches actually skipped, is
+ * mx_unet_forward_cached_mixed below; the MMDiT's is mx_mmdit_forward_cached_mixed.  The cached state belongs to one batch composition: a different
  * batch_key, batch size or latent size invalidates it (every block runs once and refills it).  Not combined with patch parallelism.
  *   predict(ctx, block, is_up, n_samples, n_feat, timesteps[n], mse[n * n_feat], run_out[n]): mse = MX_MSE_UNCACHED when the block has no
  *   cached input; return non-zero to abort the forward.  The reference's predictors are cuML random forests that are not loadable here:

@@ -41,16 +41,19 @@ class CacheManagerRef:
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
-# The cached FORWARD: the seven block wrappers of modules/unet_2d_blocks.py around the oracle's blocks, with real tensors.
+# The cached FORWARD at the SAMPLE unit: the seven block wrappers of modules/unet_2d_blocks.py around the oracle's blocks, with real tensors.
+# (Round 4: this is the oracle of mx_unet_forward_cached's own unsliced unit -- "a sample that did not ask keeps its block outputs" -- not of the
+# reference's behaviour inside a running block, which exists only sliced and per patch: oracle/cache_patch_ref.py restates that.)
 # Restates, for the case of one patch per latent (is_sliced False: unet.py:261-272 keys every cache by request id, so a "patch" is a sample):
 #   * PatchCrossAttnDownBlock2D / PatchDownBlock2D (unet_2d_blocks.py:66-170): mask = input.get_mask(...); the body runs when mask.sum() != 0;
 #     output = save_and_get_block_states / _tupple (hidden state and the skip tensors the block emits);
 #   * PatchUNetMidBlock2DCrossAttn (:9-62);
 #   * PatchCrossAttnUpBlock2D / PatchUpBlock2D (:180-382): get_mask(..., is_upsample=True, res_tuple = the skips the block consumes);
-#   * inside a running block every Split* / Patch* op computes the asking rows and returns its own cached output for the others
-#     (cache_manager.py:84-99 update_and_return; resnet.py:157-172, 414-454; attention.py:73-76, 104, 224).  Samples do not interact inside a
-#     block (GroupNorm, attention and convolution are per sample), so op by op this gives, for a sample that did not ask, exactly the
-#     outputs the block produced for it at its last run -- restated here at block granularity, row by row.
+#   * inside a running block this oracle (like mx_unet_forward_cached) RESTORES THE BLOCK'S OUTPUTS of a sample that did not ask.  Round 3
+#     argued that this is what the reference's per-op caches give for non-interacting samples; it is not: in the reference only the
+#     convolutions and the attention sub-blocks return cached outputs, while the normalisations, the feed-forward, the shortcut and the
+#     residual adds of such a sample run on its fresh input (resnet.py:401-458, transformer.py:191-288), and its unsliced attention branches
+#     cannot take a partial mask at all (attention.py:204-224).  So this is the library's own sample-unit semantics, stated as such.
 # The mse features are the reference's: nn.MSELoss(reduction='none')(cached, new).mean(dim=(-1, -2, -3)) per sample.
 # ---------------------------------------------------------------------------------------------------------------------------------------
 class CachedUNetRef:

@@ -61,7 +61,10 @@ struct AttnArgs {
 // ordinary kernel body on it: `p` is a wave-uniform reference into the kernel-argument segment (scalar loads).  n == 1: an ordinary launch.
 struct AttnGroup {
   AttnArgs g[MX_MAX_SEGS];
-  int blk0[MX_MAX_SEGS + 1];           // first workgroup of every problem
+  int blk0[MX_MAX_SEGS + 1];           // first workgroup of every problem: a multiple of 8, so that (workgroup & 7) is the hardware XCD in EVERY
+                                       // problem (advisor, round 3: after a problem with an odd workgroup count the later problems' XCD-aware map
+                                       // was rotated and their K / V^T panels lost their L2)
+  int nblk[MX_MAX_SEGS];               // workgroups of every problem; the padding workgroups behind them exit at once
   int n;
 };
 
@@ -78,6 +81,7 @@ __device__ __forceinline__ const AttnArgs& attn_locate(const AttnGroup& ga, int&
   for (int i = 1; i < MX_MAX_SEGS; ++i) if (i < ga.n && lin >= ga.blk0[i]) s = i;
   const AttnArgs& p = ga.g[s];
   lin -= ga.blk0[s];
+  if (lin >= ga.nblk[s]) { qb = -1; bh = 0; return p; }      // padding up to the next problem's 8-aligned start
   const int gx = (p.Lq + ROWS - 1) / ROWS;
   if (p.xcd_map) {
     const int local = lin >> 3;
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnGroup ga) {
   // of 8, XCD x instead owns the pairs == x (mod 8) and walks their query blocks consecutively.
   int qb, bh;
   const AttnArgs& p = attn_locate<128>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
+  if (qb < 0) return;
   const int head = bh % p.H;
   const int b = bh / p.H;
   const int q0 = qb * 128 + wave * 32;
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnGroup ga
   // of 8, XCD x instead owns the pairs == x (mod 8) and walks their query blocks consecutively.
   int qb, bh;
   const AttnArgs& p = attn_locate<128>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
+  if (qb < 0) return;
   const int head = bh % p.H;
   const int b = bh / p.H;
   const int q0 = qb * 128 + wave * 32;
@@ -739,6 +745,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnGroup ga) 
   const int hh = lane >> 5;  // half-wave
   int qb, bh;
   const AttnArgs& p = attn_locate<256>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
+  if (qb < 0) return;
   const int head = bh % p.H;
   const int b = bh / p.H;
   const int q0 = qb * 256 + wave * 64;
@@ -1045,6 +1052,7 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnGroup ga) 
   const int hh = lane >> 5;
   int qb, bh;
   const AttnArgs& p = attn_locate<4 * XK_QPW>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
+  if (qb < 0) return;
   const int head = bh % p.H;
   const int b = bh / p.H;
   const int nblk = (p.Lk + 31) >> 5;           // <= XK_MAXBLK (launcher)
@@ -1242,7 +1250,13 @@ static int launch_attention_group(void* stream, mx::AttnGroup& ga, bool pre) {
   else if (whole_tiles) kind = K_DMA;                                     // whole tiles: LDS-DMA staging two tiles ahead
   const int rows = kind == K_CROSS ? 4 * XK_QPW : kind == K_W64 ? 256 : 128;
   long blocks = 0;
-  for (int i = 0; i < n; ++i) { ga.blk0[i] = (int)blocks; blocks += (long)cdiv(ga.g[i].Lq, rows) * ga.g[i].H * ga.g[i].B; }
+  for (int i = 0; i < n; ++i) {
+    blocks = (blocks + 7) & ~7L;
+    ga.blk0[i] = (int)blocks;
+    ga.nblk[i] = cdiv(ga.g[i].Lq, rows) * ga.g[i].H * ga.g[i].B;
+    blocks += ga.nblk[i];
+  }
+  for (int i = n; i < MX_MAX_SEGS; ++i) ga.nblk[i] = 0;
   for (int i = n; i <= MX_MAX_SEGS; ++i) ga.blk0[i] = (int)blocks;
   MX_CHECK(blocks < 2147483647L, "attention: too many workgroups");
   hipStream_t st = (hipStream_t)stream;

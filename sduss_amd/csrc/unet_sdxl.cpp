@@ -100,6 +100,7 @@ struct Plan {
   int bc_rows = 0;                // samples a state tensor holds: the batch, or bc->n_slots when the caller keeps one slot per request
   const int* bc_dslot = nullptr;  // device copy of bc->slots (null: sample i lives in row i)
   std::vector<unsigned char> bc_valid;   // per sample: the state holds its tensors of an earlier step
+  std::vector<int> bc_sel;               // selection table of a partially reused block (host copy kept for the forward's lifetime)
   bool bc_all_valid = false, bc_any_valid = false;
   // head of the state: comparison partial sums, the slot table, the selection table of a partially reused block
   static size_t bc_scratch_bytes(int lpb, int rows) { return (((size_t)(lpb + 2) * rows * 64 * sizeof(double) + 2 * (size_t)rows * sizeof(int)) + 255) & ~(size_t)255; }
@@ -1032,7 +1033,8 @@ struct Plan {
       // outputs of a not-asking sample are the cached ones": the block runs for the batch and those rows are then restored from the state.
       // (With several patches per latent the reference also feeds the stale patches' values into their neighbours' halos, GroupNorm
       // statistics and attention keys: not reproduced -- the unit here is the sample.)
-      std::vector<int> sel(B, -1);
+      std::vector<int>& sel = bc_sel;                          // (a Plan member: the source of the asynchronous copy below outlives this block)
+      sel.assign(B, -1);
       bool partial = false;
       if (any) for (int b = 0; b < B; ++b) if (!run[b] && bc_valid[b]) { sel[b] = bc->slots ? bc->slots[b] : b; partial = true; }
       if (partial && ok() && hipMemcpyAsync(bc_dsel(), sel.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess)

@@ -75,13 +75,14 @@ def test_grouped_gemm_bias_residual(cuda_device, ms, n, k):
     out_g = [torch.empty(m, n, dtype=torch.bfloat16, device="cuda") for m in ms]
     out_s = [torch.empty(m, n, dtype=torch.bfloat16, device="cuda") for m in ms]
     segs = _segs(lib, [dict(a=Ag[i], c=out_g[i], residual=Rg[i], M=ms[i]) for i in range(len(ms))])
-    d = _desc(lib, a=Ag[0], w=wg, c=out_g[0], bias=bg, residual=Rg[0], N=n, K=k, lda=k, ldc=n, ldr=n, n_segs=len(ms))
+    # splitk=1 on both sides: the bit-equality below is a property of the unsplit tilings (a K slicing adds a row's products in another order)
+    d = _desc(lib, a=Ag[0], w=wg, c=out_g[0], bias=bg, residual=Rg[0], N=n, K=k, lda=k, ldc=n, ldr=n, n_segs=len(ms), splitk=1)
     d.segs = segs
     kg = _kinds(lambda: lib.check(l.mx_gemm(lib.current_stream(), C.byref(d)), "grouped mx_gemm"))
     assert len(kg) == 1
     ks = []
     for i, m in enumerate(ms):
-        di = _desc(lib, a=Ag[i], w=wg, c=out_s[i], bias=bg, residual=Rg[i], M=m, N=n, K=k, lda=k, ldc=n, ldr=n)
+        di = _desc(lib, a=Ag[i], w=wg, c=out_s[i], bias=bg, residual=Rg[i], M=m, N=n, K=k, lda=k, ldc=n, ldr=n, splitk=1)
         ks += _kinds(lambda: lib.check(l.mx_gemm(lib.current_stream(), C.byref(di)), "mx_gemm"))
     for i, m in enumerate(ms):
         _close(out_g[i], A[i] @ w.t() + bias + R[i], 2.0 ** -7, f"grouped gemm problem {i} (M {m})")
@@ -141,7 +142,7 @@ def test_grouped_conv3x3(cuda_device, cin, cout, stride, up):
                          Hout=ho[i], Wout=ho[i]))
     segs = _segs(lib, rows)
     d = _desc(lib, a=Xg[0], w=wg, c=out_g[0], bias=bg, residual=Rg[0], rowbias=rbg, N=cout, K=9 * cin, ldc=cout, ldr=cout, ldrb=cout, Cin=cin,
-              stride=stride, up=up, n_segs=3)
+              stride=stride, up=up, n_segs=3, splitk=1)
     d.segs = segs
     lib.check(l.mx_conv3x3(lib.current_stream(), C.byref(d)), "grouped conv3x3")
     for i, (b, h) in enumerate(spec):
@@ -150,9 +151,12 @@ def test_grouped_conv3x3(cuda_device, cin, cout, stride, up):
         _close(out_g[i].permute(0, 3, 1, 2), want, 2.0 ** -7, f"grouped conv {cin}->{cout} s{stride} up{up} problem {i} ({h}x{h})")
         o1 = torch.empty_like(out_g[i])
         d1 = _desc(lib, a=Xg[i], w=wg, c=o1, bias=bg, residual=Rg[i], rowbias=rbg[b0[i]:], M=b * ho[i] * ho[i], N=cout, K=9 * cin, ldc=cout, ldr=cout,
-                   ldrb=cout, rows_per_batch=ho[i] * ho[i], B=b, Hin=h, Win=h, Cin=cin, Hout=ho[i], Wout=ho[i], stride=stride, up=up)
+                   ldrb=cout, rows_per_batch=ho[i] * ho[i], B=b, Hin=h, Win=h, Cin=cin, Hout=ho[i], Wout=ho[i], stride=stride, up=up, splitk=1)
         lib.check(l.mx_conv3x3(lib.current_stream(), C.byref(d1)), "conv3x3")
         assert torch.equal(o1, out_g[i]), f"problem {i}: grouped != separate"
+        d1.splitk = 0                          # the library's own choice (these small images split over the taps): same values within the rounding
+        lib.check(l.mx_conv3x3(lib.current_stream(), C.byref(d1)), "conv3x3")
+        _close(o1.permute(0, 3, 1, 2), want, 2.0 ** -7, f"conv {cin}->{cout} problem {i}, automatic split")
 
 
 def test_grouped_geglu_and_ln_fold_256x256(cuda_device):
