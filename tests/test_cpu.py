@@ -383,7 +383,7 @@ def test_layernorm_fold_algebra_and_tile_policy():
     # producers: one slab per wave column panel (80 columns of a 160-wide tile, 64 of a 128-wide one); none from the generic kernel
     assert l.mx_gemm_stats_slabs(C.byref(desc(8192, 1280, 1280))) == 16
     assert l.mx_gemm_stats_slabs(C.byref(desc(2048, 1280, 5120))) == 20      # (a 5 % split-K gain is below the 25 % margin: unsplit 128 x 128 tiles)
-    assert l.mx_gemm_stats_slabs(C.byref(desc(512, 1280, 5120))) == 16       # round 4: split-K moves a 512 px request's ff.net.2 to 128 x 160 tiles in K slices
+    assert l.mx_gemm_stats_slabs(C.byref(desc(1152, 1280, 5120))) == 16      # round 4: split-K moves a 768 px request's ff.net.2 to 128 x 160 tiles in 3 K slices (80-column panels)
     assert l.mx_gemm_splitk(C.byref(desc(512, 1280, 5120)), 0) >= 2 and l.mx_gemm_splitk(C.byref(desc(2048, 1280, 1280)), 0) == 1
     assert l.mx_gemm_stats_slabs(C.byref(desc(64, 1280, 1280))) == 0             # M < 128: generic kernel
     assert l.mx_gemm_stats_slabs(C.byref(desc(8192, 1280, 1280, lib.EPI_GEGLU))) == 0
