@@ -12,7 +12,7 @@ Extra legs (outside the timed region):
   roofline     one more step with every GEMM/conv/attention launch bracketed by hipEvents on its stream
                (mx_profile_enable): achieved = algorithmic FLOPs / summed launch time of the dominant kernel
   stream       the BASELINE.md section 4 procedure: fixed-prompt Poisson streams at the reference's offered loads
-               (1.0 req/s per GPU x 120 requests, short legs at 0.8 and 1.2), p50 / p90 latency and throughput per load
+               (1.0 req/s per GPU x 80 requests, short legs at 0.8 and 1.2), p50 / p90 latency and throughput per load
   mixed_stream BASELINE configs[4] shape: a mixed-resolution Poisson stream (512 / 768 / 1024 px, 30-50 steps), continuous batching with
                the resolutions of a step in ONE launch sequence, the reference's metrics (SLO rate, goodput)
   sd3          BASELINE configs[2]: SD3.5-medium 1024^2 28-step, the same timed-step protocol, with its own roofline
@@ -71,6 +71,14 @@ def pmc_traffic_bytes(kernel_label, model):
     return (mb / n * 1e6, os.path.basename(files[-1])) if n else (None, None)
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """one line per finished leg on stderr (the JSON line on stdout comes last): long runs stay visibly alive"""
+    print(f"[bench {time.perf_counter() - _T0:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,11 +88,11 @@ def parse():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--model", choices=["sdxl", "sd3"], default="sdxl", help="sdxl = BASELINE configs[1] (the headline metric); sd3 = configs[2]")
     ap.add_argument("--sliced", action="store_true", help="is_sliced=True, patch_size=256 (the reference's mixed-policy setting)")
-    ap.add_argument("--stream-requests", type=int, default=120, help="requests per GPU of the main Poisson leg (0 = skip the stream legs)")
+    ap.add_argument("--stream-requests", type=int, default=80, help="requests per GPU of the main Poisson leg (0 = skip the stream legs)")
     ap.add_argument("--stream-rates", type=str, default="1.0,0.8,1.2",
                     help="offered loads in requests/s PER GPU (the reference sweeps {0.8..1.2} x N_gpu req/s, scripts/paper/scalibility.sh:12-13); "
                          "the first is the main leg, the others run stream-requests/5 requests each")
-    ap.add_argument("--mix", type=int, default=None, help="(default: 32 on the default SDXL run, else 0) configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
+    ap.add_argument("--mix", type=int, default=None, help="(default: 28 on the default SDXL run, else 0) configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
                                                        "reference traces exp/<model>/qps_*.csv) per offered load of --mix-rates; reports the reference's metrics "
                                                        "(scripts/draw/get_metric.py: SLO rate, average latency, goodput, throughput)")
     ap.add_argument("--mix-rates", type=str, default="1.0,2.0")
@@ -101,7 +109,7 @@ def parse():
     ap.add_argument("--no-two-model", action="store_true", help="skip the configs[4] leg with SDXL and SD3.5 requests interleaved in one stream")
     a = ap.parse_args()
     if a.mix is None:
-        a.mix = 32 if (a.model == "sdxl" and a.res == 1024) else 0
+        a.mix = 28 if (a.model == "sdxl" and a.res == 1024) else 0
     if a.pp is None:
         a.pp = a.gpus if (a.gpus > 1 and a.model == "sdxl") else 0
     if a.pp and (a.pp < 2 or a.gpus % a.pp):
@@ -634,9 +642,10 @@ def dry_rehearsal(args, rank, world):
 
 def sd3_parity_start(net3, reqs3, P3):
     """The SD3.5 block's parity check (configs[2] at the batch the bench times): the HIP forward of the WHOLE batch of 2 x requests on its
-    first-step inputs now, and the fp32 oracle's answer for its last row (the conditional row of the last request) computed by a background
-    host thread while the GPU legs run (the oracle costs ~75 s of host time and is not a timed quantity).  Returns (hip row, thread, box)."""
-    import threading
+    first-step inputs is taken now; the fp32 oracle's answer for its last row (the conditional row of the last request) is computed when the
+    returned closure is called -- after every latency-measured leg (round 4 first ran it on a host thread beside the stream legs: 128 oracle
+    threads starved the launch path and the stream's p50 went from 2.5 s to 13 s, so it runs alone now, ~75 s of host time).
+    Returns (hip row, oracle closure, row index)."""
     from oracle import sd3_mmdit_ref as mref
     n = len(reqs3)
     lat = torch.cat([r.latents for r in reqs3], dim=0)
@@ -650,25 +659,11 @@ def sd3_parity_start(net3, reqs3, P3):
     f = lambda t: t[k:k + 1].float().cpu()
     row = (f(x), f(ts2).reshape(1), f(ehs), f(pooled))
     P32 = {name: v.float().cpu() for name, v in P3.items()}
-    box = {}
 
-    def work():
-        try:
-            # keep the oracle's worker threads (a pool of its own, created by this thread's first parallel region and inheriting its affinity)
-            # on the upper half of the host's CPUs: the main thread keeps feeding the GPU legs from the lower half, whose latencies are reported
-            try:
-                cpus = sorted(os.sched_getaffinity(0))
-                if len(cpus) >= 16:
-                    os.sched_setaffinity(0, set(cpus[len(cpus) // 2:]))
-            except (AttributeError, OSError):
-                pass
-            with torch.inference_mode():
-                box["want"] = mref.mmdit_forward(P32, mref.MMDiTConfig.sd35_medium(), *row)
-        except Exception as e:                                  # noqa: BLE001
-            box["error"] = f"{type(e).__name__}: {e}"
-    th = threading.Thread(target=work, daemon=True)
-    th.start()
-    return got[k:k + 1].float().cpu(), th, box, k
+    def oracle():
+        with torch.inference_mode():
+            return mref.mmdit_forward(P32, mref.MMDiTConfig.sd35_medium(), *row)
+    return got[k:k + 1].float().cpu(), oracle, k
 
 
 def main():
@@ -738,6 +733,7 @@ def main():
             "achieved_tflops_whole_step": 2 * batch * m["flop"] / step_seconds / 1e12 if res == 1024 else None,
             "frac_of_mfma_peak_whole_step": 2 * batch * m["flop"] / step_seconds / MFMA_PEAK_BF16 if res == 1024 else None,
         }
+    progress(f"timed region: {1e3 * step_s:.2f} ms/step")
     h = headline(args.model, mdl, args.res, step_s, images_per_s, args.batch, finite)
     result = {
         "metric": h["metric"], "value": h["value"], "unit": "images/s",
@@ -756,8 +752,8 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    # ---- the second model (configs[2] / configs[4]) is built NOW so that the oracle of its parity check can run on host threads beside the
-    #      stream legs below; both denoisers stay resident from here (SDXL 5.1 GB + SD3.5 5 GB of weights) ----
+    # ---- the second model (configs[2] / configs[4]) is built now: both denoisers stay resident from here (SDXL 5.1 GB + SD3.5 5 GB of weights)
+    #      and the HIP side of the SD3.5 parity check is taken on the block's own first-step batch ----
     sd3_built = sd3_parity = None
     want_sd3_block = rank == 0 and world == 1 and args.model == "sdxl" and args.res == 1024 and not args.no_sd3
     want_two_model = args.model == "sdxl" and args.res == 1024 and args.mix > 0 and not args.no_two_model and not args.no_sd3
@@ -783,6 +779,7 @@ def main():
             n_req = args.stream_requests if li == 0 else max(8, args.stream_requests // 5)
             lat, window = run_stream(den, cfg, args, device, shared, rate, n_req, rank, world)
             lat, window = dp.gather_stream_stats(lat, window, dist)
+            progress(f"stream leg {rate} req/s done")
             if rank == 0:
                 legs.append({"offered_req_per_s_per_gpu": rate, "offered_frac_of_closed_loop_capacity": rate * world / images_per_s,
                              "requests": len(lat), "p50_latency_s": float(np.percentile(lat, 50)), "p90_latency_s": float(np.percentile(lat, 90)),
@@ -804,6 +801,7 @@ def main():
         for rate, policy in [(float(x), pol) for x in args.mix_rates.split(",") if x for pol in ("fcfs_mixed", "continuous")]:
             rows, window = run_mix(den, cfg, args, device, shared, rate, args.mix, rank, world, args.model, policy)
             rows_all, window = dp.gather_stream_stats(rows, window, dist)
+            progress(f"mixed leg {rate} req/s {policy} done")
             if rank == 0:
                 ddl = REF_DEADLINES_S[args.model]
                 lat = [l for _r, l in rows_all]
@@ -824,6 +822,7 @@ def main():
                 from sduss_amd.block_cache import QuantilePredictor
                 net.enable_block_cache(QuantilePredictor(0.5))
                 rows, window = run_mix(den, cfg, args, device, shared, 1.0, args.mix, rank, world, args.model, "continuous")
+                progress("mixed leg with the block cache on done")
                 pc = net._patch_cache
                 frac = (pc.patches_asked / pc.patches_total) if pc is not None and pc.patches_total else None
                 skipped = (sum(bin(h ^ 0x7f).count("1") for h in pc.history) / (7.0 * len(pc.history))) if pc is not None and pc.history else None
@@ -871,6 +870,7 @@ def main():
             cfg3, net3, den3 = sd3_built
             rows2, win2 = run_two_model({"sdxl": (den, cfg), "sd3": (den3, cfg3)}, args, device, 1.0, args.mix, rank, world)
             rows2, win2 = dp.gather_stream_stats(rows2, win2, dist)
+            progress("two-model leg done")
             if rank == 0:
                 result.setdefault("mixed_stream", {})["two_model"] = two_model_summary(rows2, win2, 1.0)
         except Exception as e:
@@ -897,6 +897,7 @@ def main():
             sd3_built = None
             reqs3 = make_batch(den3, cfg3, args.batch, 1024, device, {})
             s3, step3 = timed_steps(den3, reqs3, "1024", args, None, device, False)
+            progress(f"sd3 timed region: {1e3 * s3:.2f} ms/step")
             fin3 = all(torch.isfinite(r.latents.float()).all().item() for r in reqs3)
             blk = headline("sd3", m3, 1024, s3, args.batch / (m3["steps"] * s3), args.batch, fin3)
             blk.update({"steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "data": "synthetic", "n_gpus": 1})
@@ -913,16 +914,18 @@ def main():
                                        "goodput_req_per_s": ok3 / (win3[1] - win3[0]), "throughput_req_per_s": len(rows3) / (win3[1] - win3[0]),
                                        "policy": "FCFS mixed batching, is_sliced=True / patch 256, the resolutions of a step in ONE launch sequence"}
             if sd3_parity is not None:
-                hip_row, th, box, k3 = sd3_parity
-                th.join()
-                if "want" in box:
-                    err = hip_row - box["want"]
-                    l2, mx = float(err.norm() / box["want"].norm()), float(err.abs().max() / box["want"].abs().max())
+                hip_row, oracle3, k3 = sd3_parity
+                progress("sd3 oracle starts")
+                try:
+                    want3 = oracle3()
+                    err = hip_row - want3
+                    l2, mx = float(err.norm() / want3.norm()), float(err.abs().max() / want3.abs().max())
                     blk["parity_check"] = {"what": f"row {k3} (conditional row of the last request) of the HIP forward of this block's own batch of {2 * args.batch} at its "
-                                                   "first step vs the fp32 oracle on the same weights and inputs (oracle computed by a host thread beside the GPU legs)",
+                                                   "first step vs the fp32 oracle on the same weights and inputs",
                                            "rel_l2": l2, "max_err_frac_of_range": mx, "bound_rel_l2": 0.03, "bound_max": 0.05, "ok": bool(l2 <= 0.03 and mx <= 0.05)}
-                else:
-                    blk["parity_check"] = {"error": box.get("error", "no result")}
+                except Exception as e:                          # noqa: BLE001
+                    blk["parity_check"] = {"error": f"{type(e).__name__}: {e}"}
+                progress("sd3 oracle done")
             result["sd3"] = blk
             del step3, den3, net3, reqs3
             torch.cuda.empty_cache()
@@ -935,7 +938,9 @@ def main():
 
     # ---- CPU baseline leg (+ the parity check of the headline batch's row) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress("cpu baseline starts")
         result["cpu_baseline"], want = cpu_baseline(args.res, args.model, parity_row)
+        progress("cpu baseline done")
         if parity_row is not None:
             err = (parity_hip - want)
             l2 = float(err.norm() / want.norm())
