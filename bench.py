@@ -666,6 +666,30 @@ def sd3_parity_start(net3, reqs3, P3):
     return got[k:k + 1].float().cpu(), oracle, k
 
 
+def config1_first_step(net, cfg, den, device):
+    """BASELINE.json configs[0] / BASELINE.md section 3 "always-run plumbing baseline": SDXL, one prompt, 4 denoise steps at 512 x 512.  The HIP
+    forward of its first step (UNet batch 2 under CFG) is taken here; cpu_baseline() times the oracle on the same inputs (one of the 4 steps) and
+    compares.  Returns (hip noise prediction [2, 4, 64, 64] fp32 on the CPU, oracle inputs)."""
+    from sduss_amd import ops
+    from sduss_amd.pipeline import synthetic_request
+    r = synthetic_request(424242, 512, 4, cfg, den, device, shared={})
+    sig = torch.tensor([float(r.sigmas[0])], device=device)
+    ts2 = torch.tensor([float(r.timesteps[0])] * 2, device=device)
+    x = ops.euler_scale_input(r.latents, sig, 2)
+    ehs = torch.cat([r.negative_prompt_embeds, r.prompt_embeds], dim=0)
+    pooled = torch.cat([r.negative_pooled_prompt_embeds, r.pooled_prompt_embeds], dim=0)
+    tids = torch.cat([r.negative_add_time_ids, r.add_time_ids], dim=0)
+    got = net.forward_one(x, ts2, ehs, pooled, tids)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):                                      # the same launch sequence eight times: the UNet share of two 4-step images
+        net.forward_one(x, ts2, ehs, pooled, tids)
+    e1.record()
+    e1.synchronize()
+    f = lambda t: t.float().cpu()
+    return f(got), (f(x), f(ts2), f(ehs), f(pooled), f(tids)), e0.elapsed_time(e1) / 8e3
+
+
 def main():
     global STEPS_PER_IMAGE
     args = parse()
@@ -713,8 +737,10 @@ def main():
     #      the oracle's answer for one row comes from the cpu_baseline leg below (same run, same weights) ----
     parity_hip = parity_row = None
     want_parity = rank == 0 and world == 1 and args.model == "sdxl" and not args.no_parity and not args.no_cpu_baseline
+    config1 = None
     if want_parity:
         parity_hip, parity_row, parity_k = parity_row_inputs(net, reqs, P)
+        config1 = config1_first_step(net, cfg, den, device)
     del P
 
     step_s, step = timed_steps(den, reqs, key, args, dist, device, rehearse)
@@ -940,6 +966,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         progress("cpu baseline starts")
         result["cpu_baseline"], want = cpu_baseline(args.res, args.model, parity_row)
+        if config1 is not None and parity_row is not None:       # configs[0]: one of its four 512^2 steps on the host cores, same weights
+            from oracle import sdxl_unet_ref as oref
+            hip1, in1, hip_dt1 = config1
+            with torch.inference_mode():
+                t0 = time.perf_counter()
+                want1 = oref.unet_forward(parity_row[0], oref.UNetConfig.sdxl_base(), *in1)
+                dt1 = time.perf_counter() - t0
+            e1 = hip1 - want1
+            result["cpu_baseline"]["config1"] = {
+                "what": "BASELINE configs[0]: SDXL-base, one prompt, 4 denoise steps, 512x512, CFG (UNet batch 2): ONE of the four steps timed on the host cores "
+                        "(fp32 torch oracle), x4; the HIP forward of the same step compared with it",
+                "cpu_seconds_per_step": dt1, "cpu_seconds_4_steps_extrapolated": 4 * dt1, "cpu_images_per_s": 1.0 / (4 * dt1),
+                "hip_seconds_per_step": hip_dt1, "hip_images_per_s_unet_only": 1.0 / (4 * hip_dt1),
+                "hip_vs_oracle_rel_l2": float(e1.norm() / want1.norm()), "hip_vs_oracle_max_err_frac_of_range": float(e1.abs().max() / want1.abs().max())}
         progress("cpu baseline done")
         if parity_row is not None:
             err = (parity_hip - want)
