@@ -1,6 +1,6 @@
 """77-key cross-attention, per launch, same box: the short-key kernel at 64 / 128 / 256 queries per wave (MX_XQPW, an experiment hook of round 4)
-and the general register-staged kernel (MX_XQPW=0).  One process per setting (the hook is read per launch, so one process would do; the
-separate runs keep the clock history comparable).  Usage on the GPU box: python tools/exp/cross_attn_bench.py"""
+and the general register-staged kernel (MX_XQPW=0).  The hook lived in an experimental build of attention.hip (template parameter QPW of
+attn_cross_kernel, chosen per launch) that was not kept: profiles/r04_n_cross_attn_bench.txt.  With the shipped library every column times the same launch."""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sduss_amd import ops
