@@ -190,6 +190,16 @@ typedef struct mx_gemm_desc {
   /* split-K (see mx_gemm_splitk): 0 = the library decides from the shape (a split is taken where its estimate beats the unsplit launch by 25 %),
    * 1 = never, 2..4 = that many slices wherever the launch is eligible at all (a 128-row tiling, >= 8 K tiles per slice, no split A operand) */
   int splitk;
+  /* FINALISED row statistics (round 4): the form of the folded LayerNorm the persistent 256 x 256 kernel can afford.  A producer launched with
+   * stats_out AND ln_final_out != NULL (256-row x 160 / 128 tiles only: mx_gemm_ln_final_supported) also leaves, per output row, the pair
+   * (mean, rstd) over its N columns in ln_final_out[m * 2 + {0, 1}] (rstd with the producer's own ln_eps): the LAST workgroup of a 256-row
+   * panel to finish -- a ticket in ln_final_cnt[panel], one unsigned per 256 rows, ZERO before the launch and zero again after it -- adds the
+   * panel's slabs in slab order (bit-stable run to run).  A consumer launched with ln_final != NULL (and ln_colsum; ln_stats NULL; no grouped
+   * launch, no row remap) reads those 8 bytes per row instead of the slabs: it runs on the 256 x 256 kernel where the plain launch would, and
+   * the normalisation pass in front of it disappears.  16-byte aligned. */
+  const float* ln_final;
+  float* ln_final_out;
+  unsigned* ln_final_cnt;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -199,6 +209,8 @@ int mx_gemm_stats_slabs(const mx_gemm_desc* d);        /* slabs d->stats_out rec
  * normalises with mx_layernorm(gamma = NULL) and launches d without ln_stats.  The 256 / 128-row kernels hide the statistics behind their
  * first operand fetch: 0. */
 int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d);
+/* 1 when mx_gemm(d) with stats_out can also write ln_final_out (the launch takes a 256-row tile of the register-exchange kernels, ungrouped) */
+int mx_gemm_ln_final_supported(const mx_gemm_desc* d);
 #define MX_STATS_PITCH(slabs) (((slabs) + 3) & ~3)     /* slabs per row of a statistics buffer: [M][pitch][2] floats */
 /* stats[m * 4 * 2 + {0, 1}] = (sum_c x[m][c], sum_c x[m][c]^2), x bf16 [M, C] with row stride ldx: the one-slab input of ln_stats
  * (buffer of M * MX_STATS_PITCH(1) * 2 floats) */

@@ -49,6 +49,11 @@ struct GemmArgs {
   int ln_slabs;
   float ln_eps;
   float* stats_out;        // row statistics of the stored values, one slab per wave column panel; nullptr = off
+  // finalised row statistics (mxdenoise.h, ln_final): consumer side (the 256 x 256 kernel) / producer side (256-row tiles) + its panel tickets
+  const float* ln_final;
+  float* ln_final_out;
+  unsigned* ln_final_cnt;
+  int ln_final_slabs;      // slabs the producer's own launch writes per row (N / wave panel)
   // split-K (128-row tiles, small launches: gemm_bf16_v2.hip): the K tiles of an output tile are dealt to `splitk` workgroups; each leaves its
   // fp32 partial tile in sk_ws and takes a ticket from sk_cnt[tile]; the last one sums the partials in slice order and runs the epilogue
   int splitk;
@@ -160,6 +165,65 @@ __device__ __forceinline__ void gemm_ln_row(const GemmArgs& p, const int m, cons
   const float var = fmaxf(s2 * inv - mean * mean, 0.f);
   rstd = rsqrtf(var + p.ln_eps);
   rm = rstd * mean;
+}
+
+// ---- finalised row statistics (mxdenoise.h, ln_final).  PRODUCER side, after the epilogue of a 256-row tile whose launch has ln_final_out:
+// the slabs of this tile's rows went out as write-through (sc1) stores; the workgroup drains them, takes a ticket of its 256-row panel, and the
+// LAST of the panel's N / BN workgroups reads the panel's slabs back (sc1 loads), adds them in slab order and leaves (mean, rstd) per row.  No
+// fence (an L2 write-back of the whole tile's output) and no acquire: the same hand-off as split-K below.  Every thread of the workgroup calls. ----
+__device__ __forceinline__ void gemm_ln_finalize(const GemmArgs& p, const int tm, const int nt, volatile int* ticket_word) {
+  const int tid = threadIdx.x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) *ticket_word = (int)__hip_atomic_fetch_add(p.ln_final_cnt + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*ticket_word != nt - 1) return;
+  if (tid == 0) __hip_atomic_store(p.ln_final_cnt + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+  const int slabs = p.ln_final_slabs;
+  const int pitch = (slabs + 3) & ~3;
+  const int m = tm * 256 + (tid >> 1);         // two threads per row: slabs [0, half) and [half, slabs), each in slab order
+  const int half = (slabs + 1) >> 1;
+  const int s0 = (tid & 1) ? half : 0, s1 = (tid & 1) ? slabs : half;
+  float a = 0.f, q = 0.f;
+  if (m < p.M) {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p.stats_out + (long)m * pitch * 2);
+    for (int s = s0; s < s1; ++s) {
+      const unsigned long long v = __hip_atomic_load(src + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a += __uint_as_float((unsigned)v); q += __uint_as_float((unsigned)(v >> 32));
+    }
+  }
+  const float a2 = __shfl_xor(a, 1, 64), q2 = __shfl_xor(q, 1, 64);
+  if (!(tid & 1) && m < p.M) {
+    const float inv = 1.0f / (float)p.N;
+    const float mean = (a + a2) * inv;
+    const float var = fmaxf((q + q2) * inv - mean * mean, 0.f);
+    *reinterpret_cast<f32x2*>(p.ln_final_out + (long)m * 2) = f32x2{mean, rsqrtf(var + p.ln_eps)};
+  }
+}
+
+// CONSUMER side (the persistent 256 x 256 kernel): the tile's accumulators start at -mean_m * colsum_n from 8 bytes per row; rstd for the epilogue.
+// KEEP: rstd stays in registers across the K loop; otherwise the epilogue fetches it again, one token block ahead (gemm_epilogue_regs
+// RSTD_LOAD: the QKV instantiation has no registers to spare)
+template <int NI, int MI, bool KEEP>
+__device__ __forceinline__ void gemm_ln_init_final(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0, const int fr,
+                                                   const int fq, float (&rstd)[MI]) {
+  f32x2 st[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m_wave0 + j * 16 + fr;
+    st[j] = *reinterpret_cast<const f32x2*>(p.ln_final + (long)(m < p.M ? m : p.M - 1) * 2);
+  }
+  f32x4 cs[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) cs[i] = *reinterpret_cast<const f32x4*>(p.ln_colsum + wave_n0 + i * 16 + fq * 4);
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) rstd[j] = st[j][1];
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = cs[i] * (-st[j][0]);
 }
 
 // ---- split-K hand-off (cdna guide, "Projection GEMM at M = 256" item 2 and Guideline 16): partial tiles travel through memory as write-through
@@ -442,7 +506,12 @@ __host__ __device__ inline int gemm_epi_features(int flags) {
   const int acts = flags & (MX_EPI_SILU | MX_EPI_GELU | MX_EPI_GELU_TANH | MX_EPI_QUICK_GELU | MX_EPI_GEGLU_TANH);
   return ((flags & MX_EPI_QKV) ? EPI_F_QKV : 0) | (acts == 0 ? 0 : acts == MX_EPI_GELU_TANH ? EPI_F_TANH : EPI_F_ACT);
 }
-template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true, int FEAT = EPI_F_ALL>
+// EMIT: stats_out is compiled in (STATS alone: only the folded LayerNorm's rstd -- the 256 x 256 kernel's LN instantiations)
+// RSTD_LOAD: the folded LayerNorm's rstd is fetched from p.ln_final one token block ahead instead of arriving in ln_rstd_a (two registers
+// instead of MI: the QKV instantiation of the 256 x 256 kernel)
+// (Tried in round 4 and dropped: the WHOLE fold in the epilogue -- acc * rstd + (bias - rstd * mean * colsum) from one 8-byte load per token block, nothing in
+// front of the K loop.  +7.9 us per GEGLU launch against +4 us for the accumulator start: the block-ahead load does not cover an L2 round trip.)
+template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true, int FEAT = EPI_F_ALL, bool EMIT = STATS, bool RSTD_LOAD = false>
 __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
                                                    const int fr, const int fq, const float (&ln_rstd_a)[MI]) {
   constexpr int NIO = GEGLU ? NI / 2 : NI;     // output blocks per wave
@@ -486,7 +555,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   }
   // folded LayerNorm: the accumulators arrive as x W'^T - mean_m colsum_n (gemm_ln_init) and ln_rstd_a holds rstd_m (1 without the fold,
   // and acc * 1 + bias is acc + bias exactly)
-  const bool stats = STATS && !GEGLU && !qkv && p.stats_out != nullptr;
+  const bool stats = EMIT && !GEGLU && !qkv && p.stats_out != nullptr;
 
   // ---- V^T waves of the fused q | k | v projection: keys along the lanes, 2-byte stores (see gemm_epilogue); nothing else applies to them
   //      (no RMSNorm, no q scale, no residual), so they take their own short path here -- with their own token walk, so that neither this
@@ -501,12 +570,19 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       const int key_off = p.c_batch_rows > 0 ? p.c_row_off : 0;
       const int nv = p.N / p.period;
       const long feat0 = (long)seg_grp * p.seg + (wave_n0 - seg_idx * p.seg) + fq * 4;     // V feature of v[0][0]
+      auto rstd_at = [&](int j) __attribute__((always_inline)) -> float {
+        const int m = m_first + 16 * j;
+        return p.ln_final[(long)(m < p.M ? m : p.M - 1) * 2 + 1];
+      };
+      float rs_next = RSTD_LOAD ? rstd_at(0) : 1.0f;
 #pragma unroll
       for (int j = 0; j < MI; ++j) {
+        const float rs_cur = rs_next;
+        if (RSTD_LOAD && j + 1 < MI) rs_next = rstd_at(j + 1);
         if (m_first + 16 * j < p.M) {
           const int key = MX_VT_POS(key_off + rv);
           bf16_t* dst = p.vt + ((long)bv * nv + feat0) * p.ldvt + key;
-          const float rs = STATS ? ln_rstd_a[j] : 1.0f;
+          const float rs = RSTD_LOAD ? rs_cur : STATS ? ln_rstd_a[j] : 1.0f;
 #pragma unroll
           for (int i = 0; i < NIO; ++i) {
             const f32x4 t = STATS ? acc[i][j] * rs + bias_r[i] : acc[i][j] + bias_r[i];
@@ -612,6 +688,11 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
     }
   }
 
+  auto rstd_at = [&](int j) __attribute__((always_inline)) -> float {
+    const int m = token(j);
+    return p.ln_final[(long)(m < p.M ? m : p.M - 1) * 2 + 1];
+  };
+  float rstd_next = RSTD_LOAD ? rstd_at(0) : 1.0f;
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = token(j);
@@ -619,7 +700,9 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
     float v[NIO][4];
     float rms_mul = 1.0f;
     if constexpr (!VPF) { if (has_rb || has_gate) load_batch_vectors(j); }
-    const float ln_rstd = STATS ? ln_rstd_a[j] : 1.0f;
+    const float rstd_cur = rstd_next;
+    if (RSTD_LOAD && j + 1 < MI) rstd_next = rstd_at(j + 1);
+    const float ln_rstd = RSTD_LOAD ? rstd_cur : STATS ? ln_rstd_a[j] : 1.0f;
     float st1 = 0.f, st2 = 0.f;                // stats_out: this lane's part of the token's sums
     if (rms) {                                 // every lane takes part in the shuffles (masking happens at the store)
       float ss = 0.f;
@@ -759,7 +842,13 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
       if (fq == 0 && m < p.M) {
         const int slab = wave_n0 / (16 * NI), pitch = (p.N / (16 * NI) + 3) & ~3;
-        *reinterpret_cast<f32x2*>(p.stats_out + ((long)m * pitch + slab) * 2) = f32x2{st1, st2};
+        float* dst = p.stats_out + ((long)m * pitch + slab) * 2;
+        if (p.ln_final_out != nullptr) {        // read back inside this launch by the panel's last workgroup (gemm_ln_finalize): write-through (sc1)
+          const unsigned long long bits = (unsigned long long)__float_as_uint(st1) | ((unsigned long long)__float_as_uint(st2) << 32);
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          *reinterpret_cast<f32x2*>(dst) = f32x2{st1, st2};
+        }
       }
     }
   }

@@ -245,6 +245,7 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
     const int bn = cands[c].bn, rows = cands[c].rows;
     if (d->N % bn != 0 || Mtot < rows) continue;
     if (bn == 256 && (conv || !fits32 || d->a2 || d->ln_stats || d->stats_out)) continue;   // (built without those hooks)
+    if (d->ln_final && bn != 256) continue;   // finalised statistics are the 256 x 256 kernel's form of the fold (the others read the slabs)
     if (geglu && bn == 160) continue;
     if (qkv && d->seg % 64 != 0) continue;
     if ((d->flags & MX_EPI_RMSNORM) && bn == 160) continue;   // a 64-wide head must lie inside one wave panel (gemm_epilogue_regs)
@@ -379,6 +380,14 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   a.gate = d->gate; a.ldg = d->ldg; a.out_scale = d->out_scale;
   a.rms_wq = d->rms_wq; a.rms_wk = d->rms_wk; a.rms_eps = d->rms_eps;
   a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum; a.ln_slabs = d->ln_slabs; a.ln_eps = d->ln_eps; a.stats_out = nullptr;
+  a.ln_final = nullptr; a.ln_final_out = nullptr; a.ln_final_cnt = nullptr; a.ln_final_slabs = 0;
+  if (d->ln_final) {
+    MX_CHECK(!conv && !d->ln_stats && d->ln_colsum && d->n_segs == 0, "gemm: ln_final needs ln_colsum, excludes ln_stats and grouped launches (mx_gemm only)");
+    MX_CHECK(!(d->flags & MX_EPI_RMSNORM) && d->a_batch_rows <= 0 && d->c_batch_rows <= 0 && !d->a2 && !d->rowbias && !d->gate && !d->stats_out,
+             "gemm: ln_final excludes RMSNORM, the row remaps, the split A operand, per-sample vectors and stats_out");
+    MX_CHECK((((uintptr_t)d->ln_final & 15) | ((uintptr_t)d->ln_colsum & 15)) == 0, "gemm: ln_final / ln_colsum must be 16-byte aligned");
+    a.ln_final = d->ln_final;
+  }
   a.nseg = d->n_segs; a.mt_total = 0;
   const bool grouped = d->n_segs > 0;
   if (d->ln_stats) {
@@ -439,6 +448,12 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(((uintptr_t)d->stats_out & 15) == 0, "gemm: stats_out must be 16-byte aligned");
     a.stats_out = d->stats_out;
   }
+  if (d->ln_final_out) {
+    MX_CHECK(d->stats_out && d->ln_final_cnt && !grouped && tc.rows == 256 && tc.bn != 256 && tc.bn != 0,
+             "gemm: ln_final_out needs stats_out, ln_final_cnt and an ungrouped launch on a 256-row tile (mx_gemm_ln_final_supported)");
+    MX_CHECK((((uintptr_t)d->ln_final_out & 15) | ((uintptr_t)d->ln_final_cnt & 3)) == 0, "gemm: ln_final_out must be 16-byte aligned");
+    a.ln_final_out = d->ln_final_out; a.ln_final_cnt = d->ln_final_cnt; a.ln_final_slabs = stats_slabs_of(d, conv, tc);
+  }
   if (grouped) {
     // the problems' tiles follow each other in the launch's tile list; the kernel argument's own a is the lowest problem base (the 256 x 256
     // kernel addresses A by 32-bit offsets from it: pick_tile checked the reach)
@@ -493,8 +508,9 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     prof_begin(s, kind, flops, bytes, (int)Mt, d->N, (int)kk);
   }
   const int mt128 = grouped ? a.mt_total : cdiv(d->M, BM);      // m-tiles of the generic kernel
+  if (d->ln_final) MX_CHECK(v2bn == 256, "gemm: ln_final is the 256 x 256 kernel's form of the folded LayerNorm; this shape does not run there (use ln_stats)");
   if (v2bn == 256) {
-    launch_v4(s, a);                                           // 256 x 256 ping-pong (gemm_bf16_v4.hip)
+    MX_CHECK(launch_v4(s, a) == 0, "gemm: no 256 x 256 instantiation serves ln_final with this epilogue (GEGLU, QKV or plain bias only)");   // 256 x 256 ping-pong (gemm_bf16_v4.hip)
   } else if (v2bn) {
     // 256-row tiles: ping-pong schedule (gemm_bf16_v5.hip).  128-row tiles (small M) stay on the lock-step loop of gemm_bf16_v2.hip: the
     // ping-pong form is a tie there (same-box A/B, profiles/r03_d_gemm_bench_small_*: M2048 N1280 K1280 19.3 vs 19.2 us, conv B2 1280@32 98.9 vs
@@ -529,6 +545,13 @@ extern "C" int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d) {
   mx_gemm_desc plain = *d;
   plain.ln_stats = nullptr; plain.stats_out = nullptr;
   return mx::pick_tile(&plain, false).bn == 256;
+}
+extern "C" int mx_gemm_ln_final_supported(const mx_gemm_desc* d) {
+  if (!d || d->n_segs > 0 || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  mx_gemm_desc q = *d;
+  if (!q.stats_out) q.stats_out = reinterpret_cast<float*>(16);      // (shape query: the chooser only looks at which operands exist)
+  const mx::TileChoice tc = mx::pick_tile(&q, false);
+  return tc.rows == 256 && tc.bn != 256 && tc.bn != 0 && mx::stats_slabs_of(&q, false, tc) > 0;
 }
 extern "C" int mx_conv3x3(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, true); }
 extern "C" int mx_gemm_splitk(const mx_gemm_desc* d, int conv) {

@@ -79,7 +79,11 @@ __device__ unsigned long long g_v4_stamps[256 * 2 * 64];
 #endif
 
 // VEC: per-sample vectors (row bias, gate) compiled in; FEAT: gemm_args.h EPI_F_*; GEGLU: the gated epilogue INSTEAD of the plain one
-template <bool VEC, int FEAT, bool GEGLU>
+// LN (round 4): folded LayerNorm from FINALISED row statistics (mxdenoise.h ln_final: 8 bytes per row, written by the producing launch's last
+// workgroup per panel).  Round 3 measured the slab form here (16 slabs per row summed in the hand-over between two tiles): +10-20 us per
+// launch, more than the normalisation pass it replaces; the finalised form needs 8 + 4 loads per lane and tile, requested BEFORE the
+// previous tile's epilogue so that their latency hides behind it.
+template <bool VEC, int FEAT, bool GEGLU, bool LN = false>
 __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   constexpr int NI = 4;                        // 16-wide feature blocks per wave (64 features)
   constexpr int MI = 8;                        // 16-wide token blocks per wave (128 tokens)
@@ -200,6 +204,27 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // position 0 has landed (this thread's part)
   MX_BAR();
 
+  // LN: (mean, rstd) of the lane's eight tokens and the column sums of its 16 features for the NEXT tile, requested before the current tile's
+  // epilogue (dead during the K loop, so they cost the loop nothing); the QKV instantiation has no registers for that and loads at the tile start
+  constexpr bool LN_PF = LN && FEAT != EPI_F_QKV;
+  [[maybe_unused]] f32x2 pst[MI];
+  [[maybe_unused]] f32x4 pcs[NI];
+  auto ln_prefetch = [&](const int t, const bool with_cs) __attribute__((always_inline)) {
+    int tm_i, tn_i;
+    gemm_tile_of_block(t, mt, nt, pk.xcd_map, tm_i, tn_i);
+    if (!with_cs) {
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int m = tm_i * BM4 + wm * 16 * MI + j * 16 + fr;
+        pst[j] = *reinterpret_cast<const f32x2*>(pk.ln_final + (long)(m < pk.M ? m : pk.M - 1) * 2);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) pcs[i] = *reinterpret_cast<const f32x4*>(pk.ln_colsum + tn_i * BN4 + wn * 16 * NI + i * 16 + fq * 4);
+    }
+  };
+  if constexpr (LN_PF) ln_prefetch(blockIdx.x, false);
+
   int rs = 0;                                  // ring slot of XH0 of the K tile being computed (stream index 4 t mod 10)
   for (int tile = blockIdx.x; tile < total_tiles; tile += (int)gridDim.x) {
     f32x4 acc[NI][MI];
@@ -207,7 +232,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float ln_rstd[MI] = {};              // (no folded LayerNorm in this kernel: pick_tile, gemm_bf16.hip)
+    float ln_rstd[MI] = {};                    // (LN == false: unused, the epilogue is built without the rstd multiply)
+    if constexpr (LN_PF) {
+      ln_prefetch(tile, true);                 // the column sums (64 bytes per lane, the same for every token panel: cache-hot) at the tile start
+#pragma unroll
+      for (int j = 0; j < MI; ++j) ln_rstd[j] = pst[j][1];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = pcs[i] * (-pst[j][0]);
+    } else if constexpr (LN) {
+      int tm_i, tn_i;
+      gemm_tile_of_block(tile, mt, nt, pk.xcd_map, tm_i, tn_i);
+      gemm_ln_init_final<NI, MI, FEAT != EPI_F_QKV>(pk, acc, tm_i * BM4 + wm * 16 * MI, tn_i * BN4 + wn * 16 * NI, fr, fq, ln_rstd);
+    }
 
     if (wm == 1) MX_BAR();                     // wave row 1 runs one barrier behind row 0
     MX_STAMP(stamp_i);
@@ -277,7 +315,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
     GemmArgs p = pk;
     gemm_select_seg(p, pk, tm);
     const int m0 = tm * BM4, n0 = tn * BN4;
-    gemm_epilogue_regs<NI, MI, GEGLU, VEC, false, false, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
+    if constexpr (LN_PF) { if (tile + (int)gridDim.x < total_tiles) ln_prefetch(tile + (int)gridDim.x, false); }
+    gemm_epilogue_regs<NI, MI, GEGLU, VEC, false, LN, FEAT, false, LN && FEAT == EPI_F_QKV>(p, acc, m0 + wm * 16 * MI, n0 + wn * 16 * NI, fr, fq, ln_rstd);
     MX_STAMP(stamp_i + 2);
     stamp_i += 3;
   }
@@ -296,6 +335,13 @@ int launch_v4(hipStream_t s, const GemmArgs& a) {
   const bool vec = a.rowbias || a.gate;
   const int feat = gemm_epi_features(a.flags);
 #define MX_V4(VEC_, FEAT_, GEGLU_) hipLaunchKernelGGL((gemm_v4_kernel<VEC_, FEAT_, GEGLU_>), grid, block, 0, s, a)
+  if (a.ln_final != nullptr) {                 // the folded LayerNorm's instantiations: GEGLU / QKV / plain, no per-sample vectors (the launcher checked)
+    if ((a.flags & MX_EPI_GEGLU) && !(feat & EPI_F_ACT)) hipLaunchKernelGGL((gemm_v4_kernel<false, 0, true, true>), grid, block, 0, s, a);
+    else if (!(a.flags & MX_EPI_GEGLU) && feat == EPI_F_QKV) hipLaunchKernelGGL((gemm_v4_kernel<false, EPI_F_QKV, false, true>), grid, block, 0, s, a);
+    else if (!(a.flags & MX_EPI_GEGLU) && feat == 0) hipLaunchKernelGGL((gemm_v4_kernel<false, 0, false, true>), grid, block, 0, s, a);
+    else return 1;
+    return 0;
+  }
   if (a.flags & MX_EPI_GEGLU) {
     if (feat & EPI_F_ACT) MX_V4(false, EPI_F_ACT, true); else MX_V4(false, 0, true);      // (the gated epilogue takes no per-sample vectors)
   } else if (!vec) {

@@ -266,6 +266,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   gemm_epilogue_regs<NI, MI, GEGLU, VEC, true, true, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
   MX5_STAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the past-the-end DMAs are drained before the workgroup retires
+  if constexpr (!CONV && !GEGLU && BM5 == 256) {      // finalised row statistics: the last workgroup of the 256-row panel folds its slabs (gemm_args.h)
+    if (pk.ln_final_out != nullptr) gemm_ln_finalize(p, tm, pk.N / BN, reinterpret_cast<volatile int*>(smem));
+  }
 }
 
 // bn: 160 or 128 features per tile; rows: 256, or 128 when the 256-row tiling would leave most CUs idle (small M)

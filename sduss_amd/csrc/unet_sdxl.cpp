@@ -347,32 +347,40 @@ struct Plan {
     return true;
   }
   // row statistics (sum, sum of squares per row and slab) of the hidden states: what the folded LayerNorms read (mx_gemm_desc.ln_stats)
-  struct RowStats { float* buf = nullptr; int slabs = 0; };
+  // fin / cnt: the FINALISED form (mean, rstd per row: mx_gemm_desc.ln_final) for consumers on the 256 x 256 kernel; cnt = the producers' panel tickets
+  struct RowStats { float* buf = nullptr; int slabs = 0; float* fin = nullptr; unsigned* cnt = nullptr; };
+  unsigned* ln_cnt = nullptr;     // panel tickets of the finalising producers: zeroed once per run, every launch leaves them zero
+  static constexpr int kLnCnt = 4096;
   // launch d; the statistics of its output rows go to st (from the epilogue when the chosen kernel can, else a pass over the output)
-  bool gemm_with_stats(mx_gemm_desc& d, RowStats& st) {
+  bool gemm_with_stats(mx_gemm_desc& d, RowStats& st, bool finalise = false) {
     if (!ok()) return false;
     const int slabs = mx_gemm_stats_slabs(&d);
+    if (finalise) {
+      if (slabs <= 0 || !mx_gemm_ln_final_supported(&d) || (d.M + 255) / 256 > kLnCnt) return fail("finalised row statistics: the producing launch cannot write them");
+      d.ln_final_out = st.fin; d.ln_final_cnt = st.cnt; d.ln_eps = u->cfg.layer_norm_eps;
+    }
     if (slabs > 0) { d.stats_out = st.buf; st.slabs = slabs; return gemm(d, false); }
     st.slabs = 1;
     if (!gemm(d, false)) return false;
     if (!quiet() && mx_row_stats(stream, d.c, d.ldc, st.buf, d.M, d.N)) return fail(std::string("row_stats: ") + mx_last_error());
     return true;
   }
-  void use_ln(mx_gemm_desc& d, const RowStats& st, const std::string& csname) {
-    d.ln_stats = st.buf; d.ln_slabs = st.slabs; d.ln_colsum = wf(csname, d.N); d.ln_eps = u->cfg.layer_norm_eps;
+  void use_ln(mx_gemm_desc& d, const RowStats& st, const std::string& csname, bool final = false) {
+    if (final) d.ln_final = st.fin; else { d.ln_stats = st.buf; d.ln_slabs = st.slabs; }
+    d.ln_colsum = wf(csname, d.N); d.ln_eps = u->cfg.layer_norm_eps;
   }
   // ln: the A operand is the UN-normalised hidden state and the LayerNorm in front of this linear is folded into it (weights.py
   // fold_layernorm): statistics ln, column sums `wname`-stem + ".colsum".  stats_out: also produce the statistics of the output rows.
   bool linear(const bf16_t* a, int lda, const std::string& wname, const std::string& bname, void* c, int ldc, int M, int N,
               int K, const void* residual = nullptr, int ldr = 0, int flags = 0, float out_scale = 0.f, const bf16_t* a2 = nullptr, int lda2 = 0,
-              const RowStats* ln = nullptr, RowStats* stats_out = nullptr) {
+              const RowStats* ln = nullptr, RowStats* stats_out = nullptr, bool ln_final = false, bool finalise = false) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
     d.out_scale = out_scale;
     if (a2) { d.a2 = a2; d.lda2 = lda2; d.k_split = lda; }      // A = [a | a2] along K, read in place
     d.a = a; d.lda = lda; d.w = wb(wname, (size_t)N * K); d.bias = bname.empty() ? nullptr : wf(bname, N);
     d.c = c; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.residual = residual; d.ldr = ldr; d.flags = flags;
-    if (ln) use_ln(d, *ln, wname.substr(0, wname.size() - 6) + "colsum");      // "<stem>.weight" -> "<stem>.colsum"
-    if (stats_out) return gemm_with_stats(d, *stats_out);
+    if (ln) use_ln(d, *ln, wname.substr(0, wname.size() - 6) + "colsum", ln_final);      // "<stem>.weight" -> "<stem>.colsum"
+    if (stats_out) return gemm_with_stats(d, *stats_out, finalise);
     return gemm(d, false);
   }
   // 3x3 conv over the images of every group at the current level (Hin, Win: the first group's size; the others come from ch / cw).  A mixed
@@ -597,12 +605,29 @@ struct Plan {
       pass1 = mx_gemm_ln_prefers_pass(&d1) != 0; pass2 = mx_gemm_ln_prefers_pass(&d2) != 0; pass3 = mx_gemm_ln_prefers_pass(&d3) != 0;
     }
     if (pc) pass1 = pass2 = pass3 = true;   // the hidden state of a masked layer is produced by the state-merge kernel, which leaves no row statistics
+    // Round 4: where the consumer runs on the 256 x 256 kernel (pass1 / pass3) and the launches that write the hidden state in front of it can
+    // FINALISE the row statistics (256-row tiles: mx_gemm_ln_final_supported), the pass disappears as well: the producer's last workgroup per
+    // panel leaves (mean, rstd) per row and the consumer starts its accumulators from those 8 bytes (mx_gemm_desc.ln_final).  One resolution
+    // group, no patch cache, not patch-parallel (their hidden states come from other kernels / are compared bit for bit with the unsplit run).
+    bool fin1 = false, fin3 = false;
+    if (ng == 1 && !pc && !is_pp() && ln_cnt != nullptr && (M + 255) / 256 <= kLnCnt) {
+      auto can_finalise = [&](int K, bool residual) {
+        mx_gemm_desc d = lin_desc(y, y, C, C, 0, 0.f);
+        d.K = K; d.lda = K; if (residual) { d.residual = y; d.ldr = C; }
+        return mx_gemm_ln_final_supported(&d) != 0;
+      };
+      fin1 = pass1 && can_finalise(C, false) && (layers == 1 || can_finalise(4 * C, true));
+      fin3 = pass3 && can_finalise(C, true);
+      if (fin1 || fin3) { st.fin = (float*)ar.alloc((size_t)M * 2 * sizeof(float)); st.cnt = ln_cnt; if (!st.fin) fail("workspace too small"); }
+    }
+    if (fin1) pass1 = false;
+    if (fin3) pass3 = false;
     bf16_t* pqc = nullptr; bf16_t* paoc = nullptr; bf16_t* ptc = nullptr;     // patch-unit cache: compact queries / attention output / projection output
     if (pc) { pqc = alloc<bf16_t>((size_t)M * C); paoc = alloc<bf16_t>((size_t)M * C); ptc = alloc<bf16_t>((size_t)M * C); }
     auto normalise = [&]() {      // ln = (y - mean) * rstd, no affine (it lives in the folded weights)
       if (ok() && !quiet() && mx_layernorm(stream, y, ln, nullptr, nullptr, M, C, u->cfg.layer_norm_eps)) fail(std::string("layernorm: ") + mx_last_error());
     };
-    linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, pass1 ? nullptr : &st);
+    linear(n, C, p + ".proj_in.weight", p + ".proj_in.bias", y, C, M, C, C, nullptr, 0, 0, 0.f, nullptr, 0, nullptr, pass1 ? nullptr : &st, false, fin1);
     // patch-parallel: every rank gathers the other ranks' K rows and V^T columns (modules/pp/attn.py:137: all_gather(kv))
     // -- K alone travels: the QKV epilogue writes q|k interleaved, so the K halves are packed into a contiguous send buffer first
     bf16_t* k_send = nullptr; bf16_t* k_all = nullptr; bf16_t* vt_all = nullptr;
@@ -688,7 +713,7 @@ struct Plan {
       {
         if (pass1) normalise();
         mx_gemm_desc d = qkv_desc(b, pass1 ? ln : y);
-        if (!pass1) { use_ln(d, st, b + ".attn1.to_qkv.colsum"); use_ln_grouped(d, st); } else wf(b + ".attn1.to_qkv.colsum", 3 * C);
+        if (!pass1) { use_ln(d, st, b + ".attn1.to_qkv.colsum", fin1); if (!fin1) use_ln_grouped(d, st); } else wf(b + ".attn1.to_qkv.colsum", 3 * C);
         gemm(d, false);
       }
       if (is_pp()) {
@@ -729,13 +754,13 @@ struct Plan {
         attention(q2, C, kvp->k + (size_t)li * C, kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, kvp->ldvt, kvp->vt_bstride,
                   ao, C, heads, L, ctx_len);
       }
-      linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, pass3 ? nullptr : &st);
+      linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, pass3 ? nullptr : &st, false, fin3);
       // GEGLU feed-forward (norm3 in the GEGLU projection)
       if (pass3) normalise();
       linear(pass3 ? ln : y, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU, 0.f, nullptr, 0,
-             pass3 ? nullptr : &st);
+             pass3 ? nullptr : &st, nullptr, fin3);
       linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C, 0, 0.f, nullptr, 0, nullptr,
-             (k + 1 < layers && !pass1) ? &st : nullptr);
+             (k + 1 < layers && !pass1) ? &st : nullptr, false, fin1 && k + 1 < layers);
     }
     linear(y, C, p + ".proj_out.weight", p + ".proj_out.bias", out, C, M, C, C, x, C);
     ar.release(m0);
@@ -754,6 +779,9 @@ struct Plan {
     const int addw = c.projection_class_embeddings_input_dim;
     const int ctx = c.cross_attention_dim;
 
+    // panel tickets of the producers that finalise LayerNorm statistics (transformer()): zero once, every launch leaves them zero
+    ln_cnt = (unsigned*)ar.alloc((size_t)kLnCnt * sizeof(unsigned));
+    if (ok() && !quiet() && ln_cnt && hipMemsetAsync(ln_cnt, 0, (size_t)kLnCnt * sizeof(unsigned), stream) != hipSuccess) fail("ln tickets: memset failed");
     // ---- time / added-condition embeddings (unet.py:314-341) ----
     bf16_t* tsin = alloc<bf16_t>((size_t)B * C0);
     bf16_t* addin = alloc<bf16_t>((size_t)B * addw);

@@ -23,12 +23,17 @@ def _bf16(t):
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, silu: bool = False, geglu: bool = False,
          out_f32: bool = False, out_scale: float = 0.0, ln_stats: Optional[torch.Tensor] = None, ln_colsum: Optional[torch.Tensor] = None,
-         ln_eps: float = 1e-5, want_stats: bool = False, splitk: int = 0):
+         ln_eps: float = 1e-5, want_stats: bool = False, splitk: int = 0, ln_final: Optional[torch.Tensor] = None, want_final: bool = False,
+         final_buffers=None):
     """C[M,N] = (A[M,K] W[N,K]^T + bias) * out_scale (+rowbias +residual, silu | geglu).  With ``geglu`` the weight/bias rows must be
     interleaved as weights._geglu_interleave does; the output is [M, N/2].
     ``ln_stats`` = (stats [M, pitch, 2], slabs) + ``ln_colsum`` [N]: LayerNorm folded into this GEMM (w, bias folded by
     weights.fold_layernorm).  ``want_stats``: also return the row statistics of C as such a pair (from the epilogue when the kernel can,
-    else mx_row_stats); entries past ``slabs`` of a row are not initialised."""
+    else mx_row_stats); entries past ``slabs`` of a row are not initialised.
+    ``want_final`` (with ``want_stats``): also return the FINALISED statistics [M, 2] = (mean, rstd with ``ln_eps``) the launch's last workgroup per
+    256-row panel leaves (mx_gemm_desc.ln_final_out), or None where the launch cannot (mx_gemm_ln_final_supported); ``ln_final`` + ``ln_colsum``:
+    the consumer side (the 256 x 256 kernel's form of the folded LayerNorm).  ``final_buffers`` = (final [M, 2] fp32, tickets [ceil(M / 256)] int32,
+    zero): reuse these instead of allocating (and skip the host-side check of the tickets, which synchronises)."""
     l = _lib.load()
     _bf16(a); _bf16(w)
     m, k = a.shape
@@ -48,16 +53,31 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         st_, slabs_ = ln_stats
         assert st_.dtype == torch.float32 and ln_colsum.dtype == torch.float32 and st_.shape == (m, stats_pitch(slabs_), 2)
         d.ln_stats, d.ln_colsum, d.ln_slabs, d.ln_eps = st_.data_ptr(), ln_colsum.data_ptr(), slabs_, ln_eps
+    if ln_final is not None:
+        assert ln_final.dtype == torch.float32 and ln_final.shape == (m, 2) and ln_colsum.dtype == torch.float32
+        d.ln_final, d.ln_colsum, d.ln_eps = ln_final.data_ptr(), ln_colsum.data_ptr(), ln_eps
     stats = None
+    final = None
     if want_stats:
         slabs = l.mx_gemm_stats_slabs(C.byref(d))
         stats = torch.full((m, stats_pitch(max(slabs, 1)), 2), float("nan"), dtype=torch.float32, device=a.device)
         if slabs > 0:
             d.stats_out = stats.data_ptr()
+            if want_final and l.mx_gemm_ln_final_supported(C.byref(d)):
+                if final_buffers is not None:
+                    final, cnt = final_buffers
+                else:
+                    final = torch.full((m, 2), float("nan"), dtype=torch.float32, device=a.device)
+                    cnt = torch.zeros((m + 255) // 256, dtype=torch.int32, device=a.device)
+                d.ln_final_out, d.ln_final_cnt, d.ln_eps = final.data_ptr(), cnt.data_ptr(), ln_eps
     _lib.check(l.mx_gemm(_lib.current_stream(), C.byref(d)), "mx_gemm")
     if want_stats:
         if not d.stats_out:
             _lib.check(l.mx_row_stats(_lib.current_stream(), c.data_ptr(), nout, stats.data_ptr(), m, nout), "mx_row_stats")
+        if want_final:
+            if final is not None and final_buffers is None:
+                assert int(cnt.abs().sum()) == 0, "ln_final_cnt must be zero again after the launch"
+            return c, (stats, max(slabs, 1)), final
         return c, (stats, max(slabs, 1))
     return c
 
@@ -103,7 +123,7 @@ def unpack_vt(vt: torch.Tensor, lk: int) -> torch.Tensor:
 
 def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_batch: int, q_scale: float = 0.0,
              ln_stats: Optional[torch.Tensor] = None, ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-             bias: Optional[torch.Tensor] = None):
+             bias: Optional[torch.Tensor] = None, ln_final: Optional[torch.Tensor] = None):
     """Fused projection with the V segments written transposed.  Returns (c [M, N/period*(period-1)],
     vt [M/rows_per_batch, N/period, ldvt] in MX_VT_POS key order; see unpack_vt)."""
     l = _lib.load()
@@ -122,6 +142,8 @@ def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_b
     d.bias = _p(bias)
     if ln_stats is not None:
         d.ln_stats, d.ln_colsum, d.ln_slabs, d.ln_eps = ln_stats[0].data_ptr(), ln_colsum.data_ptr(), ln_stats[1], ln_eps
+    if ln_final is not None:
+        d.ln_final, d.ln_colsum, d.ln_eps = ln_final.data_ptr(), ln_colsum.data_ptr(), ln_eps
     _lib.check(l.mx_gemm(_lib.current_stream(), C.byref(d)), "mx_gemm(qkv)")
     return c, vt
 

@@ -115,3 +115,90 @@ def test_row_stats_from_the_producing_epilogue(cuda_device, m, k, n):
     got = ops.gemm(y, wf.cuda(), bf_.cuda(), ln_stats=st, ln_colsum=colsum.cuda())
     want = F.layer_norm(yf, (n,), gamma, beta, 1e-5) @ w2.t()
     _close(got, want, 2.0 ** -7, f"producer stats -> folded consumer {m}x{k}->{n}")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# FINALISED row statistics (round 4, mx_gemm_desc.ln_final): the producer's last workgroup per 256-row panel leaves (mean, rstd) per row and the
+# 256 x 256 kernel folds the LayerNorm from those 8 bytes
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,k,n", [(8192, 1280, 1280), (8192, 5120, 1280), (9000, 640, 640), (32768, 2560, 640)])
+def test_finalised_row_statistics_of_the_producer(cuda_device, m, k, n):
+    """(mean, rstd) per row from the producing launch itself: equal to the moments of the rows it stored (to the bf16 rounding noise of a row),
+    bit-identical run to run (the slabs are added in slab order whichever workgroup arrives last), tickets back at zero, slabs still written"""
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(m + k + n)
+    a = _rt(torch.randn(m, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5); bias = torch.randn(n, generator=g)
+    res = _hidden(g, m, n)
+    ag, wg, bg, rg = _bf(a).cuda(), _bf(w).cuda(), bias.cuda(), _bf(res).cuda()
+    y, st, fin = ops.gemm(ag, wg, bg, residual=rg, want_stats=True, want_final=True, ln_eps=1e-5)      # (asserts the tickets are zero again)
+    assert fin is not None, "a 256-row tile serves this shape: the launch must be able to finalise"
+    yf = y.float().cpu()
+    mean, rstd = yf.mean(dim=1), (yf.var(dim=1, unbiased=False) + 1e-5).rsqrt()
+    f = fin.cpu()
+    assert torch.isfinite(f).all()
+    assert (f[:, 0] - mean).abs().max().item() <= 2.0 ** -8 * yf.abs().mean(dim=1).max().item()
+    assert ((f[:, 1] - rstd).abs() / rstd).max().item() <= 2.0 ** -8
+    buf, slabs = st
+    assert torch.isfinite(buf[:, :slabs]).all()
+    for _ in range(3):
+        y2, _st2, fin2 = ops.gemm(ag, wg, bg, residual=rg, want_stats=True, want_final=True, ln_eps=1e-5)
+        assert torch.equal(fin2, fin) and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("m,c,kind", [(8192, 1280, "geglu"), (8192, 1280, "qkv"), (16384, 640, "geglu"), (8192, 1280, "plain"), (9000, 640, "plain")])
+def test_ln_folded_from_finalised_statistics(cuda_device, m, c, kind):
+    """producer (to_out / ff.net.2 shape, with the residual) -> finalised statistics -> consumer on the 256 x 256 kernel, against LayerNorm -> linear in
+    fp32 on the rows the producer stored; GEGLU (norm3), the fused q | k | v projection (norm1) and a plain linear"""
+    from sduss_amd import lib, ops
+    from sduss_amd.weights import _geglu_interleave, fold_layernorm
+    g = torch.Generator().manual_seed(m + c + len(kind))
+    a = _rt(torch.randn(m, c, generator=g)); w0 = _rt(torch.randn(c, c, generator=g) * c ** -0.5); b0 = torch.randn(c, generator=g)
+    res = _hidden(g, m, c)
+    y, _st, fin = ops.gemm(_bf(a).cuda(), _bf(w0).cuda(), b0.cuda(), residual=_bf(res).cuda(), want_stats=True, want_final=True, ln_eps=1e-5)
+    assert fin is not None
+    yf = y.float().cpu()
+    gamma, beta = _ln_params(g, c)
+    ln = F.layer_norm(yf, (c,), gamma, beta, 1e-5)
+    from test_headline_shapes_gpu import _records
+    rec, out = [], {}
+    def run(fn):
+        rec.extend(_records(lambda: out.__setitem__("o", fn())))
+        return out["o"]
+    if kind == "geglu":
+        w = _rt(torch.randn(8 * c, c, generator=g) * c ** -0.5); b = torch.randn(8 * c, generator=g)
+        hid, gate = (ln @ w.t() + b).chunk(2, dim=-1)
+        want = hid * F.gelu(gate)
+        wf, colsum, bf_ = fold_layernorm(_geglu_interleave(w), _geglu_interleave(b), gamma, beta)
+        got = run(lambda: ops.gemm(y, wf.cuda(), bf_.cuda(), geglu=True, ln_final=fin, ln_colsum=colsum.cuda()))
+        _close(got, want, 2.0 ** -7, f"finalised ln -> geglu {m}x{c}")
+    elif kind == "qkv":
+        rows = 1024
+        w = _rt(torch.randn(3 * c, c, generator=g) * c ** -0.5)
+        want = ln @ w.t()
+        wf, colsum, bf_ = fold_layernorm(w, None, gamma, beta)
+        cq, vt = run(lambda: ops.gemm_qkv(y, wf.cuda(), c, 3, rows, q_scale=0.25, ln_final=fin, ln_colsum=colsum.cuda(), bias=bf_.cuda()))
+        _close(cq[:, :c], want[:, :c] * 0.25, 2.0 ** -7, "finalised ln -> q")
+        _close(cq[:, c:], want[:, c:2 * c], 2.0 ** -7, "finalised ln -> k")
+        _close(ops.unpack_vt(vt, rows).reshape(m, c), want[:, 2 * c:], 2.0 ** -7, "finalised ln -> v^T")
+    else:
+        n = 1024
+        w = _rt(torch.randn(n, c, generator=g) * c ** -0.5); b = 0.1 * torch.randn(n, generator=g)
+        want = ln @ w.t() + b
+        wf, colsum, bf_ = fold_layernorm(w, b, gamma, beta)
+        got = run(lambda: ops.gemm(y, wf.cuda(), bf_.cuda(), ln_final=fin, ln_colsum=colsum.cuda()))
+        _close(got, want, 2.0 ** -7, f"finalised ln -> linear {m}x{c}->{n}")
+    assert len(rec) == 1 and rec[0][0] == "gemm_256x256", rec       # the fold ran on the 256 x 256 kernel
+
+
+def test_ln_final_is_refused_where_the_256x256_kernel_does_not_run(cuda_device):
+    from sduss_amd import lib, ops
+    g = torch.Generator().manual_seed(3)
+    # a small launch takes 128-row tiles, which do not finalise: the caller is told (None) and keeps the slabs
+    a = _bf(torch.randn(2048, 1280, generator=g)).cuda(); w0 = _bf(torch.randn(1280, 1280, generator=g) * 0.03).cuda()
+    _y, (_buf, slabs), fin0 = ops.gemm(a, w0, None, want_stats=True, want_final=True)
+    assert fin0 is None and slabs > 0
+    y = _bf(torch.randn(512, 640, generator=g)).cuda()
+    w = _bf(torch.randn(1920, 640, generator=g)).cuda()            # 1920 % 256 != 0: a 160-wide tile serves it, which reads the slabs
+    fin = torch.zeros(512, 2, device="cuda"); cs = torch.zeros(1920, device="cuda")
+    with pytest.raises(lib.MxError, match="ln_final"):
+        ops.gemm(y, w, None, ln_final=fin, ln_colsum=cs)
