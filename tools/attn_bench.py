@@ -16,6 +16,11 @@ if os.environ.get("ATTN_SHAPES") == "cross":      # the short-key launches of a 
     SHAPES = [(8, 20, 1024, 77), (2, 20, 1024, 77), (8, 10, 4096, 77), (2, 10, 4096, 77), (8, 20, 576, 77), (8, 20, 256, 77)]
 
 
+if os.environ.get("ATTN_SHAPES") == "l1024":      # L = 1024 self-attention at workgroup counts around whole rounds of 3 per CU (768): 384, 640, 768, 1280, 1536, 2304, 2560
+    SHAPES = [(8, 6, 1024, 1024), (8, 10, 1024, 1024), (8, 12, 1024, 1024), (8, 20, 1024, 1024), (8, 24, 1024, 1024), (8, 36, 1024, 1024), (16, 20, 1024, 1024),
+              (8, 20, 2048, 2048), (8, 20, 512, 512)]
+
+
 def main():
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
