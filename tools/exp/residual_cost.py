@@ -1,5 +1,8 @@
 """What the residual costs a single-round 256 x 160 launch (round 4): the same GEMM with and without the residual operand, and with the row statistics / their
-finalisation on top (to_out / ff.net.2 as the step launches them).  Upper bound of what staging the residual through the K loop's idle LDS-DMA slots could save.
+finalisation on top (to_out / ff.net.2 as the step launches them).  "residual (no prefetch)" / "residual" differed in an experimental build whose two past-the-end
+LDS-DMA groups fetched the tile's residual (into LDS stages nobody reads: an L2 prefetch for the epilogue's loads) instead of the zero page -- 0.5-1.7 us per launch,
+nothing on the step (profiles/r04_u_residual_prefetch.txt); not kept, with the shipped library both columns time the same launch.  The "+stats" columns include a
+1-MB torch fill of the statistics buffer per call.
 Usage on the GPU box: python tools/exp/residual_cost.py"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
