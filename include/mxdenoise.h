@@ -203,6 +203,10 @@ typedef struct mx_gemm_desc {
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
+/* 2 where mx_gemm cuts d along N (TAIL SPLIT: a launch of the persistent 256 x 256 kernel whose last round would be less than half full -- one
+ * 1024 px request's GEGLU projection is 1.25 rounds -- runs its whole rounds there and the remaining column panels as ONE round of a smaller tile;
+ * plain / gated epilogues, ungrouped, no statistics), else 1.  Shape-based and host-only. */
+int mx_gemm_launches(const mx_gemm_desc* d);
 int mx_gemm_stats_slabs(const mx_gemm_desc* d);        /* slabs d->stats_out receives from mx_gemm(d); 0 = not supported for this shape */
 /* 1 when mx_gemm(d) with ln_stats would run on the persistent 256 x 256 kernel, where applying the statistics costs more than a separate
  * normalisation pass saves (10-20 us per launch in the hand-over between two tiles against an 11-us pass at M = 8192); the step plan then

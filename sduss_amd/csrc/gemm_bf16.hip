@@ -533,7 +533,50 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
 
 }  // namespace mx
 
-extern "C" int mx_gemm(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, false); }
+namespace mx {
+// TAIL SPLIT (round 4).  The persistent 256 x 256 kernel walks whole rounds of one tile per CU; a launch whose tile count leaves a short last round
+// (one 1024 px request: GEGLU M 2048 x N 10240 = 320 tiles = 1.25 rounds, 77 us for 1.25 rounds of work) pays a full round for it.  Where the tiles
+// of the whole rounds are whole column panels, the launch is cut along N: columns [0, N1) keep the 256 x 256 kernel in whole rounds, the rest
+// becomes a second launch on whatever tile the chooser gives it, accepted only if that is ONE round of a cheaper tile (128 x 128 / 128 x 160 /
+// 256 x 128).  Columns are independent, so the results are those of the single launch bit for bit where both tilings add a row's products in
+// the same order (every unsplit tiling does).  Plain and gated epilogues only (no QKV segments, statistics, fp32 output, grouped launches).
+static bool tail_split(const mx_gemm_desc* d, mx_gemm_desc& d1, mx_gemm_desc& d2) {
+  if (d->n_segs != 0 || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->N % 256 != 0) return false;
+  if (d->flags & (MX_EPI_QKV | MX_EPI_OUT_F32 | MX_EPI_RES_BCAST | MX_EPI_RMSNORM)) return false;
+  if (d->stats_out || d->ln_stats || d->ln_final || d->ln_final_out || d->a_batch_rows > 0 || d->c_batch_rows > 0 || d->splitk > 1) return false;
+  if (pick_tile(d, false).bn != 256) return false;
+  const int ncu = cu_count();
+  if (ncu <= 0) return false;
+  const long mt = cdiv(d->M, 256), nt = d->N / 256, tiles = mt * nt;
+  const long full = tiles / ncu, rem = tiles % ncu;
+  if (full < 1 || rem == 0 || rem * 2 > ncu || (full * ncu) % mt != 0) return false;
+  const long nt1 = full * ncu / mt;
+  if (nt1 <= 0 || nt1 >= nt) return false;
+  const int N1 = (int)nt1 * 256, N2 = d->N - N1;
+  const bool geglu = (d->flags & MX_EPI_GEGLU) != 0;
+  const long cofs = geglu ? N1 / 2 : N1;       // first output column of the second launch
+  d1 = *d; d2 = *d;
+  d1.N = N1; d2.N = N2;
+  d2.w = (const char*)d->w + (size_t)N1 * d->K * 2;
+  if (d->bias) d2.bias = d->bias + N1;
+  d2.c = (char*)d->c + (size_t)cofs * 2;
+  if (d->residual) d2.residual = (const char*)d->residual + (size_t)N1 * 2;
+  if (d->rowbias) d2.rowbias = d->rowbias + N1;
+  if (d->gate) d2.gate = d->gate + N1;
+  const TileChoice t2 = pick_tile(&d2, false);
+  if (t2.bn == 0 || t2.bn == 256 || t2.rows + t2.bn > 384) return false;
+  if (m_tiles_of(&d2, t2.rows) * (N2 / t2.bn) > ncu) return false;
+  return pick_tile(&d1, false).bn == 256;
+}
+}  // namespace mx
+
+extern "C" int mx_gemm(void* stream, const mx_gemm_desc* d) {
+  mx_gemm_desc d1, d2;
+  if (d != nullptr && mx::tail_split(d, d1, d2)) { if (int rc = mx::launch(stream, &d1, false)) return rc; return mx::launch(stream, &d2, false); }
+  return mx::launch(stream, d, false);
+}
+/* launches mx_gemm(d) issues: 2 where the tail split applies (tests, planning) */
+extern "C" int mx_gemm_launches(const mx_gemm_desc* d) { mx_gemm_desc d1, d2; return d != nullptr && mx::tail_split(d, d1, d2) ? 2 : 1; }
 extern "C" int mx_gemm_stats_slabs(const mx_gemm_desc* d) {
   if (!d || mx::rows_of(d) <= 0 || d->N <= 0 || d->K <= 0) return 0;
   mx_gemm_desc q = *d;

@@ -185,6 +185,7 @@ SYMBOLS = {
     "mx_unet_block_cache_bytes": (_sz, [_vp, _i, _i, _i]),
     "mx_gemm_splitk": (_i, [_vp, _i]),
     "mx_gemm_ln_final_supported": (_i, [C.POINTER(GemmDesc)]),
+    "mx_gemm_launches": (_i, [C.POINTER(GemmDesc)]),
     "mx_unet_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_mmdit_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "mx_mmdit_workspace_bytes_cached_mixed": (_sz, [_vp, C.POINTER(UNetGroup), _i, _i, _i]),

@@ -529,3 +529,35 @@ def test_conv3x3_splitk(cuda_device):
     _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, "split-K conv3x3")
     again = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(w)).cuda(), bias.cuda(), splitk=3)
     assert torch.equal(again.view(torch.int16), got.view(torch.int16))
+
+
+def test_gemm_tail_split_of_the_256x256_kernel(cuda_device):
+    """One 1024 px request's GEGLU projection (M 2048, N 10240, K 1280 = 320 tiles of 256 x 256 = 1.25 rounds): mx_gemm cuts it along N into the whole
+    round on the 256 x 256 kernel and ONE round of a smaller tile (mx_gemm_launches == 2).  The result is that of LayerNorm-free GEGLU in fp32 and is bit
+    for bit what the same rows give inside the headline batch's launch (M 8192: whole rounds, one launch): no tiling changes a row's summation order."""
+    import ctypes as C
+    from sduss_amd import lib, ops
+    from sduss_amd.weights import _geglu_interleave
+    from test_headline_shapes_gpu import _records
+    g = torch.Generator().manual_seed(2048)
+    m, dim = 2048, 1280
+    a = _rt(torch.randn(m, dim, generator=g)); w = _rt(torch.randn(8 * dim, dim, generator=g) * dim ** -0.5); b = torch.randn(8 * dim, generator=g)
+    hid, gate = (a @ w.t() + b).chunk(2, dim=-1)
+    want = hid * F.gelu(gate)
+    ag, wg, bg = _bf(a).cuda(), _bf(_geglu_interleave(w)).cuda(), _geglu_interleave(b).cuda()
+    out = {}
+    rec = _records(lambda: out.__setitem__("o", ops.gemm(ag, wg, bg, geglu=True)))
+    assert [r[0] for r in rec].count("gemm_256x256") == 1 and len(rec) == 2, rec
+    assert sum(r[2] for r in rec) == 8 * dim and rec[0][2] == 8192, rec          # columns [0, 8192) in whole rounds, the rest on the smaller tile
+    _close(out["o"], want, 2.0 ** -7, "tail-split geglu")
+    big = ops.gemm(ag.repeat(4, 1), wg, bg, geglu=True)                          # M 8192: 1280 tiles = 5 whole rounds, one launch
+    assert torch.equal(big[:m], out["o"]) and torch.equal(big[3 * m:], out["o"])
+    # plain epilogue with a residual, M 4096 x N 10240: 640 tiles = 2.5 rounds -> 2 rounds + one round of 256 x 128
+    r = _rt(torch.randn(2 * m, 8 * dim, generator=g))
+    a2 = _rt(torch.randn(2 * m, dim, generator=g))
+    d = lib.GemmDesc(); d.M, d.N, d.K, d.lda, d.ldc, d.ldr = 2 * m, 8 * dim, dim, dim, 8 * dim, 8 * dim
+    d.a = d.w = d.c = d.residual = 256
+    n_launch = lib.load().mx_gemm_launches(C.byref(d))
+    got = ops.gemm(_bf(a2).cuda(), _bf(w).cuda(), b.cuda(), residual=_bf(r).cuda())
+    _close(got, a2 @ w.t() + b + r, 2.0 ** -7, f"tail-split plain + residual ({n_launch} launches)")
+    assert n_launch == 2
