@@ -59,8 +59,11 @@ struct GraphCache {
 
   // body(stream) enqueues the plan on `stream` and returns true on success.  Returns true if the work was enqueued (by
   // replay or eagerly); false if body failed (its error is already recorded).
+  // capture_on_miss == false (the mixed-resolution forwards: their key holds every group's pointers and batch sizes, which under continuous batching of
+  // a mixed stream rarely repeat): a miss runs eagerly, captures nothing and does NOT count towards the streak that switches the handle's cache off --
+  // otherwise a mixed stream would disable the replay of the fixed-composition forwards of the same handle (advisor, round 3).
   template <class F>
-  bool run(hipStream_t user, const std::vector<uint64_t>& key, F&& body) {
+  bool run(hipStream_t user, const std::vector<uint64_t>& key, F&& body, bool capture_on_miss = true) {
     if (disabled || !env_on() || prof_enabled()) { ++n_eager; return body(user); }
     hipStream_t s = user;
     const bool forked = (user == nullptr);
@@ -76,6 +79,7 @@ struct GraphCache {
     hipGraphExec_t exec = nullptr;
     for (auto& e : entries)
       if (e.key == key) { exec = e.exec; e.stamp = ++clock; e.last = s; break; }
+    if (!exec && !capture_on_miss) { ++n_eager; return body(user); }
     if (!exec) {
       if (++miss_streak > 16) { disabled = true; return body(user); }
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); disabled = true; return body(user); }

@@ -24,6 +24,8 @@
 
 #include "../../include/mxdenoise.h"
 #include "common.h"
+#include <map>
+
 #include "graph_cache.h"
 #include "pp_exchange.h"
 #include "patch_cache.h"
@@ -45,6 +47,7 @@ struct mx_mmdit {
   uint64_t blob_bytes = 0;
   std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> table;
   mx::GraphCache graphs;   // hipGraph replay of the forward, keyed by its arguments (graph_cache.h)
+  std::map<std::vector<long>, std::vector<size_t>> pp_sizes;   // recorded exchange sizes of the patch-parallel plan per shape (as in unet_sdxl.cpp)
 };
 
 namespace {
@@ -693,12 +696,17 @@ int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, c
     p.ar.base = (char*)workspace; p.ar.cap = workspace_bytes; p.ar.top = 0; p.ar.peak = 0; p.ar.dry = dry;
     if (pp) p.px.set(comm, stale);
     if (pp && stale) {      // the state layout (exchanges dealt into chunks, pp_exchange.h) from a host-only recording walk of the same plan
-      std::vector<size_t> sizes;
-      Plan q = p;
-      q.dry = true; q.ar.dry = true; q.ar.base = nullptr; q.ar.cap = 0; q.stage = nullptr; q.lookup = false;
-      q.px.record = &sizes;
-      if (!q.run(nullptr, io_dtype, nullptr, nullptr, nullptr, nullptr)) { err = q.err; return false; }
-      p.px.build_layout(sizes);
+      const std::vector<long> lk = {(long)batch, (long)H, (long)W, (long)ctx_len, (long)comm->world, (long)io_dtype};
+      auto it = u->pp_sizes.find(lk);
+      if (it == u->pp_sizes.end()) {
+        std::vector<size_t> sizes;
+        Plan q = p;
+        q.dry = true; q.ar.dry = true; q.ar.base = nullptr; q.ar.cap = 0; q.stage = nullptr; q.lookup = false;
+        q.px.record = &sizes;
+        if (!q.run(nullptr, io_dtype, nullptr, nullptr, nullptr, nullptr)) { err = q.err; return false; }
+        it = u->pp_sizes.emplace(lk, std::move(sizes)).first;
+      }
+      p.px.build_layout(it->second);
     }
     const bool okr = p.run(latents, io_dtype, timesteps, ehs, pooled, out);
     plan_peak = p.ar.peak;
@@ -717,7 +725,7 @@ int forward_impl(mx_mmdit* u, void* stream, const void* latents, int io_dtype, c
     for (int g = 1; g < n_groups; ++g)
       for (uint64_t v : {(uint64_t)groups[g].batch, (uint64_t)groups[g].H, (uint64_t)groups[g].W, (uint64_t)(uintptr_t)groups[g].latents, (uint64_t)(uintptr_t)groups[g].out})
         key.push_back(v);
-    okr = u->graphs.run((hipStream_t)stream, key, enqueue);
+    okr = u->graphs.run((hipStream_t)stream, key, enqueue, /*capture_on_miss=*/n_groups <= 1);
   }
   if (peak) *peak = plan_peak;
   if (!okr) { mx::set_error(err); return 1; }

@@ -25,6 +25,8 @@
 
 #include "../../include/mxdenoise.h"
 #include "common.h"
+#include <map>
+
 #include "graph_cache.h"
 #include "pp_exchange.h"
 #include "patch_cache.h"
@@ -55,6 +57,9 @@ struct mx_unet {
   uint64_t blob_bytes = 0;
   std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> table;
   mx::GraphCache graphs;   // hipGraph replay of the forward, keyed by its arguments (graph_cache.h)
+  // patch-parallel stale forwards: the exchange sizes of the plan, recorded by a host-only walk ONCE per (batch, H, W, ctx_len, gn_patch, world) instead
+  // of at every step (advisor, round 3: the walk sat on the path whose purpose is to hide latency)
+  std::map<std::vector<long>, std::vector<size_t>> pp_sizes;
 };
 
 namespace {
@@ -1217,12 +1222,17 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
     if (pp) { p.pp_rank = comm->rank; p.pp_world = comm->world; p.Htot = H * comm->world; }
     if (pp) p.px.set(comm, stale);
     if (pp && stale) {      // the state layout (exchanges dealt into chunks, pp_exchange.h) from a host-only recording walk of the same plan
-      std::vector<size_t> sizes;
-      Plan q = p;
-      q.dry = true; q.ar.dry = true; q.ar.base = nullptr; q.ar.cap = 0; q.stage = nullptr; q.lookup = false;
-      q.px.record = &sizes;
-      if (!q.run(nullptr, io_dtype, nullptr, nullptr, nullptr, nullptr, nullptr)) { err = q.err; return false; }
-      p.px.build_layout(sizes);
+      const std::vector<long> lk = {(long)batch, (long)H, (long)W, (long)ctx_len, (long)gn_patch, (long)comm->world, (long)io_dtype};
+      auto it = u->pp_sizes.find(lk);
+      if (it == u->pp_sizes.end()) {
+        std::vector<size_t> sizes;
+        Plan q = p;
+        q.dry = true; q.ar.dry = true; q.ar.base = nullptr; q.ar.cap = 0; q.stage = nullptr; q.lookup = false;
+        q.px.record = &sizes;
+        if (!q.run(nullptr, io_dtype, nullptr, nullptr, nullptr, nullptr, nullptr)) { err = q.err; return false; }
+        it = u->pp_sizes.emplace(lk, std::move(sizes)).first;
+      }
+      p.px.build_layout(it->second);
     }
     const bool okr = p.run(latents, io_dtype, timesteps, ehs, text_embeds, time_ids, out);
     plan_peak = p.ar.peak;
@@ -1241,7 +1251,7 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
     for (int g = 1; g < n_groups; ++g)
       for (uint64_t v : {(uint64_t)groups[g].batch, (uint64_t)groups[g].H, (uint64_t)groups[g].W, (uint64_t)(uintptr_t)groups[g].latents, (uint64_t)(uintptr_t)groups[g].out})
         key.push_back(v);
-    okr = u->graphs.run((hipStream_t)stream, key, enqueue);
+    okr = u->graphs.run((hipStream_t)stream, key, enqueue, /*capture_on_miss=*/n_groups <= 1);
   }
   if (peak) *peak = plan_peak;
   if (!okr) { mx::set_error(err); return 1; }
