@@ -181,7 +181,7 @@ REF_DEADLINES_S = {  # SLO = 5 deadlines of the reference's metric script (scrip
     "sdxl": {512: 16.35, 768: 17.5, 1024: 19.31}, "sd3": {512: 11.0, 768: 18.0, 1024: 30.0}}
 REF_STEP_MIX = ((30, 0.054), (35, 0.178), (40, 0.460), (45, 0.228), (50, 0.080))   # step histogram of exp/sdxl/qps_1.0.csv
 STEP_SECONDS = {  # single-request seconds per step on MI355X (profiles/predictor_{sdxl,sd3}_mi355x.txt): the service model of dp.replay_placement
-    "sdxl": {512: 0.0178, 768: 0.0208, 1024: 0.0271}, "sd3": {512: 0.0111, 768: 0.0179, 1024: 0.0286}}
+    "sdxl": {512: 0.0140, 768: 0.0185, 1024: 0.0247}, "sd3": {512: 0.0099, 768: 0.0165, 1024: 0.0260}}
 
 
 def run_mix(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, world, model, policy="continuous"):

@@ -612,16 +612,18 @@ struct Plan {
     if (pc) pass1 = pass2 = pass3 = true;   // the hidden state of a masked layer is produced by the state-merge kernel, which leaves no row statistics
     // Round 4: where the consumer runs on the 256 x 256 kernel (pass1 / pass3) and the launches that write the hidden state in front of it can
     // FINALISE the row statistics (256-row tiles: mx_gemm_ln_final_supported), the pass disappears as well: the producer's last workgroup per
-    // panel leaves (mean, rstd) per row and the consumer starts its accumulators from those 8 bytes (mx_gemm_desc.ln_final).  One resolution
-    // group, no patch cache, not patch-parallel (their hidden states come from other kernels / are compared bit for bit with the unsplit run).
+    // panel leaves (mean, rstd) per row and the consumer starts its accumulators from those 8 bytes (mx_gemm_desc.ln_final).  No patch cache, not
+    // patch-parallel (their hidden states come from other kernels / are compared bit for bit with the unsplit run).
     bool fin1 = false, fin3 = false;
-    if (ng == 1 && !pc && !is_pp() && ln_cnt != nullptr && (M + 255) / 256 <= kLnCnt) {
+    if (!pc && !is_pp() && ln_cnt != nullptr && (M + 255) / 256 <= kLnCnt) {
       auto can_finalise = [&](int K, bool residual) {
         mx_gemm_desc d = lin_desc(y, y, C, C, 0, 0.f);
         d.K = K; d.lda = K; if (residual) { d.residual = y; d.ldr = C; }
         return mx_gemm_ln_final_supported(&d) != 0;
       };
-      fin1 = pass1 && can_finalise(C, false) && (layers == 1 || can_finalise(4 * C, true));
+      // (norm1's consumer, the fused q | k | v projection, is a GROUPED launch in a mixed batch -- one problem per resolution -- and keeps the pass there;
+      //  norm3's consumer is a per-token linear over all rows, one ordinary launch whatever the mix)
+      fin1 = ng == 1 && pass1 && can_finalise(C, false) && (layers == 1 || can_finalise(4 * C, true));
       fin3 = pass3 && can_finalise(C, true);
       if (fin1 || fin3) { st.fin = (float*)ar.alloc((size_t)M * 2 * sizeof(float)); st.cnt = ln_cnt; if (!st.fin) fail("workspace too small"); }
     }
