@@ -200,6 +200,12 @@ typedef struct mx_gemm_desc {
   const float* ln_final;
   float* ln_final_out;
   unsigned* ln_final_cnt;
+  /* GroupNorm statistics from the producing launch (round 4): gn_part_out != NULL makes a conv / GEMM on a 256-row tile whose epilogue is bias (+ per-sample
+   * row bias) only ALSO leave, per 64 consecutive output rows and per channel, the sum and the sum of squares of the values it stores (fp32, before the bf16
+   * rounding): gn_part_out[(m / 64 * N + n) * 2 + {0, 1}], M % 64 == 0 (and rows_per_batch % 64 == 0 with a row bias).  mx_groupnorm_nhwc_from_partials then
+   * needs no statistics pass over the tensor (the reference's resnet: conv1 + time embedding -> norm2, resnet.py:414-429).  mx_gemm_gn_partials_supported(d,
+   * conv) tells whether the launch can. */
+  float* gn_part_out;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -215,6 +221,7 @@ int mx_gemm_stats_slabs(const mx_gemm_desc* d);        /* slabs d->stats_out rec
 int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d);
 /* 1 when mx_gemm(d) with stats_out can also write ln_final_out (the launch takes a 256-row tile of the register-exchange kernels, ungrouped) */
 int mx_gemm_ln_final_supported(const mx_gemm_desc* d);
+int mx_gemm_gn_partials_supported(const mx_gemm_desc* d, int conv);   /* 1 when mx_gemm / mx_conv3x3 (d) can write gn_part_out */
 #define MX_STATS_PITCH(slabs) (((slabs) + 3) & ~3)     /* slabs per row of a statistics buffer: [M][pitch][2] floats */
 /* stats[m * 4 * 2 + {0, 1}] = (sum_c x[m][c], sum_c x[m][c]^2), x bf16 [M, C] with row stride ldx: the one-slab input of ln_stats
  * (buffer of M * MX_STATS_PITCH(1) * 2 floats) */
@@ -300,6 +307,11 @@ int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const float* gamma, 
  * norm1 (unet_2d_blocks.py via unet.py:458-462) without materialising the concatenation.  x2 == NULL: mx_groupnorm_nhwc. */
 int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const void* x2, void* y, const float* gamma, const float* beta,
                           int B, int H, int W, int C, int groups, float eps, int silu, int patch, void* workspace);
+/* GroupNorm (+SiLU) of x [B, H, W, C] from per-chunk partial sums a producing launch left (mx_gemm_desc.gn_part_out): part[(token / chunk * C + c) * 2 + {0, 1}] over
+ * `chunk` consecutive tokens (chunk divides H * W), exact statistics only (no sliced form).  Fold + apply: the statistics read pass does not run.
+ * workspace: mx_groupnorm_nhwc_workspace_bytes(B, H, W, C). */
+int mx_groupnorm_nhwc_from_partials(void* stream, const void* x, void* y, const float* gamma, const float* beta, int B, int H, int W, int C, int groups, float eps,
+                                    int silu, const float* part, int chunk, void* workspace);
 
 /* Grouped form (see mx_gemm_seg): the GroupNorms of all resolutions present in a mixed batch as ONE stats / fold / apply launch each.  x2 as in
  * mx_groupnorm_nhwc_cat (all problems or none); workspace >= mx_groupnorm_nhwc_grouped_workspace_bytes(probs, n, C). */

@@ -54,6 +54,7 @@ struct GemmArgs {
   float* ln_final_out;
   unsigned* ln_final_cnt;
   int ln_final_slabs;      // slabs the producer's own launch writes per row (N / wave panel)
+  float* gn_part;          // GroupNorm partial sums per 64 output rows and channel (mxdenoise.h gn_part_out); nullptr = off
   // split-K (128-row tiles, small launches: gemm_bf16_v2.hip): the K tiles of an output tile are dealt to `splitk` workgroups; each leaves its
   // fp32 partial tile in sk_ws and takes a ticket from sk_cnt[tile]; the last one sums the partials in slice order and runs the epilogue
   int splitk;
@@ -165,6 +166,40 @@ __device__ __forceinline__ void gemm_ln_row(const GemmArgs& p, const int m, cons
   const float var = fmaxf(s2 * inv - mean * mean, 0.f);
   rstd = rsqrtf(var + p.ln_eps);
   rm = rstd * mean;
+}
+
+// ---- GroupNorm partial sums from the producing launch (mxdenoise.h gn_part_out).  Called BEFORE the epilogue of a 256-row tile whose epilogue is
+// bias (+ per-sample row bias) only: the value a token stores is acc + c with c = bias[n] + rowbias[sample][n], known per lane and constant over the wave's
+// 64 tokens (one sample: rows_per_batch % 64 == 0), so the sums come from the accumulators while the fragment registers are dead and the epilogue itself
+// is untouched.  Lane (token fr, fq) holds features 16 i + 4 fq + {0..3}: sum over its MI token blocks, then over the 16 lanes of its DPP row. ----
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1, 0, 3, 2]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2, 3, 0, 1]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
+  return x;
+}
+template <int NI, int MI>
+__device__ __forceinline__ void gemm_gn_partials(const GemmArgs& p, const f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0, const int fr, const int fq) {
+  static_assert(MI == 4, "one 64-token chunk per wave");
+  if (m_wave0 >= p.M) return;                  // (M % 64 == 0: a chunk is whole or absent)
+  const int bidx = p.rowbias != nullptr ? m_wave0 / p.rows_per_batch : 0;
+  float* dst = p.gn_part + ((long)(m_wave0 >> 6) * p.N + wave_n0 + fq * 4) * 2;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int n = wave_n0 + i * 16 + fq * 4;
+    f32x4 c = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.rowbias != nullptr) c += *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ldrb + n);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MI; ++j) { const f32x4 v = acc[i][j] + c; s += v; q += v * v; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[e] = row16_sum(s[e]); q[e] = row16_sum(q[e]); }
+    if (fr == 0) {
+      *reinterpret_cast<f32x4*>(dst + i * 32) = f32x4{s[0], q[0], s[1], q[1]};
+      *reinterpret_cast<f32x4*>(dst + i * 32 + 4) = f32x4{s[2], q[2], s[3], q[3]};
+    }
+  }
 }
 
 // ---- finalised row statistics (mxdenoise.h, ln_final).  PRODUCER side, after the epilogue of a 256-row tile whose launch has ln_final_out:

@@ -448,6 +448,14 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     MX_CHECK(((uintptr_t)d->stats_out & 15) == 0, "gemm: stats_out must be 16-byte aligned");
     a.stats_out = d->stats_out;
   }
+  a.gn_part = nullptr;
+  if (d->gn_part_out) {
+    MX_CHECK(!grouped && tc.rows == 256 && tc.bn != 256 && tc.bn != 0 && tc.splitk <= 1, "gemm: gn_part_out needs an ungrouped launch on a 256-row tile (mx_gemm_gn_partials_supported)");
+    MX_CHECK(d->flags == 0 && !d->residual && !d->gate && d->out_scale == 0.f && !d->ln_stats && !d->ln_final && d->a_batch_rows <= 0 && d->c_batch_rows <= 0,
+             "gemm: gn_part_out needs an epilogue of bias (+ row bias) only");
+    MX_CHECK(d->M % 64 == 0 && (!d->rowbias || d->rows_per_batch % 64 == 0) && ((uintptr_t)d->gn_part_out & 15) == 0, "gemm: gn_part_out needs M % 64 == 0, rows_per_batch % 64 == 0 and 16-byte alignment");
+    a.gn_part = d->gn_part_out;
+  }
   if (d->ln_final_out) {
     MX_CHECK(d->stats_out && d->ln_final_cnt && !grouped && tc.rows == 256 && tc.bn != 256 && tc.bn != 0,
              "gemm: ln_final_out needs stats_out, ln_final_cnt and an ungrouped launch on a 256-row tile (mx_gemm_ln_final_supported)");
@@ -588,6 +596,13 @@ extern "C" int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d) {
   mx_gemm_desc plain = *d;
   plain.ln_stats = nullptr; plain.stats_out = nullptr;
   return mx::pick_tile(&plain, false).bn == 256;
+}
+extern "C" int mx_gemm_gn_partials_supported(const mx_gemm_desc* d, int conv) {
+  if (!d || d->n_segs > 0 || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->M % 64 != 0) return 0;
+  if (d->flags != 0 || d->residual || d->gate || d->out_scale != 0.f || d->ln_stats || d->ln_final || d->a_batch_rows > 0 || d->c_batch_rows > 0) return 0;
+  if (d->rowbias && (d->rows_per_batch <= 0 || d->rows_per_batch % 64 != 0)) return 0;
+  const mx::TileChoice tc = mx::pick_tile(d, conv != 0);
+  return tc.rows == 256 && tc.bn != 256 && tc.bn != 0 && tc.splitk <= 1;
 }
 extern "C" int mx_gemm_ln_final_supported(const mx_gemm_desc* d) {
   if (!d || d->n_segs > 0 || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;

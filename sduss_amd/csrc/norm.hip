@@ -402,6 +402,28 @@ extern "C" int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const 
   return mx_groupnorm_nhwc_grouped(stream, &q, 1, C1, gamma, beta, C, groups, eps, silu, patch, workspace);
 }
 
+/* GroupNorm from the partial sums a producing launch left (mx_gemm_desc.gn_part_out): the fold reads them as "tiles" of `chunk` pixels; no statistics pass */
+extern "C" int mx_groupnorm_nhwc_from_partials(void* stream, const void* x, void* y, const float* gamma, const float* beta, int B, int H, int W, int C, int groups,
+                                               float eps, int silu, const float* part, int chunk, void* workspace) {
+  using namespace mx;
+  MX_CHECK(x && y && gamma && beta && part && workspace && B > 0 && H > 0 && W > 0, "groupnorm: null operand / empty problem");
+  MX_CHECK(groups > 0 && C % groups == 0 && chunk > 0 && (H * W) % chunk == 0 && ((uintptr_t)part & 15) == 0, "groupnorm: bad groups / chunk / alignment");
+  GnGroup G;
+  G.n = 1;
+  if (!gn_fill(G, 0, x, C, nullptr, y, (long)H * W * C, B, H, W, C, 0, (char*)workspace)) return 1;
+  GnGroup F = G;                               // the fold's view: one "tile" per chunk of the producer, its sums where the statistics pass would have put them
+  F.p[0].part = const_cast<float*>(part);
+  F.p[0].g.tiles_y = H * W / chunk; F.p[0].g.tiles_x = 1; F.p[0].g.th = chunk; F.p[0].g.tw = 1;
+  hipStream_t s = (hipStream_t)stream;
+  prof_begin(s, PROF_NORM, 0.0, 2.0 * 2.0 * B * H * (double)W * C);
+  gn_prefix(F, 1, groups);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(F.blk0[MX_MAX_SEGS]), dim3(kFoldThreads), 0, s, F, gamma, beta, groups, eps);
+  MX_LAUNCH_CHECK();
+  if (gn_launch_apply(s, G, silu)) return 1;
+  prof_end(s);
+  return 0;
+}
+
 namespace mx {
 // local part: stats -> per-(image, group) fp64 sums.  workspace: gn_workspace_exact(B, H, W, C, 0) bytes; sums: double [B][groups][2]
 int launch_gn_pp_partial(hipStream_t s, const void* x, int C1, const void* x2, int B, int H, int W, int C, int groups, void* workspace, double* sums) {

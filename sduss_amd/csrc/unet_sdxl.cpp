@@ -390,8 +390,10 @@ struct Plan {
   }
   // 3x3 conv over the images of every group at the current level (Hin, Win: the first group's size; the others come from ch / cw).  A mixed
   // batch is ONE grouped launch: problem g = group g's images, its output grid, its samples' rows of the time-embedding row bias.
+  // gn_part / gn_done: ask the launch to leave the GroupNorm partial sums of its output (mx_gemm_desc.gn_part_out); *gn_done tells whether it could
   bool conv(const bf16_t* x, int Hin, int Win, int Cin, const std::string& prefix, bf16_t* out, int Cout, int stride, int up,
-            int corner_patch, const float* rowbias = nullptr, int ldrb = 0, const void* residual = nullptr, int vhalo = 0) {
+            int corner_patch, const float* rowbias = nullptr, int ldrb = 0, const void* residual = nullptr, int vhalo = 0, float* gn_part = nullptr,
+            bool* gn_done = nullptr) {
     mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
     d.vhalo = vhalo;
     const int Hv = Hin << up, Wv = Win << up;
@@ -418,6 +420,7 @@ struct Plan {
       }
       d.segs = sg; d.n_segs = ng;
     }
+    if (gn_part && gn_done && ng == 1 && mx_gemm_gn_partials_supported(&d, 1)) { d.gn_part_out = gn_part; *gn_done = true; }
     return gemm(d, true);
   }
   bool groupnorm(const bf16_t* x, bf16_t* y, const std::string& prefix, int h, int wd, int C, float eps, bool silu, int patch,
@@ -437,6 +440,20 @@ struct Plan {
     const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
     if (ok() && !quiet()) {
       if (mx_groupnorm_nhwc_grouped(stream, pr, ng, x2 ? C1 : C, g, b, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, patch, ws))
+        fail(std::string("groupnorm: ") + mx_last_error());
+    }
+    ar.release(m);
+    return ok();
+  }
+  // GroupNorm whose statistics the producing launch left as partial sums per 64 rows (conv(): gn_part); one resolution group, exact statistics
+  bool groupnorm_from_partials(const bf16_t* x, bf16_t* y, const std::string& prefix, int h, int wd, int C, float eps, bool silu, const float* part) {
+    if (!ok()) return false;
+    const size_t m = ar.mark();
+    void* ws = ar.alloc(mx::gn_workspace_exact(gB[0], h, wd, C, 0));
+    if (!ws) return fail("workspace too small");
+    const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
+    if (ok() && !quiet()) {
+      if (mx_groupnorm_nhwc_from_partials(stream, x, y, g, b, gB[0], h, wd, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, part, 64, ws))
         fail(std::string("groupnorm: ") + mx_last_error());
     }
     ar.release(m);
@@ -523,10 +540,16 @@ struct Plan {
     bf16_t* n1 = alloc<bf16_t>((size_t)M * Cin);
     groupnorm(x, n1, p + ".norm1", h, wd, Cin, u->cfg.norm_eps, true, patch, x2, C1);
     bf16_t* h1 = alloc<bf16_t>((size_t)M * Cout);
-    conv(n1, h, wd, Cin, p + ".conv1", h1, Cout, 1, 0, patch, temb_all ? temb_all + temb_off : nullptr, temb_total);
+    // norm2's statistics come from conv1's own launch where it can leave them (round 4: one resolution, exact statistics, a 256-row tile): per 64
+    // output rows and channel the sums of conv + bias + time embedding, so the statistics pass over h1 does not run (resnet.py:414-429)
+    float* gpart = nullptr;
+    bool gdone = false;
+    if (ng == 1 && patch == 0 && M % 64 == 0 && (h * wd) % 64 == 0) gpart = (float*)ar.alloc((size_t)(M / 64) * Cout * 2 * sizeof(float));
+    conv(n1, h, wd, Cin, p + ".conv1", h1, Cout, 1, 0, patch, temb_all ? temb_all + temb_off : nullptr, temb_total, nullptr, 0, gpart, &gdone);
     temb_off += Cout;
     bf16_t* n2 = alloc<bf16_t>((size_t)M * Cout);
-    groupnorm(h1, n2, p + ".norm2", h, wd, Cout, u->cfg.norm_eps, true, patch);
+    if (gdone) groupnorm_from_partials(h1, n2, p + ".norm2", h, wd, Cout, u->cfg.norm_eps, true, gpart);
+    else groupnorm(h1, n2, p + ".norm2", h, wd, Cout, u->cfg.norm_eps, true, patch);
     const bf16_t* sc = x;
     if (Cin != Cout) {
       bf16_t* s2 = alloc<bf16_t>((size_t)M * Cout);

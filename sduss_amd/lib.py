@@ -48,7 +48,7 @@ class GemmDesc(C.Structure):
         ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("vhalo", C.c_int), ("a2", C.c_void_p), ("lda2", C.c_int), ("k_split", C.c_int),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_slabs", C.c_int), ("ln_eps", C.c_float), ("stats_out", C.c_void_p),
         ("segs", C.POINTER(GemmSeg)), ("n_segs", C.c_int), ("splitk", C.c_int),
-        ("ln_final", C.c_void_p), ("ln_final_out", C.c_void_p), ("ln_final_cnt", C.c_void_p),
+        ("ln_final", C.c_void_p), ("ln_final_out", C.c_void_p), ("ln_final_cnt", C.c_void_p), ("gn_part_out", C.c_void_p),
     ]
 
 
@@ -186,6 +186,8 @@ SYMBOLS = {
     "mx_gemm_splitk": (_i, [_vp, _i]),
     "mx_gemm_ln_final_supported": (_i, [C.POINTER(GemmDesc)]),
     "mx_gemm_launches": (_i, [C.POINTER(GemmDesc)]),
+    "mx_gemm_gn_partials_supported": (_i, [C.POINTER(GemmDesc), _i]),
+    "mx_groupnorm_nhwc_from_partials": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp, _i, _vp]),
     "mx_unet_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_mmdit_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "mx_mmdit_workspace_bytes_cached_mixed": (_sz, [_vp, C.POINTER(UNetGroup), _i, _i, _i]),

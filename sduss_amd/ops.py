@@ -149,8 +149,9 @@ def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_b
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, up: int = 0,
-            corner_patch: int = 0, rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, splitk: int = 0) -> torch.Tensor:
-    """x NHWC bf16 [B,H,W,Cin]; w bf16 [Cout, 9*Cin] tap-major; returns NHWC bf16 [B,Ho,Wo,Cout]."""
+            corner_patch: int = 0, rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, splitk: int = 0, want_gn_partials: bool = False):
+    """x NHWC bf16 [B,H,W,Cin]; w bf16 [Cout, 9*Cin] tap-major; returns NHWC bf16 [B,Ho,Wo,Cout].  ``want_gn_partials``: also return the per-64-row,
+    per-channel (sum, sum of squares) of the output [M / 64, Cout, 2] the launch left (mx_gemm_desc.gn_part_out), or None where it cannot."""
     l = _lib.load()
     _bf16(x); _bf16(w)
     b, h, wd, cin = x.shape
@@ -165,7 +166,13 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stri
     d.rows_per_batch = ho * wo
     d.B, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.up, d.corner_patch = b, h, wd, cin, ho, wo, stride, up, corner_patch
     d.splitk = splitk
+    part = None
+    if want_gn_partials and l.mx_gemm_gn_partials_supported(C.byref(d), 1):
+        part = torch.full((b * ho * wo // 64, cout, 2), float("nan"), dtype=torch.float32, device=x.device)
+        d.gn_part_out = part.data_ptr()
     _lib.check(l.mx_conv3x3(_lib.current_stream(), C.byref(d)), "mx_conv3x3")
+    if want_gn_partials:
+        return c, part
     return c
 
 
@@ -196,6 +203,19 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     y = torch.empty_like(x)
     _lib.check(l.mx_layernorm(_lib.current_stream(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                               x.shape[0], x.shape[1], eps), "mx_layernorm")
+    return y
+
+
+def groupnorm_nhwc_from_partials(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool, part: torch.Tensor,
+                                 chunk: int = 64) -> torch.Tensor:
+    """GroupNorm (+SiLU) of x NHWC from the partial sums the producing launch left (conv3x3(..., want_gn_partials=True)): no statistics pass."""
+    l = _lib.load()
+    _bf16(x)
+    b, h, w, c = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty(l.mx_groupnorm_nhwc_workspace_bytes(b, h, w, c), dtype=torch.uint8, device=x.device)
+    _lib.check(l.mx_groupnorm_nhwc_from_partials(_lib.current_stream(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), b, h, w, c, groups, eps,
+                                                 1 if silu else 0, part.data_ptr(), chunk, ws.data_ptr()), "mx_groupnorm_nhwc_from_partials")
     return y
 
 

@@ -561,3 +561,32 @@ def test_gemm_tail_split_of_the_256x256_kernel(cuda_device):
     got = ops.gemm(_bf(a2).cuda(), _bf(w).cuda(), b.cuda(), residual=_bf(r).cuda())
     _close(got, a2 @ w.t() + b + r, 2.0 ** -7, f"tail-split plain + residual ({n_launch} launches)")
     assert n_launch == 2
+
+
+@pytest.mark.parametrize("b,hw,cin,cout", [(8, 32, 1280, 1280), (8, 32, 640, 1280), (2, 64, 640, 640), (4, 64, 320, 640), (3, 24, 1280, 1280)])
+def test_groupnorm_from_the_producing_convs_partial_sums(cuda_device, b, hw, cin, cout):
+    """resnet conv1 (+ bias + time-embedding row bias) leaves, per 64 output rows and channel, the sum and sum of squares of what it stores
+    (mx_gemm_desc.gn_part_out); norm2 + SiLU from those partials equals GroupNorm + SiLU of the stored tensor (resnet.py:414-429) and the statistics pass is gone;
+    where the launch cannot (a small batch on 128-row tiles) the caller is told (None)."""
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(b + hw + cin + cout)
+    x = _rt(torch.randn(b, cin, hw, hw, generator=g)); w = _rt(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g); temb = torch.randn(b, cout, generator=g)
+    ga = 1.0 + 0.2 * torch.randn(cout, generator=g); be = 0.1 * torch.randn(cout, generator=g)
+    y, part = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(w)).cuda(), bias.cuda(), rowbias=temb.cuda(), want_gn_partials=True)
+    if b * hw * hw < 4096:
+        assert part is None or part.shape[0] == b * hw * hw // 64
+    if part is None:
+        pytest.skip("this launch takes 128-row tiles: no partial sums (the plan keeps the statistics pass there)")
+    yf = y.float().cpu()                                   # [b, hw, hw, cout]
+    rows = yf.reshape(-1, 64, cout)
+    pc = part.cpu()
+    assert torch.isfinite(pc).all()
+    s_ref, q_ref = rows.sum(dim=1), (rows * rows).sum(dim=1)
+    assert (pc[..., 0] - s_ref).abs().max().item() <= 2.0 ** -8 * rows.abs().sum(dim=1).max().item()      # fp32 sums before the bf16 rounding vs sums of the rounded values
+    assert ((pc[..., 1] - q_ref).abs() / q_ref).max().item() <= 2.0 ** -7
+    want = F.silu(F.group_norm(yf.permute(0, 3, 1, 2), 32, ga, be, 1e-5))
+    got = ops.groupnorm_nhwc_from_partials(y, ga.cuda(), be.cuda(), 32, 1e-5, True, part)
+    _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, f"groupnorm from the conv's partial sums b{b} {hw}x{hw} {cin}->{cout}")
+    again = ops.groupnorm_nhwc_from_partials(y, ga.cuda(), be.cuda(), 32, 1e-5, True, ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(w)).cuda(), bias.cuda(), rowbias=temb.cuda(), want_gn_partials=True)[1])
+    assert torch.equal(again, got)                         # fixed summation order: bit-stable run to run
