@@ -574,10 +574,9 @@ def test_groupnorm_from_the_producing_convs_partial_sums(cuda_device, b, hw, cin
     bias = torch.randn(cout, generator=g); temb = torch.randn(b, cout, generator=g)
     ga = 1.0 + 0.2 * torch.randn(cout, generator=g); be = 0.1 * torch.randn(cout, generator=g)
     y, part = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(w)).cuda(), bias.cuda(), rowbias=temb.cuda(), want_gn_partials=True)
-    if b * hw * hw < 4096:
-        assert part is None or part.shape[0] == b * hw * hw // 64
-    if part is None:
-        pytest.skip("this launch takes 128-row tiles: no partial sums (the plan keeps the statistics pass there)")
+    if part is None:                                       # a small launch takes 128-row tiles: no partial sums, the plan keeps the statistics pass there
+        assert b * hw * hw <= 8192, "a chip-filling conv must be able to leave its partial sums"
+        return
     yf = y.float().cpu()                                   # [b, hw, hw, cout]
     rows = yf.reshape(-1, 64, cout)
     pc = part.cpu()
