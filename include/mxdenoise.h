@@ -201,9 +201,10 @@ typedef struct mx_gemm_desc {
   float* ln_final_out;
   unsigned* ln_final_cnt;
   /* GroupNorm statistics from the producing launch (round 4): gn_part_out != NULL makes a conv / GEMM on a 256-row tile whose epilogue is bias (+ per-sample
-   * row bias) only ALSO leave, per 64 consecutive output rows and per channel, the sum and the sum of squares of the values it stores (fp32, before the bf16
-   * rounding): gn_part_out[(m / 64 * N + n) * 2 + {0, 1}], M % 64 == 0 (and rows_per_batch % 64 == 0 with a row bias).  mx_groupnorm_nhwc_from_partials then
-   * needs no statistics pass over the tensor (the reference's resnet: conv1 + time embedding -> norm2, resnet.py:414-429).  mx_gemm_gn_partials_supported(d,
+   * row bias) only ALSO leave, per 64 consecutive output rows and per channel, the sum and the sum of squares of its ACCUMULATORS -- the values it stores minus
+   * the per-channel constants bias[n] + rowbias[sample][n] (fp32): gn_part_out[(m / 64 * N + n) * 2 + {0, 1}], M % 64 == 0 (and rows_per_batch % 64 == 0 with a row
+   * bias).  mx_groupnorm_nhwc_from_partials, given the same bias / row bias, adds the constants back in closed form and needs no statistics pass over the tensor
+   * (the reference's resnet: conv1 + time embedding -> norm2, resnet.py:414-429).  mx_gemm_gn_partials_supported(d,
    * conv) tells whether the launch can. */
   float* gn_part_out;
 } mx_gemm_desc;
@@ -308,10 +309,11 @@ int mx_groupnorm_nhwc(void* stream, const void* x, void* y, const float* gamma, 
 int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const void* x2, void* y, const float* gamma, const float* beta,
                           int B, int H, int W, int C, int groups, float eps, int silu, int patch, void* workspace);
 /* GroupNorm (+SiLU) of x [B, H, W, C] from per-chunk partial sums a producing launch left (mx_gemm_desc.gn_part_out): part[(token / chunk * C + c) * 2 + {0, 1}] over
- * `chunk` consecutive tokens (chunk divides H * W), exact statistics only (no sliced form).  Fold + apply: the statistics read pass does not run.
- * workspace: mx_groupnorm_nhwc_workspace_bytes(B, H, W, C). */
+ * `chunk` consecutive tokens (chunk divides H * W), exact statistics only (no sliced form).  add_bias [C] (may be NULL) / add_rowbias [B][ldrb] (may be NULL): the
+ * partial sums are those of x[.., c] - (add_bias[c] + add_rowbias[image][c]) -- the producer's bias and per-sample row bias.  Fold + apply: the statistics read
+ * pass does not run.  workspace: mx_groupnorm_nhwc_workspace_bytes(B, H, W, C). */
 int mx_groupnorm_nhwc_from_partials(void* stream, const void* x, void* y, const float* gamma, const float* beta, int B, int H, int W, int C, int groups, float eps,
-                                    int silu, const float* part, int chunk, void* workspace);
+                                    int silu, const float* part, int chunk, const float* add_bias, const float* add_rowbias, int ldrb, void* workspace);
 
 /* Grouped form (see mx_gemm_seg): the GroupNorms of all resolutions present in a mixed batch as ONE stats / fold / apply launch each.  x2 as in
  * mx_groupnorm_nhwc_cat (all problems or none); workspace >= mx_groupnorm_nhwc_grouped_workspace_bytes(probs, n, C). */

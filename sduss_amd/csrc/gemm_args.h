@@ -168,10 +168,12 @@ __device__ __forceinline__ void gemm_ln_row(const GemmArgs& p, const int m, cons
   rm = rstd * mean;
 }
 
-// ---- GroupNorm partial sums from the producing launch (mxdenoise.h gn_part_out).  Called BEFORE the epilogue of a 256-row tile whose epilogue is
-// bias (+ per-sample row bias) only: the value a token stores is acc + c with c = bias[n] + rowbias[sample][n], known per lane and constant over the wave's
-// 64 tokens (one sample: rows_per_batch % 64 == 0), so the sums come from the accumulators while the fragment registers are dead and the epilogue itself
-// is untouched.  Lane (token fr, fq) holds features 16 i + 4 fq + {0..3}: sum over its MI token blocks, then over the 16 lanes of its DPP row. ----
+// ---- GroupNorm partial sums from the producing launch (mxdenoise.h gn_part_out).  Called AFTER the epilogue of a 256-row tile whose epilogue is
+// bias (+ per-sample row bias) only: the value a token stores is acc + c with c constant per channel and sample, so the launch leaves the sums of the
+// ACCUMULATORS and the GroupNorm's fold adds c back in closed form (sum + 64 c, sum of squares + 2 c sum + 64 c^2, in fp64) -- no load here, nothing
+// in front of the epilogue's own loads and stores (a first form summed acc + c before the epilogue: its loads and stores sat in front of the epilogue's
+// and cost the conv 7 us per launch).  Lane (token fr, fq) holds features 16 i + 4 fq + {0..3}: sum over its MI token blocks, then over the 16 lanes of
+// its DPP row; the stores overlap the drain of the tile's own. ----
 __device__ __forceinline__ float row16_sum(float x) {
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1, 0, 3, 2]
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2, 3, 0, 1]
@@ -183,16 +185,12 @@ template <int NI, int MI>
 __device__ __forceinline__ void gemm_gn_partials(const GemmArgs& p, const f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0, const int fr, const int fq) {
   static_assert(MI == 4, "one 64-token chunk per wave");
   if (m_wave0 >= p.M) return;                  // (M % 64 == 0: a chunk is whole or absent)
-  const int bidx = p.rowbias != nullptr ? m_wave0 / p.rows_per_batch : 0;
   float* dst = p.gn_part + ((long)(m_wave0 >> 6) * p.N + wave_n0 + fq * 4) * 2;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int n = wave_n0 + i * 16 + fq * 4;
-    f32x4 c = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.rowbias != nullptr) c += *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ldrb + n);
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < MI; ++j) { const f32x4 v = acc[i][j] + c; s += v; q += v * v; }
+    for (int j = 0; j < MI; ++j) { s += acc[i][j]; q += acc[i][j] * acc[i][j]; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s[e] = row16_sum(s[e]); q[e] = row16_sum(q[e]); }
     if (fr == 0) {

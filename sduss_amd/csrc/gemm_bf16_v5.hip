@@ -262,11 +262,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v5_kernel(const GemmArgs pk) {
   if (!group_b) MX5_BAR();                    // re-align the two groups
 
   const int m0 = tm * BM5, n0 = tn * BN;
-  if constexpr (!GEGLU && FEAT == 0 && MI == 4) {      // GroupNorm partial sums of what this tile is about to store (gemm_args.h)
-    if (pk.gn_part != nullptr) gemm_gn_partials<NI, MI>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq);
-  }
   static_assert(!GEGLU || (NI % 4 == 0 && !CONV), "the gated epilogue pairs whole 32-feature halves");
   gemm_epilogue_regs<NI, MI, GEGLU, VEC, true, true, FEAT>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq, ln_rstd);
+  if constexpr (!GEGLU && FEAT == 0 && MI == 4) {      // GroupNorm partial sums of the accumulators (gemm_args.h): pure ALU + 10 stores behind the tile's own
+    if (pk.gn_part != nullptr) gemm_gn_partials<NI, MI>(p, acc, m0 + wm * 16 * MI, n0 + wn * (BN / 2), fr, fq);
+  }
   MX5_STAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the past-the-end DMAs are drained before the workgroup retires
   if constexpr (!CONV && !GEGLU && BM5 == 256) {      // finalised row statistics: the last workgroup of the 256-row panel folds its slabs (gemm_args.h)

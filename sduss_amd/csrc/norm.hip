@@ -117,8 +117,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // one workgroup (four waves) per (group, image): fp64 fold of tiles x channels-per-group, patch by patch.  Four waves because the fold is a
 // chain of dependent loads: with one wave the 640..1280 items of a 128 x 128 level took 11 us per launch, 46 launches a step.
 constexpr int kFoldThreads = 256;
+// add_bias / add_rowbias (mx_groupnorm_nhwc_from_partials): the partial sums are those of x - c with c = add_bias[ch] + add_rowbias[image][ch] (what a
+// producing conv's accumulators hold before its epilogue adds the bias and the time embedding); the sums of x follow in closed form per tile
 __global__ __launch_bounds__(kFoldThreads) void gn_fold_kernel(const GnGroup G, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               int groups, float eps) {
+                                                               int groups, float eps, const float* __restrict__ add_bias = nullptr,
+                                                               const float* __restrict__ add_rowbias = nullptr, int ldrb = 0) {
   int local;
   const GnProb& P = gn_locate(G, local);
   const GnGeom& g = P.g;
@@ -147,8 +150,16 @@ __global__ __launch_bounds__(kFoldThreads) void gn_fold_kernel(const GnGroup G, 
       const int iy = tl / tpx, ix = tl - iy * tpx;
       const int tile = (py * tpy + iy) * g.tiles_x + px * tpx + ix;
       const float2 v = *reinterpret_cast<const float2*>(part + (((long)b * ntiles + tile) * g.C + grp * cpg + c) * 2);
-      s += (double)v.x;
-      q += (double)v.y;
+      if (add_bias != nullptr) {
+        const int chn = grp * cpg + c;
+        const double cc = (double)add_bias[chn] + (add_rowbias != nullptr ? (double)add_rowbias[(long)b * ldrb + chn] : 0.0);
+        const double npx = (double)(g.th * g.tw);
+        s += (double)v.x + npx * cc;
+        q += (double)v.y + 2.0 * cc * (double)v.x + npx * cc * cc;
+      } else {
+        s += (double)v.x;
+        q += (double)v.y;
+      }
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
@@ -404,7 +415,8 @@ extern "C" int mx_groupnorm_nhwc_cat(void* stream, const void* x, int C1, const 
 
 /* GroupNorm from the partial sums a producing launch left (mx_gemm_desc.gn_part_out): the fold reads them as "tiles" of `chunk` pixels; no statistics pass */
 extern "C" int mx_groupnorm_nhwc_from_partials(void* stream, const void* x, void* y, const float* gamma, const float* beta, int B, int H, int W, int C, int groups,
-                                               float eps, int silu, const float* part, int chunk, void* workspace) {
+                                               float eps, int silu, const float* part, int chunk, const float* add_bias, const float* add_rowbias, int ldrb,
+                                               void* workspace) {
   using namespace mx;
   MX_CHECK(x && y && gamma && beta && part && workspace && B > 0 && H > 0 && W > 0, "groupnorm: null operand / empty problem");
   MX_CHECK(groups > 0 && C % groups == 0 && chunk > 0 && (H * W) % chunk == 0 && ((uintptr_t)part & 15) == 0, "groupnorm: bad groups / chunk / alignment");
@@ -417,7 +429,8 @@ extern "C" int mx_groupnorm_nhwc_from_partials(void* stream, const void* x, void
   hipStream_t s = (hipStream_t)stream;
   prof_begin(s, PROF_NORM, 0.0, 2.0 * 2.0 * B * H * (double)W * C);
   gn_prefix(F, 1, groups);
-  hipLaunchKernelGGL(gn_fold_kernel, dim3(F.blk0[MX_MAX_SEGS]), dim3(kFoldThreads), 0, s, F, gamma, beta, groups, eps);
+  MX_CHECK(add_rowbias == nullptr || (add_bias != nullptr && ldrb >= C), "groupnorm: add_rowbias needs add_bias and ldrb >= C");
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(F.blk0[MX_MAX_SEGS]), dim3(kFoldThreads), 0, s, F, gamma, beta, groups, eps, add_bias, add_rowbias, ldrb);
   MX_LAUNCH_CHECK();
   if (gn_launch_apply(s, G, silu)) return 1;
   prof_end(s);

@@ -446,14 +446,15 @@ struct Plan {
     return ok();
   }
   // GroupNorm whose statistics the producing launch left as partial sums per 64 rows (conv(): gn_part); one resolution group, exact statistics
-  bool groupnorm_from_partials(const bf16_t* x, bf16_t* y, const std::string& prefix, int h, int wd, int C, float eps, bool silu, const float* part) {
+  bool groupnorm_from_partials(const bf16_t* x, bf16_t* y, const std::string& prefix, int h, int wd, int C, float eps, bool silu, const float* part,
+                               const float* add_bias, const float* add_rowbias, int ldrb) {
     if (!ok()) return false;
     const size_t m = ar.mark();
     void* ws = ar.alloc(mx::gn_workspace_exact(gB[0], h, wd, C, 0));
     if (!ws) return fail("workspace too small");
     const float* g = wf(prefix + ".weight", C); const float* b = wf(prefix + ".bias", C);
     if (ok() && !quiet()) {
-      if (mx_groupnorm_nhwc_from_partials(stream, x, y, g, b, gB[0], h, wd, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, part, 64, ws))
+      if (mx_groupnorm_nhwc_from_partials(stream, x, y, g, b, gB[0], h, wd, C, u->cfg.norm_num_groups, eps, silu ? 1 : 0, part, 64, add_bias, add_rowbias, ldrb, ws))
         fail(std::string("groupnorm: ") + mx_last_error());
     }
     ar.release(m);
@@ -548,7 +549,8 @@ struct Plan {
     conv(n1, h, wd, Cin, p + ".conv1", h1, Cout, 1, 0, patch, temb_all ? temb_all + temb_off : nullptr, temb_total, nullptr, 0, gpart, &gdone);
     temb_off += Cout;
     bf16_t* n2 = alloc<bf16_t>((size_t)M * Cout);
-    if (gdone) groupnorm_from_partials(h1, n2, p + ".norm2", h, wd, Cout, u->cfg.norm_eps, true, gpart);
+    if (gdone) groupnorm_from_partials(h1, n2, p + ".norm2", h, wd, Cout, u->cfg.norm_eps, true, gpart, wf(p + ".conv1.bias", Cout),
+                                       temb_all ? temb_all + (temb_off - Cout) : nullptr, temb_total);
     else groupnorm(h1, n2, p + ".norm2", h, wd, Cout, u->cfg.norm_eps, true, patch);
     const bf16_t* sc = x;
     if (Cin != Cout) {

@@ -151,7 +151,7 @@ def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_b
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, up: int = 0,
             corner_patch: int = 0, rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, splitk: int = 0, want_gn_partials: bool = False):
     """x NHWC bf16 [B,H,W,Cin]; w bf16 [Cout, 9*Cin] tap-major; returns NHWC bf16 [B,Ho,Wo,Cout].  ``want_gn_partials``: also return the per-64-row,
-    per-channel (sum, sum of squares) of the output [M / 64, Cout, 2] the launch left (mx_gemm_desc.gn_part_out), or None where it cannot."""
+    per-channel (sum, sum of squares) of its ACCUMULATORS (the output minus bias and row bias) [M / 64, Cout, 2] (mx_gemm_desc.gn_part_out), or None where it cannot."""
     l = _lib.load()
     _bf16(x); _bf16(w)
     b, h, wd, cin = x.shape
@@ -207,15 +207,17 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 def groupnorm_nhwc_from_partials(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool, part: torch.Tensor,
-                                 chunk: int = 64) -> torch.Tensor:
-    """GroupNorm (+SiLU) of x NHWC from the partial sums the producing launch left (conv3x3(..., want_gn_partials=True)): no statistics pass."""
+                                 chunk: int = 64, add_bias: Optional[torch.Tensor] = None, add_rowbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm (+SiLU) of x NHWC from the partial sums the producing launch left (conv3x3(..., want_gn_partials=True): sums of its accumulators, i.e. of
+    x minus ``add_bias`` [C] + ``add_rowbias`` [B, ld] -- pass the conv's bias and row bias): no statistics pass."""
     l = _lib.load()
     _bf16(x)
     b, h, w, c = x.shape
     y = torch.empty_like(x)
     ws = torch.empty(l.mx_groupnorm_nhwc_workspace_bytes(b, h, w, c), dtype=torch.uint8, device=x.device)
     _lib.check(l.mx_groupnorm_nhwc_from_partials(_lib.current_stream(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), b, h, w, c, groups, eps,
-                                                 1 if silu else 0, part.data_ptr(), chunk, ws.data_ptr()), "mx_groupnorm_nhwc_from_partials")
+                                                 1 if silu else 0, part.data_ptr(), chunk, _p(add_bias), _p(add_rowbias),
+                                                 add_rowbias.shape[1] if add_rowbias is not None else 0, ws.data_ptr()), "mx_groupnorm_nhwc_from_partials")
     return y
 
 
