@@ -16,7 +16,7 @@ Extra legs (outside the timed region):
   mixed_stream BASELINE configs[4] shape: a mixed-resolution Poisson stream (512 / 768 / 1024 px, 30-50 steps), continuous batching with
                the resolutions of a step in ONE launch sequence, the reference's metrics (SLO rate, goodput)
   sd3          BASELINE configs[2]: SD3.5-medium 1024^2 28-step, the same timed-step protocol, with its own roofline
-  cpu_baseline the CPU oracle (torch fp32, all host cores) timed on ONE UNet sample-forward at 1024^2 = 1/100 image -- on the inputs and
+  cpu_baseline the CPU oracle (torch fp32, ORACLE_THREADS = 32 host threads: the count at which it runs fastest on the GPU box) timed on ONE UNet sample-forward at 1024^2 = 1/100 image -- on the inputs and
                weights of one row of the bench's own batch, so the same run also checks that row of the HIP forward (parity_check)
 """
 import argparse
@@ -472,6 +472,25 @@ def time_side_stages(device, batch, step_s):
                     "on the host; NOT included in `value`"}
 
 
+ORACLE_THREADS = 32   # host threads of the fp32 torch oracles.  Measured on the GPU box (tools/exp/oracle_threads.py, profiles/r04_oracle_threads.txt: 256 CPUs visible,
+                      # torch's default 128 threads): one SD3.5-medium sample-forward 77 s at 128 threads, 55 at 64, 39.6 at 32, 39.4 at 16; SDXL-base 57 / 23 / 11.5 / 12.8 s
+
+
+def oracle_threads():
+    """context: the oracle legs run on ORACLE_THREADS host threads (or fewer where torch's default is lower)"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def ctx():
+        n = torch.get_num_threads()
+        torch.set_num_threads(min(n, ORACLE_THREADS))
+        try:
+            yield torch.get_num_threads()
+        finally:
+            torch.set_num_threads(n)
+    return ctx()
+
+
 def cpu_baseline(res, model, row=None):
     """The CPU baseline on the host cores: one sample-forward of the denoiser at full width.  Probes for stock diffusers + weights
     first (kind 'diffusers'); on this pool the probe has always come back negative (profiles/r02_probe_env_gpubox.json), so the
@@ -479,7 +498,7 @@ def cpu_baseline(res, model, row=None):
     (params fp32 on the CPU, sample, timestep, ehs, text_embeds, time_ids) -- so that the oracle's answer for the row also checks the
     HIP forward of the headline batch (returned as the second value)."""
     usable, probe_note = probe_diffusers()
-    threads = torch.get_num_threads()
+    threads = min(torch.get_num_threads(), ORACLE_THREADS)     # (the caller holds oracle_threads())
     if model == "sd3":
         from oracle import sd3_mmdit_ref as mref
         cfg = mref.MMDiTConfig.sd35_medium()
@@ -943,7 +962,8 @@ def main():
                 hip_row, oracle3, k3 = sd3_parity
                 progress("sd3 oracle starts")
                 try:
-                    want3 = oracle3()
+                    with oracle_threads():
+                        want3 = oracle3()
                     err = hip_row - want3
                     l2, mx = float(err.norm() / want3.norm()), float(err.abs().max() / want3.abs().max())
                     blk["parity_check"] = {"what": f"row {k3} (conditional row of the last request) of the HIP forward of this block's own batch of {2 * args.batch} at its "
@@ -965,6 +985,8 @@ def main():
     # ---- CPU baseline leg (+ the parity check of the headline batch's row) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         progress("cpu baseline starts")
+        _oracle_ctx = oracle_threads()
+        _oracle_ctx.__enter__()
         result["cpu_baseline"], want = cpu_baseline(args.res, args.model, parity_row)
         if config1 is not None and parity_row is not None and time.perf_counter() - _T0 > 380.0:
             result["cpu_baseline"]["config1"] = {"skipped": "the run had used its wall-clock allowance (380 s) on a slow host before this leg"}
@@ -982,6 +1004,7 @@ def main():
                 "cpu_seconds_per_step": dt1, "cpu_seconds_4_steps_extrapolated": 4 * dt1, "cpu_images_per_s": 1.0 / (4 * dt1),
                 "hip_seconds_per_step": hip_dt1, "hip_images_per_s_unet_only": 1.0 / (4 * hip_dt1),
                 "hip_vs_oracle_rel_l2": float(e1.norm() / want1.norm()), "hip_vs_oracle_max_err_frac_of_range": float(e1.abs().max() / want1.abs().max())}
+        _oracle_ctx.__exit__(None, None, None)
         progress("cpu baseline done")
         if parity_row is not None:
             err = (parity_hip - want)

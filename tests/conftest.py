@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def oracle_host_threads():
+    """The fp32 torch oracles run fastest on ~32 host threads on the GPU box (256 CPUs visible, torch defaults to 128: an SDXL-base 1024^2 sample-forward takes
+    57 s at 128 threads, 11.5 s at 32; SD3.5-medium 77 s vs 39.6 s: tools/exp/oracle_threads.py, profiles/r04_oracle_threads.txt).  Fewer where the host has fewer."""
+    import torch
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(n, 32))
+    yield
+    torch.set_num_threads(n)
+
+
 @pytest.fixture(scope="session")
 def cuda_device():
     import torch

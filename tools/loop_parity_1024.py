@@ -45,6 +45,7 @@ def main_sd3(steps, log):
 
 
 def main():
+    torch.set_num_threads(min(torch.get_num_threads(), 32))     # the oracles run fastest on ~32 host threads on the GPU box (profiles/r04_oracle_threads.txt)
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "loop_parity_1024.txt")
     log = lambda m: (print(m, flush=True), open(out, "a").write(m + "\n"))
