@@ -216,3 +216,27 @@ def test_sdxl_base_width_30_step_loop_256px(full_width_sdxl):
     model = lambda x, t, e, te, ti: ref.unet_forward(P32, ocfg, x, t, e, te, ti)
     with torch.inference_mode():
         assert _run_schedule(den, dev, cpu, [0], model, "sdxl", 5.0, {}, "sdxl-base 30-step loop at 256 px", SDXL_BASE_LAW) == 30
+
+
+def test_sdxl_base_1024_loop_first_steps(full_width_sdxl):
+    """The loop AT THE HEADLINE SIZE (round 4): SDXL-base widths, ONE 1024 x 1024 request of the 50-step schedule under CFG (UNet batch 2), the first four
+    steps against the oracle chain on the original weights -- scale, UNet, CFG combine, Euler, latents kept in bf16 between steps on both sides.  (The
+    fp32 oracle costs ~25 s per CFG step at this size on 32 host threads; the first six steps are logged once per round by tools/loop_parity_1024.py:
+    0.79 / 1.16 / 1.40 / 1.80 / 2.29 / 2.22 % rel L2, profiles/r04_l_loop_parity_1024.txt.)  Same law as the 256 px loop at this width."""
+    from sduss_amd.config import UNetConfig
+    from sduss_amd.pipeline import SDXLDenoiser, synthetic_request
+    ocfg, P, _held, net = full_width_sdxl
+    den = SDXLDenoiser(net, guidance_scale=5.0)
+    r = synthetic_request(0, 1024, 50, UNetConfig.sdxl_base(), den, "cuda:0")
+    c = _mirror_sdxl(r)
+    P32 = {k: v.float() for k, v in P.items()}
+    model = lambda x, t, e, te, ti: ref.unet_forward(P32, ocfg, x, t, e, te, ti)
+    a, b = SDXL_BASE_LAW
+    with torch.inference_mode():
+        for n in range(1, 5):
+            den.denoising_step({"1024": [r]})
+            chain_ref.denoising_step({"1024": [c]}, model, "sdxl", 5.0)
+            assert r.step_index == c.step_index == n
+            l2, mx = _errs(r.latents, c.latents)
+            _log(f"sdxl-base 1024 px loop: after step {n}: rel L2 {l2:.4f} max {mx:.4f} (bound {_law(n, a, b):.4f})")
+            assert l2 <= _law(n, a, b) and mx <= 4 * _law(n, a, b), f"after {n} steps: rel L2 {l2:.4f}, max {mx:.4f} of range"
