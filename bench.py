@@ -88,11 +88,11 @@ def parse():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--model", choices=["sdxl", "sd3"], default="sdxl", help="sdxl = BASELINE configs[1] (the headline metric); sd3 = configs[2]")
     ap.add_argument("--sliced", action="store_true", help="is_sliced=True, patch_size=256 (the reference's mixed-policy setting)")
-    ap.add_argument("--stream-requests", type=int, default=64, help="requests per GPU of the main Poisson leg (0 = skip the stream legs)")
+    ap.add_argument("--stream-requests", type=int, default=80, help="requests per GPU of the main Poisson leg (0 = skip the stream legs)")
     ap.add_argument("--stream-rates", type=str, default="1.0,0.8,1.2",
                     help="offered loads in requests/s PER GPU (the reference sweeps {0.8..1.2} x N_gpu req/s, scripts/paper/scalibility.sh:12-13); "
                          "the first is the main leg, the others run stream-requests/5 requests each")
-    ap.add_argument("--mix", type=int, default=None, help="(default: 24 on the default SDXL run, else 0) configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
+    ap.add_argument("--mix", type=int, default=None, help="(default: 28 on the default SDXL run, else 0) configs[4] leg: this many mixed-resolution requests per GPU (512/768/1024 uniform, steps 30..50 as the "
                                                        "reference traces exp/<model>/qps_*.csv) per offered load of --mix-rates; reports the reference's metrics "
                                                        "(scripts/draw/get_metric.py: SLO rate, average latency, goodput, throughput)")
     ap.add_argument("--mix-rates", type=str, default="1.0,2.0")
@@ -109,7 +109,7 @@ def parse():
     ap.add_argument("--no-two-model", action="store_true", help="skip the configs[4] leg with SDXL and SD3.5 requests interleaved in one stream")
     a = ap.parse_args()
     if a.mix is None:
-        a.mix = 24 if (a.model == "sdxl" and a.res == 1024) else 0
+        a.mix = 28 if (a.model == "sdxl" and a.res == 1024) else 0
     if a.pp is None:
         a.pp = a.gpus if (a.gpus > 1 and a.model == "sdxl") else 0
     if a.pp and (a.pp < 2 or a.gpus % a.pp):
