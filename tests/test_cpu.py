@@ -389,6 +389,26 @@ def test_layernorm_fold_algebra_and_tile_policy():
     assert l.mx_gemm_stats_slabs(C.byref(desc(8192, 1280, 1280, lib.EPI_GEGLU))) == 0
     # a shape whose plain launch takes 256 x 256 tiles still yields statistics: asking for them moves it to a 256 / 128-row tile
     assert l.mx_gemm_ln_prefers_pass(C.byref(desc(32768, 5120, 640))) == 1 and l.mx_gemm_stats_slabs(C.byref(desc(32768, 5120, 640))) > 0
+    # round 4, the shape queries of the late additions (host only, the same chooser the launch uses):
+    # finalised row statistics need a 256-row tile of the producer (headline batch: yes; one request: 128-row tiles, no)
+    def producer(m, k):
+        d = desc(m, 1280, k); d.residual, d.ldr = 32768, 1280
+        return d
+    assert l.mx_gemm_ln_final_supported(C.byref(producer(8192, 1280))) == 1 and l.mx_gemm_ln_final_supported(C.byref(producer(8192, 5120))) == 1
+    assert l.mx_gemm_ln_final_supported(C.byref(producer(2048, 1280))) == 0 and l.mx_gemm_ln_final_supported(C.byref(desc(8192, 10240, 1280, lib.EPI_GEGLU))) == 0
+    # tail split: one 1024 px request's GEGLU is 1.25 rounds of 256 x 256 tiles -> two launches; the headline batch (5 whole rounds) and QKV stay one
+    assert l.mx_gemm_launches(C.byref(desc(2048, 10240, 1280, lib.EPI_GEGLU))) == 2 and l.mx_gemm_launches(C.byref(desc(4096, 10240, 1280, lib.EPI_GEGLU))) == 2
+    assert l.mx_gemm_launches(C.byref(desc(8192, 10240, 1280, lib.EPI_GEGLU))) == 1 and l.mx_gemm_launches(C.byref(desc(8192, 1280, 1280))) == 1
+    # GroupNorm partial sums: a chip-filling conv with the time-embedding row bias can leave them; with a residual, or on 128-row tiles, it cannot
+    def conv(b, hw, cin, cout, residual=False):
+        d = lib.GemmDesc()
+        d.a, d.w, d.c, d.bias, d.rowbias = 4096, 8192, 16384, 32768, 65536
+        d.M, d.N, d.K, d.ldc, d.ldr, d.ldrb, d.rows_per_batch = b * hw * hw, cout, 9 * cin, cout, cout, cout, hw * hw
+        d.B, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride = b, hw, hw, cin, hw, hw, 1
+        if residual: d.residual = 131072
+        return d
+    assert l.mx_gemm_gn_partials_supported(C.byref(conv(8, 32, 1280, 1280)), 1) == 1 and l.mx_gemm_gn_partials_supported(C.byref(conv(8, 128, 320, 320)), 1) == 1
+    assert l.mx_gemm_gn_partials_supported(C.byref(conv(8, 32, 1280, 1280, residual=True)), 1) == 0 and l.mx_gemm_gn_partials_supported(C.byref(conv(1, 32, 1280, 1280)), 1) == 0
 
 
 def test_clip_plan_resolves_packed_weights_on_host():
