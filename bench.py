@@ -42,7 +42,8 @@ HBM_PEAK = 8.0e12
 KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<128,true> (conv3x3)",
               "gemm_kernel<64,true> (conv3x3)", "attn_fwd_kernel", "groupnorm (3 kernels)", "gemm_v5/v2_kernel<160,false>",
               "gemm_v5/v2_kernel<160,true> (conv3x3)", "gemm_v5/v2_kernel<128,false>", "gemm_v5/v2_kernel<128,true> (conv3x3)",
-              "gemm_v4_kernel (256x256 ping-pong)", "attn_cross_kernel (Lk<=96)"]
+              "gemm_v4_kernel (256x256 ping-pong)", "attn_cross_kernel (Lk<=96)",
+              "attn_tail_kernel (to_out + to_q + cross-attention + to_out, one chained launch)"]
 
 
 KIND_SYMBOLS = {  # bench kernel label -> regex over the symbols in the rocprofv3 summaries (all instantiations of the kind)

@@ -230,9 +230,36 @@ int mx_row_stats(void* stream, const void* x, int ldx, float* stats, int M, int 
 int mx_conv3x3(void* stream, const mx_gemm_desc* d);   /* implicit GEMM, pad 1 */
 /* Slices the K range of d is dealt to (1 = no split).  Small launches -- fewer 128-row tiles than CUs and >= 16 K tiles: one request, light mixed
  * batches -- run SPLIT-K: every output tile is computed by up to 4 workgroups over disjoint K ranges; each leaves its fp32 partial tile in a
- * library-owned scratch (96 MB + counters per stream, allocated at a stream's first split launch, never during a capture) and takes a ticket;
- * the last arriver adds the partials IN SLICE ORDER (bit-stable run to run) and runs the ordinary epilogue.  Shape-based and host-only. */
+ * library-owned scratch (96 MB + counters per stream, allocated at a stream's first split launch -- also while that stream is being captured:
+ * the allocation does not touch the capturing stream) and takes a ticket; the last arriver adds the partials IN SLICE ORDER (bit-stable run to
+ * run) and runs the ordinary epilogue.  The value returned is what mx_gemm / mx_conv3x3 (d) DOES: the decision depends on the descriptor alone, so a
+ * shape adds its products in the same order eagerly, under capture and on replay; a scratch that cannot be allocated makes the launch fail (set
+ * d->splitk = 1 to run unsplit).  Shape-based and host-only. */
 int mx_gemm_splitk(const mx_gemm_desc* d, int conv);
+/* frees the split-K scratch of `stream` (all != 0: of every stream) after waiting for that stream; library unload frees what is left */
+void mx_gemm_release_scratch(void* stream, int all);
+
+/* ---- the ATTENTION TAIL of a BasicTransformerBlock as ONE launch (round 5; attn_tail.hip).  The four dependent launches
+ *   y = attn1.to_out(ao) + y (+ row statistics)  ->  q2 = attn2.to_q(norm2(y))  ->  ao2 = softmax(q2 K^T) V over the text keys  ->  y = attn2.to_out(ao2) + y (+ statistics)
+ * (transformer.py:204-262, attention.py:59-110) become work items of one persistent launch: a 256-row panel's items of stage s need stage s - 1 of the same
+ * panel only, and the workgroups that take them hand the panel's rows over inside the launch (write-through stores, a ticket per panel and stage).  The
+ * three descriptors are EXACTLY those of the separate launches (mx_gemm(out1); mx_gemm(to_q); mx_attention_cross_prescaled; mx_gemm(out2)) and the results
+ * equal theirs bit for bit: the same tiles of the same kernels in the same order of summation.  mx_attn_tail_supported tells whether a descriptor can be
+ * served (plain C x C linears on 256 x 160 tiles over M = B * L rows, L % 256 == 0, C = heads * 64, ctx_len <= 96; to_q reads out1's output and slab
+ * statistics; ao / y / q2 / ao2 four different buffers, the two statistics buffers different; MX_ATTN_TAIL=0 in the environment switches it off).
+ * sync: mx_attn_tail_sync_bytes(M) bytes of device memory, ZERO before the first launch; every launch leaves them zero (except the error word read by
+ * mx_attn_tail_status: != 0 when a wait inside a launch gave up after ~2^22 polls instead of hanging the device -- that launch's output is invalid). ---- */
+typedef struct mx_attn_tail_desc {
+  mx_gemm_desc out1, to_q, out2;
+  const void* k; int ldk;                    /* the layer's cross-attention keys: bf16 [B * ctx_len, ldk] */
+  const void* vt; int ldvt; int64_t vt_batch_stride;   /* V^T in MX_VT_POS order, per sample */
+  int B, heads, L, ctx_len;
+  unsigned* sync;
+} mx_attn_tail_desc;
+size_t mx_attn_tail_sync_bytes(int M);
+int mx_attn_tail_supported(const mx_attn_tail_desc* d);
+int mx_attn_tail(void* stream, const mx_attn_tail_desc* d);
+int mx_attn_tail_status(void* stream, const unsigned* sync, unsigned* word);
 
 /* V^T key order.  The attention kernel feeds its softmax accumulator straight back to the matrix core as the
  * P operand, and that register layout interleaves keys in blocks of four (lane half h owns keys 4h..4h+3 and
@@ -255,6 +282,10 @@ int mx_attention(void* stream, const void* q, int ldq, const void* k, int ldk, c
 #define MX_ATTN_QSCALE(scale) ((scale) * 1.4426950408889634f)
 int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk);
+/* the same through the SHORT-KEY kernel whatever Lq (Lk <= 96: every wave keeps the head's K / V^T in registers): what stage 2 of mx_attn_tail runs;
+ * mx_attention_prescaled itself takes this kernel from Lq >= 2048 and the general one below (the two differ in bf16 rounding of P) */
+int mx_attention_cross_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                 int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk);
 /* Grouped form: the attention problems of all resolutions present in a mixed batch in ONE launch (see mx_gemm_seg).  The problems share the row
  * strides and the head count; each has its own batch, sequence lengths and operand bases.  One kernel serves the whole launch (chosen by the
  * longest query sequence); the arithmetic per problem is that of mx_attention_prescaled with the same kernel. */
@@ -354,6 +385,17 @@ void mx_unet_destroy(mx_unet* u);
  * outlive the handle; the table is copied */
 int mx_unet_set_weights(mx_unet* u, const void* blob, uint64_t blob_bytes,
                         const mx_weight_entry* table, int n_entries);
+/* PER-COMPOSITION store of the cross-attention K / V^T (round 5).  The text embeddings of a request do not change over its steps, yet the
+ * reference's step re-concatenates them and every forward projects them again for all 70 transformer layers (pipeline_stable_diffusion_xl_esymred.py:
+ * 287-339; attention.py:59-110 to_kv).  A caller that knows the batch composition names it: key != 0 promises that every forward issued while
+ * this key is set receives encoder_hidden_states with the same CONTENT and row order as the first one did (same batch, same ctx_len).  The first
+ * such forward projects into library-owned device buffers, later ones read them -- the same GEMM's output, bit for bit -- until the key changes
+ * (up to 4 compositions are kept, least recently used first out; ~26 MB per sample row at SDXL-base width).  key = 0 (the default) projects at every
+ * forward.  Applies to mx_unet_forward / _forward_mixed (not to the patch-parallel or block-cache entry points, nor under MX_GRAPH=1);
+ * mx_unet_set_weights drops every stored projection.  Entries are handed between streams through events: forwards of one handle may be issued on
+ * several streams, from one host thread. */
+int mx_unet_set_context_key(mx_unet* u, uint64_t key);
+int mx_unet_context_stats(const mx_unet* u, long* hits, long* misses);   /* forwards served from / written to the store since creation */
 size_t mx_unet_workspace_bytes(const mx_unet* u, int batch, int H, int W, int ctx_len);
 /* host-only walk of the step plan that resolves every packed tensor by name and size (no launches, no GPU needed) */
 int mx_unet_validate(const mx_unet* u, int batch, int H, int W, int ctx_len);

@@ -167,7 +167,12 @@ def _heads(x, h):
     return x.reshape(b, l, h, c // h).transpose(1, 2)
 
 
+_LOWP = {"sdpa": False}
+
+
 def _sdpa(q, k, v):
+    if _LOWP["sdpa"]:      # the low-precision comparator only (mmdit_forward compute_dtype != fp32): the fused kernel the reference itself calls (attention.py:350)
+        return F.scaled_dot_product_attention(q, k, v)
     s = torch.matmul(q, k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
     return torch.matmul(torch.softmax(s, dim=-1), v)
 
@@ -232,18 +237,25 @@ def joint_block(P, b, x, ctx, temb, cfg: MMDiTConfig, last: bool, dual: bool):
 
 
 def mmdit_forward(P: Dict[str, torch.Tensor], cfg: MMDiTConfig, latents: torch.Tensor, timestep: torch.Tensor,
-                  encoder_hidden_states: torch.Tensor, pooled: torch.Tensor, trace: Optional[dict] = None) -> torch.Tensor:
+                  encoder_hidden_states: torch.Tensor, pooled: torch.Tensor, trace: Optional[dict] = None,
+                  compute_dtype: torch.dtype = torch.float32, device=None, sdpa: bool = False) -> torch.Tensor:
     """latents [B, C, H, W]; timestep [B]; encoder_hidden_states [B, Lt, joint_dim]; pooled [B, pooled_dim] -> [B, C, H, W]."""
-    P = {k: v.to(torch.float32) for k, v in P.items()}
-    x = latents.to(torch.float32)
+    # compute_dtype / device / sdpa: the SAME graph evaluated by stock torch ops in bf16 or fp16 on the GPU box -- the yardstick the parity
+    # tolerances are calibrated against (tests/test_parity_calibration_gpu.py); the oracle proper is the fp32 default.
+    dev = torch.device(device) if device is not None else latents.device
+    dt = compute_dtype
+    P = {k: v.to(device=dev, dtype=dt) for k, v in P.items()}
+    x = latents.to(device=dev, dtype=dt)
+    timestep = timestep.to(dev)
+    _LOWP["sdpa"] = bool(sdpa)
     b, c, hh, ww = x.shape
     ps = cfg.patch_size
     h, w = hh // ps, ww // ps
     d = cfg.dim
     # time_text_embed (SD3Transformer.py:81)
-    t = F.linear(timestep_embedding(timestep, 256), P["time_text_embed.timestep_embedder.linear_1.weight"], P["time_text_embed.timestep_embedder.linear_1.bias"])
+    t = F.linear(timestep_embedding(timestep, 256).to(dt), P["time_text_embed.timestep_embedder.linear_1.weight"], P["time_text_embed.timestep_embedder.linear_1.bias"])
     t = F.linear(F.silu(t), P["time_text_embed.timestep_embedder.linear_2.weight"], P["time_text_embed.timestep_embedder.linear_2.bias"])
-    pp = F.linear(pooled.to(torch.float32), P["time_text_embed.text_embedder.linear_1.weight"], P["time_text_embed.text_embedder.linear_1.bias"])
+    pp = F.linear(pooled.to(device=dev, dtype=dt), P["time_text_embed.text_embedder.linear_1.weight"], P["time_text_embed.text_embedder.linear_1.bias"])
     pp = F.linear(F.silu(pp), P["time_text_embed.text_embedder.linear_2.weight"], P["time_text_embed.text_embedder.linear_2.bias"])
     temb = t + pp
     # pos_embed (PatchEmbed): conv p x p stride p, flatten, + centre-cropped table (:82-83)
@@ -252,7 +264,7 @@ def mmdit_forward(P: Dict[str, torch.Tensor], cfg: MMDiTConfig, latents: torch.T
     top, left = (m - h) // 2, (m - w) // 2
     pe = P["pos_embed.pos_embed"].reshape(1, m, m, d)[:, top:top + h, left:left + w].reshape(1, h * w, d)
     x = x + pe
-    ctx = F.linear(encoder_hidden_states.to(torch.float32), P["context_embedder.weight"], P["context_embedder.bias"])
+    ctx = F.linear(encoder_hidden_states.to(device=dev, dtype=dt), P["context_embedder.weight"], P["context_embedder.bias"])
     if trace is not None:
         trace["embed"] = x; trace["context_embed"] = ctx; trace["temb"] = temb
     for i in range(cfg.num_layers):
@@ -266,6 +278,7 @@ def mmdit_forward(P: Dict[str, torch.Tensor], cfg: MMDiTConfig, latents: torch.T
     x = F.linear(x, P["proj_out.weight"], P["proj_out.bias"])
     x = x.reshape(b, h, w, ps, ps, cfg.out_channels)
     x = torch.einsum("nhwpqc->nchpwq", x).reshape(b, cfg.out_channels, h * ps, w * ps)    # :250-259
+    _LOWP["sdpa"] = False
     return x
 
 

@@ -267,7 +267,7 @@ def fast_params(cfg: UNetConfig, seed: int = 10086) -> Dict[str, torch.Tensor]:
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     """diffusers ``Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)`` -> [cos | sin]."""
     half = dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
     ang = t.reshape(-1, 1).to(torch.float32) * torch.exp(exponent)[None, :]
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
 
@@ -296,6 +296,9 @@ def _gn(x, groups, w, b, eps, gn_patch):
     return group_norm_patchavg(x, groups, w, b, eps, gn_patch)
 
 
+_LOWP = {"sdpa": False}
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
     """softmax(Q K^T / sqrt(d)) V, no mask -- what xformers.memory_efficient_attention(q,k,v)
     computes at attention.py:86,214 after ``head_to_batch_dim``."""
@@ -304,8 +307,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> 
     qh = q.reshape(b, lq, heads, d).transpose(1, 2)
     kh = k.reshape(b, -1, heads, d).transpose(1, 2)
     vh = v.reshape(b, -1, heads, d).transpose(1, 2)
-    s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.matmul(torch.softmax(s, dim=-1), vh)
+    if _LOWP["sdpa"]:      # the low-precision comparator only (unet_forward compute_dtype != fp32): the fused kernel a stock pipeline would call
+        o = F.scaled_dot_product_attention(qh, kh, vh)
+    else:
+        s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
+        o = torch.matmul(torch.softmax(s, dim=-1), vh)
     return o.transpose(1, 2).reshape(b, lq, c)
 
 
@@ -404,12 +410,13 @@ def transformer_2d(P, p, x, ctx, heads, layers, cfg: UNetConfig, gn_patch, trace
 
 def time_and_aug_embedding(P, cfg: UNetConfig, timestep, text_embeds, time_ids):
     """unet.py:314-334 -> diffusers get_time_embed / time_embedding / get_aug_embed ('text_time')."""
-    t_emb = timestep_embedding(timestep, cfg.block_out_channels[0])
+    dt = P["time_embedding.linear_1.weight"].dtype       # (diffusers: the sinusoids are fp32, then cast to the model dtype)
+    t_emb = timestep_embedding(timestep, cfg.block_out_channels[0]).to(dt)
     emb = F.linear(t_emb, P["time_embedding.linear_1.weight"], P["time_embedding.linear_1.bias"])
     emb = F.linear(F.silu(emb), P["time_embedding.linear_2.weight"], P["time_embedding.linear_2.bias"])
     b = text_embeds.shape[0]
     tid = timestep_embedding(time_ids.reshape(-1), cfg.addition_time_embed_dim).reshape(b, -1)
-    add = torch.cat([text_embeds.to(torch.float32), tid], dim=-1)
+    add = torch.cat([text_embeds.to(torch.float32), tid], dim=-1).to(dt)
     aug = F.linear(add, P["add_embedding.linear_1.weight"], P["add_embedding.linear_1.bias"])
     aug = F.linear(F.silu(aug), P["add_embedding.linear_2.weight"], P["add_embedding.linear_2.bias"])
     return emb + aug
@@ -418,7 +425,8 @@ def time_and_aug_embedding(P, cfg: UNetConfig, timestep, text_embeds, time_ids):
 def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample: torch.Tensor, timestep: torch.Tensor,
                  encoder_hidden_states: torch.Tensor, text_embeds: torch.Tensor, time_ids: torch.Tensor,
                  gn_patch: Optional[int] = None, trace: Optional[dict] = None,
-                 sliced_corners: bool = False) -> torch.Tensor:
+                 sliced_corners: bool = False, compute_dtype: torch.dtype = torch.float32, device=None,
+                 sdpa: bool = False) -> torch.Tensor:
     """One UNet forward on whole latents.
 
     sample [B, C_in, H, W] fp32; timestep [B]; encoder_hidden_states [B, 77, ctx];
@@ -429,10 +437,14 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample: torch.Tens
     ``conv3x3`` to every 3x3 conv after conv_in; ``gn_patch=p, sliced_corners=True`` is the whole-image
     equivalent of ``patch_ref.unet_forward_sliced`` (tests/test_oracle.py checks the two agree).
     """
-    P = {k: v.to(torch.float32) for k, v in P.items()}
-    x = sample.to(torch.float32)
-    ctx = encoder_hidden_states.to(torch.float32)
-    emb = time_and_aug_embedding(P, cfg, timestep, text_embeds, time_ids)
+    # compute_dtype / device / sdpa: the SAME graph evaluated by stock torch ops in bf16 or fp16 on the GPU box -- the yardstick the parity
+    # tolerances are calibrated against (tests/test_parity_calibration_gpu.py); the oracle proper is the fp32 default.
+    dev = torch.device(device) if device is not None else sample.device
+    P = {k: v.to(device=dev, dtype=compute_dtype) for k, v in P.items()}
+    x = sample.to(device=dev, dtype=compute_dtype)
+    ctx = encoder_hidden_states.to(device=dev, dtype=compute_dtype)
+    _LOWP["sdpa"] = bool(sdpa)
+    emb = time_and_aug_embedding(P, cfg, timestep.to(dev), text_embeds.to(dev), time_ids.to(dev))
     ch = cfg.block_out_channels
     nlev = len(ch)
 
@@ -480,6 +492,7 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample: torch.Tens
                 trace[f"up_blocks.{i}.upsamplers.0"] = x
     x = F.silu(_gn(x, cfg.norm_num_groups, P["conv_norm_out.weight"], P["conv_norm_out.bias"], cfg.norm_eps, lp(0)))
     x = conv3x3(x, P["conv_out.weight"], P["conv_out.bias"], 1, lp(0) if sliced_corners else None)
+    _LOWP["sdpa"] = False
     return x
 
 

@@ -37,24 +37,10 @@
 
 #include "common.h"
 #include "../../include/mxdenoise.h"
+#include "attn_cross_body.h"
 
 namespace mx {
 
-struct AttnArgs {
-  const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;
-  int ldq, ldk, ldvt, ldo;
-  long vt_bstride;
-  int B, H, Lq, Lk;
-  float scale_log2;  // scale * log2(e)
-  int xcd_map;       // 1: XCD-aware workgroup order (needs B*H % 8 == 0)
-  // patch-parallel K / V^T (mx_attention_prescaled_chunked): keys come in `key_chunk`-long chunks gathered from the ranks;
-  // chunk c of batch b starts at k + c * k_cstride + b * k_bstride (rows of ldk) and vt + c * vt_cstride + b * vt_bstride
-  int key_chunk;     // 0: one contiguous key range per batch
-  long k_bstride, k_cstride, vt_cstride;
-  int causal;        // 1: key j counts for query i only when j <= i (text encoders; attn_fwd_kernel only)
-  const float* bias; // additive score bias [H][Lq][ldb], already in the kernel's log2 domain (T5 relative position bias; attn_fwd_kernel only)
-  int ldb;
-};
 
 // Grouped launch (mx_attention_prescaled_grouped): up to MX_MAX_SEGS problems -- the resolutions of a mixed batch, each with its own
 // sequence lengths, batch and operand bases -- in ONE launch.  A workgroup finds its problem from its index with two compares and runs the
@@ -96,20 +82,6 @@ __device__ __forceinline__ const AttnArgs& attn_locate(const AttnGroup& ga, int&
 
 constexpr int KT = 64;                 // keys per tile
 constexpr int kBufBytes = 16384;       // one ring buffer: K tile (8 KB) then V^T tile (8 KB)
-
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {   // one v_cvt_pk_bf16_f32
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
-}
-
-// max over the two half-waves (lane l and l^32) without the LDS crossbar: v_permlane32_swap exchanges the upper half
-// of a with the lower half of b.  Inline asm because the builtin folds its two results when both inputs are one value.
-__device__ __forceinline__ float max_across_halves(float x) {
-  float a = x, b = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return fmaxf(a, b);
-}
 
 // EXTRA: the additive-bias and causal-mask forms of the text encoders, a separate instantiation (as run-time branches they cost the
 // 60 cross-attention launches of a UNet step 3.4 us each: profiles r02_f vs r02_g)
@@ -1039,152 +1011,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnGroup ga) 
 //     Q rows are fetched while the current one computes.
 // The launch is bound by its HBM traffic (Q read + O write); K / V^T stay in L2.
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr int XK_MAXBLK = 3;                   // 32-key blocks (Lk <= 96)
-constexpr int XK_QPW = 64;                     // queries per wave (two 32-query blocks)
-
 template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnGroup ga) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 4096];       // one 32 x 64 bf16 patch per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int r = lane & 31;
-  const int hh = lane >> 5;
   int qb, bh;
   const AttnArgs& p = attn_locate<4 * XK_QPW>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
   if (qb < 0) return;
-  const int head = bh % p.H;
-  const int b = bh / p.H;
-  const int nblk = (p.Lk + 31) >> 5;           // <= XK_MAXBLK (launcher)
-  const int nst = (p.Lk + 15) >> 4;
-
-  // ---- K fragments (A operand of S^T): K[32 kb + r][16 ks + 8 hh ..]; rows >= Lk are zero ----
-  bf16x8 kf[XK_MAXBLK][4];
-  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-#pragma unroll
-  for (int kb = 0; kb < XK_MAXBLK; ++kb) {
-    const int key = kb * 32 + r;
-    const bf16_t* kp = p.k + ((long)b * p.Lk + (key < p.Lk ? key : 0)) * p.ldk + head * 64 + hh * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = (kb < nblk && key < p.Lk) ? *reinterpret_cast<const bf16x8*>(kp + ks * 16) : zero8;
-  }
-  // ---- V^T fragments (A operand of O^T): vt[64 head + 32 db + r][16 s + 8 hh ..] (MX_VT_POS order); keys >= Lk zeroed, the pad of
-  //      a V^T row may hold anything ----
-  bf16x8 vf[2 * XK_MAXBLK][2];
-#pragma unroll
-  for (int st = 0; st < 2 * XK_MAXBLK; ++st) {
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (st < nst) {
-        v = *reinterpret_cast<const u32x4*>(p.vt + (long)b * p.vt_bstride + ((long)head * 64 + db * 32 + r) * p.ldvt + st * 16 + hh * 8);
-        // element e of the word is position 16 st + 8 hh + e = key 16 st + 4 hh + (e & 3) + 8 (e >> 2)   (MX_VT_POS swaps bits 2 and 3)
-        const int kbase = st * 16 + 4 * hh;
-        if (kbase + 12 > p.Lk) {               // some element may be past the end (only in the last step)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k0 = kbase + 2 * (e & 1) + 8 * (e >> 1);
-            unsigned w = v[e];
-            if (k0 >= p.Lk) w &= 0xffff0000u;
-            if (k0 + 1 >= p.Lk) w &= 0x0000ffffu;
-            v[e] = w;
-          }
-        }
-      }
-      vf[st][db] = __builtin_bit_cast(bf16x8, v);
-    }
-  }
-
-  const float c = PRE ? 1.0f : p.scale_log2;
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  char* patch = smem + wave * 4096;
-  const int q_wave0 = qb * (4 * XK_QPW) + wave * XK_QPW;
-
-  auto load_q = [&](bf16x8 (&qf)[4], int q0) __attribute__((always_inline)) {
-    int qi = q0 + r;
-    if (qi > p.Lq - 1) qi = p.Lq - 1;
-    const bf16_t* qp = p.q + ((long)b * p.Lq + qi) * p.ldq + head * 64 + hh * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-  };
-  bf16x8 qf[4], qn[4];
-  load_q(qf, q_wave0);
-#pragma unroll
-  for (int blk = 0; blk < XK_QPW / 32; ++blk) {
-    const int q0 = q_wave0 + blk * 32;
-    if (q0 >= p.Lq) break;                     // wave-uniform
-    if (blk + 1 < XK_QPW / 32) load_q(qn, q0 + 32);
-    // ---- S^T = K Q^T ----
-    f32x16 s[XK_MAXBLK];
-#pragma unroll
-    for (int kb = 0; kb < XK_MAXBLK; ++kb) {
-      s[kb] = zero16;
-      if (kb < nblk) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
-      }
-    }
-    // ---- single-pass softmax over the lane's keys (block kb element e = key 32 kb + (e & 3) + 8 (e >> 2) + 4 hh) ----
-    float mx_ = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < XK_MAXBLK; ++kb) {
-      if (kb >= nblk) continue;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        float v = s[kb][e] * c;
-        if ((kb + 1) * 32 > p.Lk && key >= p.Lk) v = -INFINITY;
-        s[kb][e] = v;
-        mx_ = fmaxf(mx_, v);
-      }
-    }
-    mx_ = max_across_halves(mx_);
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < XK_MAXBLK; ++kb) {
-      if (kb >= nblk) continue;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(s[kb][e] - mx_);
-        s[kb][e] = pe;
-        psum += pe;
-      }
-    }
-    const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
-    // ---- O^T = V^T P^T ----
-    f32x16 oacc[2] = {zero16, zero16};
-#pragma unroll
-    for (int st = 0; st < 2 * XK_MAXBLK; ++st) {
-      if (st >= nst) continue;
-      const int kb = st >> 1, s2 = st & 1;
-      u32x4 pw;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pw[e] = pack2(s[kb][8 * s2 + 2 * e], s[kb][8 * s2 + 2 * e + 1]);
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st][db], pf, oacc[db], 0, 0, 0);
-    }
-    // ---- O[q][d]: lane (r, hh) holds d = 32 db + 8 g + 4 hh + {0..3} of query r.  Through the wave's LDS patch (rows = queries,
-    //      128 B, 16-byte chunk ^= row & 7) so that the global stores are whole rows. ----
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const u32x2 o = {pack2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv), pack2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
-        const int chunk = (4 * db + g) ^ (r & 7);
-        *reinterpret_cast<u32x2*>(patch + r * 128 + chunk * 16 + hh * 8) = o;
-      }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (lane >> 3) + 8 * i;
-      const int ch = lane & 7;
-      const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * 128 + ((ch ^ (row & 7)) * 16));
-      const int qi = q0 + row;
-      if (qi < p.Lq) *reinterpret_cast<u32x4*>(p.o + ((long)b * p.Lq + qi) * p.ldo + head * 64 + ch * 8) = o;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
-  }
+  attn_cross_wave<PRE>(p, bh / p.H, bh % p.H, qb * (4 * XK_QPW) + wave * XK_QPW, smem + wave * 4096, lane);
 }
 
 }  // namespace mx
@@ -1222,7 +1058,7 @@ static int fill_attention_args(mx::AttnArgs& a, const void* q, int ldq, const vo
 
 // One launch over ga.n problems (ga.g filled).  The kernel is chosen for the launch as a whole -- by its longest query sequence -- and must
 // be able to serve every problem; otherwise the general register-staged kernel takes them all.
-static int launch_attention_group(void* stream, mx::AttnGroup& ga, bool pre) {
+static int launch_attention_group(void* stream, mx::AttnGroup& ga, bool pre, bool force_cross = false) {
   using namespace mx;
   const int n = ga.n;
   int maxLq = 0;
@@ -1244,7 +1080,8 @@ static int launch_attention_group(void* stream, mx::AttnGroup& ga, bool pre) {
   MX_CHECK(!extra || n == 1, "attention: the causal / bias forms are not grouped");
   // (at Lq 1024 the general kernel is 7 % faster than the short-key one: both are latency-bound)
   enum { K_GENERAL, K_CROSS, K_W64, K_DMA } kind = K_GENERAL;
-  if (all_short && maxLq >= 2048 && plain && o8) kind = K_CROSS;          // short key sequence: every wave keeps K / V^T in registers
+  if (force_cross) MX_CHECK(all_short && plain && o8, "attention: the short-key kernel needs Lk <= 96, no mask / bias / key chunks and ldo % 8 == 0");
+  if (all_short && (maxLq >= 2048 || force_cross) && plain && o8) kind = K_CROSS;          // short key sequence: every wave keeps K / V^T in registers
   else if (extra) kind = K_GENERAL;                                       // the masked / biased forms live in the register-staged kernel
   else if (pre && all_long_k && maxLq >= 2048 && o8) kind = K_W64;        // 64 query rows per wave (a tie with the 32-row kernels at Lq 1024)
   else if (whole_tiles) kind = K_DMA;                                     // whole tiles: LDS-DMA staging two tiles ahead
@@ -1314,6 +1151,15 @@ extern "C" int mx_attention(void* stream, const void* q, int ldq, const void* k,
 extern "C" int mx_attention_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                                       int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk) {
   return launch_attention(stream, q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, 1.0f, true);
+}
+
+/* mx_attention_prescaled through the short-key kernel whatever Lq: the separate-launch form of stage 2 of mx_attn_tail (attn_tail.hip) */
+extern "C" int mx_attention_cross_prescaled(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                                            int64_t vt_batch_stride, void* o, int ldo, int B, int H, int Lq, int Lk) {
+  mx::AttnGroup ga;
+  ga.n = 1;
+  if (fill_attention_args(ga.g[0], q, ldq, k, ldk, vt, ldvt, vt_batch_stride, o, ldo, B, H, Lq, Lk, 1.0f, true, 0, 0, 0, 0, false, nullptr, 0)) return 1;
+  return launch_attention_group(stream, ga, true, /*force_cross=*/true);
 }
 
 /* causal self-attention of a short sequence (the CLIP text encoders: 77 tokens), q prescaled as for mx_attention_prescaled */

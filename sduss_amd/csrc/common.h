@@ -122,7 +122,7 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- optional per-launch timing (bench.py roofline leg): hipEvents on the launch stream ----
 namespace mx {
-enum ProfKind { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_CONV128 = 2, PROF_CONV64 = 3, PROF_ATTN = 4, PROF_NORM = 5, PROF_GEMM_V2_160 = 6, PROF_CONV_V2_160 = 7, PROF_GEMM_V2_128 = 8, PROF_CONV_V2_128 = 9, PROF_GEMM_V3_256 = 10, PROF_ATTN_CROSS = 11, PROF_KINDS = 12 };
+enum ProfKind { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_CONV128 = 2, PROF_CONV64 = 3, PROF_ATTN = 4, PROF_NORM = 5, PROF_GEMM_V2_160 = 6, PROF_CONV_V2_160 = 7, PROF_GEMM_V2_128 = 8, PROF_CONV_V2_128 = 9, PROF_GEMM_V3_256 = 10, PROF_ATTN_CROSS = 11, PROF_ATTN_TAIL = 12, PROF_KINDS = 13 };
 bool prof_enabled();
 void prof_begin(hipStream_t s, int kind, double flops, double bytes, int m = 0, int n = 0, int k = 0);
 void prof_end(hipStream_t s);

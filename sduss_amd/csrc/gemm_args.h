@@ -544,7 +544,10 @@ __host__ __device__ inline int gemm_epi_features(int flags) {
 // instead of MI: the QKV instantiation of the 256 x 256 kernel)
 // (Tried in round 4 and dropped: the WHOLE fold in the epilogue -- acc * rstd + (bias - rstd * mean * colsum) from one 8-byte load per token block, nothing in
 // front of the K loop.  +7.9 us per GEGLU launch against +4 us for the accumulator start: the block-ahead load does not cover an L2 round trip.)
-template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true, int FEAT = EPI_F_ALL, bool EMIT = STATS, bool RSTD_LOAD = false>
+// WT: the output tile and its row statistics are stored WRITE-THROUGH (sc1: buffer stores with aux 16 over a descriptor of C, 8-byte agent-scope atomic
+// stores for the statistics) -- a chained launch (attn_tail.hip) hands them to other workgroups of the same launch (cdna guide, Guideline 16 R1); the
+// values stored are the same
+template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true, int FEAT = EPI_F_ALL, bool EMIT = STATS, bool RSTD_LOAD = false, bool WT = false>
 __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
                                                    const int fr, const int fq, const float (&ln_rstd_a)[MI]) {
   constexpr int NIO = GEGLU ? NI / 2 : NI;     // output blocks per wave
@@ -668,6 +671,16 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
   const unsigned ldr_b = (unsigned)p.ldr * 2u, ldc_b = (unsigned)p.ldc * 2u;
   auto res_at = [&](int row, int col) __attribute__((always_inline)) { return res_base + (unsigned long long)(unsigned)row * ldr_b + (unsigned)(col * 2); };
   auto c_at = [&](int row, int col) __attribute__((always_inline)) { return c_base + (unsigned long long)(unsigned)row * ldc_b + (unsigned)(col * 2); };
+  // stores of the output tile: plain, or write-through through a buffer descriptor of C (WT: the launcher keeps C below 2 GB)
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, WT ? (int)((unsigned)p.M * ldc_b) : 0, 0x00020000);
+  auto store_c16 = [&](int row, int col, const u32x4 v) __attribute__((always_inline)) {
+    if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(v, c_rsrc, (int)((unsigned)row * ldc_b + (unsigned)(col * 2)), 0, 16);
+    else *reinterpret_cast<u32x4*>(c_at(row, col)) = v;
+  };
+  auto store_c8 = [&](int row, int col, const u32x2 v) __attribute__((always_inline)) {
+    if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b64(v, c_rsrc, (int)((unsigned)row * ldc_b + (unsigned)(col * 2)), 0, 16);
+    else *reinterpret_cast<u32x2*>(c_at(row, col)) = v;
+  };
 
   auto load_res = [&](int j, int pr) __attribute__((always_inline)) -> u32x4 {
     if (!has_res) return u32x4{0u, 0u, 0u, 0u};
@@ -826,8 +839,8 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
         const u32x4 nb_b = lane_xor1(wb), nb_a = lane_xor1(wa);
         const u32x4 st_a = odd_lane ? nb_b : wa;     // token A (even): even lane pair 2g, odd lane pair 2g + 1 (the even lane's wb)
         const u32x4 st_b = odd_lane ? wb : nb_a;     // token B (odd): even lane pair 2g (the odd lane's wa), odd lane pair 2g + 1
-        if (ok_a) *reinterpret_cast<u32x4*>(c_at(row_a[j], col_full + 64 * g)) = st_a;
-        if (ok_b) *reinterpret_cast<u32x4*>(c_at(row_b[j], col_full + 64 * g)) = st_b;
+        if (ok_a) store_c16(row_a[j], col_full + 64 * g, st_a);
+        if (ok_b) store_c16(row_b[j], col_full + 64 * g, st_b);
       }
     }
 #pragma unroll
@@ -841,7 +854,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       finish8(o, rr);
       if (m < p.M) {
         const u32x4 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-        *reinterpret_cast<u32x4*>(c_at(row_own(j), col0 + pr * 32 + fq * 8)) = w;
+        store_c16(row_own(j), col0 + pr * 32 + fq * 8, w);
       }
     }
     // ---- odd last block: straight from the accumulator layout ----
@@ -868,7 +881,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
         for (int q = 0; q < 4; ++q) { st1 += o[q]; st2 += o[q] * o[q]; }
       }
-      if (m < p.M) *reinterpret_cast<u32x2*>(c_at(row_own(j), col0 + NP * 32 + fq * 4)) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+      if (m < p.M) store_c8(row_own(j), col0 + NP * 32 + fq * 4, u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])});
     }
     if (stats) {                               // the token's four lanes hold disjoint columns of the wave's panel: slab = panel index
       st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
@@ -876,7 +889,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       if (fq == 0 && m < p.M) {
         const int slab = wave_n0 / (16 * NI), pitch = (p.N / (16 * NI) + 3) & ~3;
         float* dst = p.stats_out + ((long)m * pitch + slab) * 2;
-        if (p.ln_final_out != nullptr) {        // read back inside this launch by the panel's last workgroup (gemm_ln_finalize): write-through (sc1)
+        if (WT || p.ln_final_out != nullptr) {  // read back inside this launch (gemm_ln_finalize by the panel's last workgroup; a chained launch's next stage): write-through (sc1)
           const unsigned long long bits = (unsigned long long)__float_as_uint(st1) | ((unsigned long long)__float_as_uint(st2) << 32);
           __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {

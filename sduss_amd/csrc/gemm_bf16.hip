@@ -197,6 +197,8 @@ int launch_v4(hipStream_t s, const GemmArgs& a);
 // problem therefore prefers small tiles (more CUs fetch in parallel: one 1024 px request gives M = 2048), a chip-filling one
 // the tiling with the fewest rounds and the largest tile (fewest bytes per FLOP; the 256x256 kernel is further discounted by
 // its measured advantage).  rows == 0: use the generic 128-row kernel.
+constexpr size_t kSplitKWsBytes = 96u << 20;     // split-K scratch per stream (below): fp32 partial tiles / arrival tickets
+constexpr size_t kSplitKCntBytes = 64u << 10;
 struct TileChoice { int bn; int rows; int splitk = 1; };
 // m-tiles of the launch for tiles of `rows` rows: the problems of a grouped launch are tiled one by one (no tile straddles two of them)
 static long m_tiles_of(const mx_gemm_desc* d, int rows) {
@@ -277,7 +279,7 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
       for (int sk = 1; sk <= 4; ++sk) {
         if (d->splitk > 1 && sk != 1 && sk != d->splitk) continue;            // a forced slice count (tests, A/B)
         if (nk / sk < 8 || (sk > 1 && tiles * sk > 2L * ncu)) continue;
-        if (sk > 1 && tiles * sk * 128L * bn * 4 > (96L << 20)) continue;          // the partial tiles must fit the library's scratch
+        if (sk > 1 && (tiles * sk * 128L * bn * 4 > (long)kSplitKWsBytes || tiles * 4 > (long)kSplitKCntBytes)) continue;   // the partial tiles and tickets must fit the library's scratch
         const double combine = sk > 1 ? 2.0 + (double)sk * mtot * d->N * 8.0 / 4.0e6 : 0.0;      // us: partial tiles out and back at ~4 TB/s
         const double t = (double)((tiles * sk + ncu - 1) / ncu) * ((double)(nk / sk) * 0.57 * (128 + bn) / 256.0 + 5.0) + combine;
         if (sk == 1 && bn == best.bn) unsplit_t = t;
@@ -291,7 +293,7 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
         const int bn = cands[c].bn, sk = d->splitk;
         if (d->N % bn != 0 || (geglu && bn == 160) || (qkv && (d->seg % 64 != 0 || d->seg % (bn / 2) != 0)) || ((d->flags & MX_EPI_RMSNORM) && bn == 160)) continue;
         const long tiles = m_tiles_of(d, 128) * (d->N / bn);
-        if (sk > 4 || nk / sk < 8 || tiles * sk * 128L * bn * 4 > (96L << 20)) continue;
+        if (sk > 4 || nk / sk < 8 || tiles * sk * 128L * bn * 4 > (long)kSplitKWsBytes || tiles * 4 > (long)kSplitKCntBytes) continue;
         const double t = (double)((tiles * sk + ncu - 1) / ncu) * ((double)(nk / sk) * 0.57 * (128 + bn) / 256.0 + 5.0);
         if (ft == 0 || t < ft) { ft = t; best = TileChoice{bn, 128, sk}; }
       }
@@ -301,25 +303,47 @@ static TileChoice pick_tile(const mx_gemm_desc* d, bool conv) {
 }
 
 // scratch of the split-K launches: fp32 partial tiles and one arrival counter per output tile, per stream (launches of one stream are ordered;
-// concurrent streams -- the per-resolution sequences of a mixed batch -- must not share them).  Allocated at the first split launch of a stream;
-// never while that stream is being captured (the launch then runs unsplit on the same tiles).
+// concurrent streams -- the per-resolution sequences of a mixed batch -- must not share them).  Allocated at the first split launch of a stream,
+// ALSO while that stream is being captured (advisor, round 4: a capture used to bake in the unsplit kernels, so eager and replayed forwards of one
+// shape added their products in different orders): the allocation runs with the thread's capture mode relaxed and zeroes the counters on a private
+// stream, neither of which touches the capturing stream.  Whether a launch is split therefore depends on its descriptor alone (pick_tile); a scratch
+// that cannot be had is an error, not a silent change of summation order.  mx_gemm_release_scratch frees a stream's scratch (library unload frees all).
 struct SplitKScratch { float* ws = nullptr; unsigned* cnt = nullptr; };
+struct SplitKPool {
+  std::mutex mu;
+  std::unordered_map<hipStream_t, SplitKScratch> per_stream;
+  static void drop(SplitKScratch& b) { if (b.ws) (void)hipFree(b.ws); if (b.cnt) (void)hipFree(b.cnt); b = SplitKScratch{}; }
+  ~SplitKPool() { for (auto& kv : per_stream) drop(kv.second); }
+};
+static SplitKPool& splitk_pool() { static SplitKPool p; return p; }
 static bool splitk_scratch(hipStream_t s, SplitKScratch& out) {
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, SplitKScratch> per_stream;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = per_stream.find(s);
-  if (it != per_stream.end()) { out = it->second; return out.ws != nullptr; }
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+  SplitKPool& pool = splitk_pool();
+  std::lock_guard<std::mutex> lock(pool.mu);
+  auto it = pool.per_stream.find(s);
+  if (it != pool.per_stream.end()) { out = it->second; return out.ws != nullptr; }
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
   SplitKScratch b;
-  if (hipMalloc(&b.ws, 96u << 20) != hipSuccess || hipMalloc(&b.cnt, 64u << 10) != hipSuccess || hipMemset(b.cnt, 0, 64u << 10) != hipSuccess) {
-    (void)hipGetLastError();
-    b = SplitKScratch{};
-  }
-  per_stream[s] = b;
+  hipStream_t z = nullptr;
+  bool ok = hipMalloc(&b.ws, kSplitKWsBytes) == hipSuccess && hipMalloc(&b.cnt, kSplitKCntBytes) == hipSuccess &&
+            hipStreamCreateWithFlags(&z, hipStreamNonBlocking) == hipSuccess && hipMemsetAsync(b.cnt, 0, kSplitKCntBytes, z) == hipSuccess &&
+            hipStreamSynchronize(z) == hipSuccess;
+  if (z) (void)hipStreamDestroy(z);
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (!ok) { (void)hipGetLastError(); SplitKPool::drop(b); return false; }      // (not remembered: a later launch may find memory)
+  pool.per_stream[s] = b;
   out = b;
-  return b.ws != nullptr;
+  return true;
+}
+static void splitk_release(hipStream_t s, bool all) {
+  SplitKPool& pool = splitk_pool();
+  std::lock_guard<std::mutex> lock(pool.mu);
+  if (all) { for (auto& kv : pool.per_stream) { (void)hipStreamSynchronize(kv.first); SplitKPool::drop(kv.second); } pool.per_stream.clear(); return; }
+  auto it = pool.per_stream.find(s);
+  if (it == pool.per_stream.end()) return;
+  (void)hipStreamSynchronize(s);
+  SplitKPool::drop(it->second);
+  pool.per_stream.erase(it);
 }
 
 // slabs of row statistics the launch of d writes: one per wave column panel of the register-exchange epilogue (gemm_epilogue_regs);
@@ -334,7 +358,8 @@ static int stats_slabs_of(const mx_gemm_desc* d, bool conv, const TileChoice& tc
   return d->N / panel;
 }
 
-static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
+// validation + the kernel argument block + the tile choice of mx_gemm / mx_conv3x3 (d); the dispatch follows in launch()
+static int prepare(void* stream, const mx_gemm_desc* d, bool conv, GemmArgs& a, TileChoice& tc_out) {
   MX_CHECK(d != nullptr, "gemm: null descriptor");
   MX_CHECK(d->a && d->w && (d->c || (d->flags & MX_EPI_QKV)), "gemm: null operand");
   MX_CHECK(d->n_segs >= 0 && d->n_segs <= MX_MAX_SEGS && (d->n_segs == 0 || d->segs != nullptr), "gemm: bad n_segs / segs");
@@ -366,7 +391,6 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   }
   MX_CHECK(d->K % BK == 0, "gemm: K must be a multiple of 64");
   MX_CHECK(d->N % 4 == 0, "gemm: N must be a multiple of 4");
-  GemmArgs a;
   a.stagger_ticks = 0;
   a.vhalo = conv ? d->vhalo : 0;
   a.a2 = conv ? nullptr : (const bf16_t*)d->a2; a.lda2 = d->lda2; a.k_split = d->k_split;
@@ -437,12 +461,13 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   if (d->residual) MX_CHECK(d->ldr >= d->N && d->ldr % 4 == 0, "gemm: bad ldr");
   const bool use128 = (d->N % 128 == 0);
   const TileChoice tc = pick_tile(d, conv);
+  tc_out = tc;
   a.splitk = 0; a.sk_ws = nullptr; a.sk_cnt = nullptr;
   if (tc.splitk > 1) {
     SplitKScratch sk;
-    if (splitk_scratch((hipStream_t)stream, sk) && m_tiles_of(d, 128) * (d->N / tc.bn) * 4 <= (64L << 10)) { a.splitk = tc.splitk; a.sk_ws = sk.ws; a.sk_cnt = sk.cnt; }
+    MX_CHECK(splitk_scratch((hipStream_t)stream, sk), "gemm: the split-K scratch (96 MB per stream) could not be allocated; set mx_gemm_desc.splitk = 1 to run unsplit");
+    a.splitk = tc.splitk; a.sk_ws = sk.ws; a.sk_cnt = sk.cnt;
   }
-  const int v2bn = tc.bn;
   if (d->stats_out) {
     MX_CHECK(stats_slabs_of(d, conv, tc) > 0, "gemm: stats_out is not supported for this shape / epilogue (see mx_gemm_stats_slabs)");
     MX_CHECK(((uintptr_t)d->stats_out & 15) == 0, "gemm: stats_out must be 16-byte aligned");
@@ -502,6 +527,24 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   } else {
     MX_CHECK(d->ldc >= d->N && d->ldc % 4 == 0, "gemm: bad ldc");
   }
+  return 0;
+}
+
+// the argument block of mx_gemm(d) for a launch that runs its tiles itself (attn_tail.hip): the same validation and tile choice
+int gemm_prepare_for_chain(void* stream, const mx_gemm_desc* d, GemmArgs& a, int& bn, int& rows, int& splitk) {
+  TileChoice tc;
+  if (int rc = prepare(stream, d, false, a, tc)) return rc;
+  bn = tc.bn; rows = tc.rows; splitk = tc.splitk;
+  return 0;
+}
+
+static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
+  GemmArgs a;
+  TileChoice tc;
+  if (int rc = prepare(stream, d, conv, a, tc)) return rc;
+  const bool grouped = d->n_segs > 0;
+  const bool use128 = (d->N % 128 == 0);
+  const int v2bn = tc.bn;
   dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   if (prof_enabled()) {
@@ -565,9 +608,11 @@ static bool tail_split(const mx_gemm_desc* d, mx_gemm_desc& d1, mx_gemm_desc& d2
   const long cofs = geglu ? N1 / 2 : N1;       // first output column of the second launch
   d1 = *d; d2 = *d;
   d1.N = N1; d2.N = N2;
+  d1.splitk = 1; d2.splitk = 1;               // both halves add a row's products in the single launch's order (advisor, round 4)
   d2.w = (const char*)d->w + (size_t)N1 * d->K * 2;
   if (d->bias) d2.bias = d->bias + N1;
   d2.c = (char*)d->c + (size_t)cofs * 2;
+  if (geglu && d->residual) return false;      // (the launcher rejects that pair anyway; its column offsets would differ)
   if (d->residual) d2.residual = (const char*)d->residual + (size_t)N1 * 2;
   if (d->rowbias) d2.rowbias = d->rowbias + N1;
   if (d->gate) d2.gate = d->gate + N1;
@@ -612,6 +657,7 @@ extern "C" int mx_gemm_ln_final_supported(const mx_gemm_desc* d) {
   return tc.rows == 256 && tc.bn != 256 && tc.bn != 0 && mx::stats_slabs_of(&q, false, tc) > 0;
 }
 extern "C" int mx_conv3x3(void* stream, const mx_gemm_desc* d) { return mx::launch(stream, d, true); }
+extern "C" void mx_gemm_release_scratch(void* stream, int all) { mx::splitk_release((hipStream_t)stream, all != 0); }
 extern "C" int mx_gemm_splitk(const mx_gemm_desc* d, int conv) {
   if (!d || mx::rows_of(d) <= 0 || d->N <= 0 || d->K <= 0) return 0;
   return mx::pick_tile(d, conv != 0).splitk;

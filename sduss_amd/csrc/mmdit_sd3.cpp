@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <string>
 #include <unordered_map>
@@ -120,6 +121,9 @@ struct Plan {
   std::vector<int> pcm_chunk_b, pcm_chunk_g;
   mx::PcSample* pcm_dimg = nullptr; mx::PcSample* pcm_dctx = nullptr; mx::PcRange* pcm_dchunks = nullptr; mx::PcRange* pcm_dtmp = nullptr; double* pcm_dpart = nullptr;
   unsigned long long pcm_asked = 0, pcm_total = 0;
+  // host copies of the range tables sent by hipMemcpyAsync: kept until the forward's final synchronisation (a pageable source must outlive the copy)
+  std::deque<std::vector<mx::PcRange>> pcm_sent;
+  ~Plan() { if (!pcm_sent.empty() && !dry) (void)hipStreamSynchronize(stream); }     // (an early error return: the copies may still be reading)
   size_t pcm_ncmax() const { return (size_t)pcm_slots * (pcm_maxh / pcm_patch) * (pcm_maxw / pcm_patch); }
   size_t pcm_head_bytes() const {
     const size_t nc = pcm_ncmax();
@@ -478,7 +482,9 @@ struct Plan {
         // ranges of the samples of the active groups (image rows / text rows), uploaded per use
         auto upload = [&](const std::vector<mx::PcRange>& v, int slot) -> const mx::PcRange* {
           mx::PcRange* dst = pcm_dtmp + (size_t)slot * pcm_ncmax();
-          if (ok() && !v.empty() && hipMemcpyAsync(dst, v.data(), v.size() * sizeof(mx::PcRange), hipMemcpyHostToDevice, stream) != hipSuccess)
+          if (!ok() || v.empty()) return dst;
+          pcm_sent.push_back(v);                // (advisor, round 4: the loop-local table died before the asynchronous copy had to have read it)
+          if (hipMemcpyAsync(dst, pcm_sent.back().data(), v.size() * sizeof(mx::PcRange), hipMemcpyHostToDevice, stream) != hipSuccess)
             fail("mmdit patch cache: sending a range table failed");
           return dst;
         };
@@ -639,6 +645,8 @@ struct Plan {
     for (int g = 0; g < ng && ok() && !dry; ++g)
       if (mx::launch_unpatchify(stream, o + r0[g] * No, g_out[g], io_dtype, gB[g], c.out_channels, gH[g], gW[g], ps, No)) fail(mx_last_error());
     if (stage && !dry && ok() && !stage_hit) fail(std::string("unknown stage '") + stage + "'");
+    // the range tables of the patch cache were copied from pcm_sent asynchronously: they are released only once the stream has read them
+    if (!pcm_sent.empty()) { if (!dry && hipStreamSynchronize(stream) != hipSuccess) fail("mmdit patch cache: final synchronisation failed"); pcm_sent.clear(); }
     return ok();
   }
 };

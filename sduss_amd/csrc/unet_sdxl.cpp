@@ -60,6 +60,31 @@ struct mx_unet {
   // patch-parallel stale forwards: the exchange sizes of the plan, recorded by a host-only walk ONCE per (batch, H, W, ctx_len, gn_patch, world) instead
   // of at every step (advisor, round 3: the walk sat on the path whose purpose is to hide latency)
   std::map<std::vector<long>, std::vector<size_t>> pp_sizes;
+  // ---- per-composition store of the cross-attention K / V^T of encoder_hidden_states (mx_unet_set_context_key, mxdenoise.h).  The text
+  // embeddings of a request are constant over its 50 steps (pipeline_stable_diffusion_xl_esymred.py:287-339 re-concatenates the same tensors every
+  // step), so the hoisted projection -- M = B * 77, N = 2 * layers * dim, K = 2048 per attention width, 0.47 ms of the headline step -- is computed
+  // once per batch composition and read from library-owned buffers afterwards: same GEMM, same bits.  A few entries (compositions alternate when
+  // the resolutions of a mixed batch run as separate sequences on separate streams); an entry is handed from one stream to another through the
+  // event its last forward recorded. ----
+  struct CtxEntry {
+    uint64_t key = 0; int B = 0, ctx_len = 0; bool valid = false; uint64_t stamp = 0;
+    std::vector<bf16_t*> k, vt; std::vector<size_t> k_bytes, vt_bytes;
+    hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool recorded = false;
+  };
+  uint64_t ctx_key = 0;                 // 0 = off: every forward projects encoder_hidden_states again
+  std::vector<CtxEntry> ctx_store;
+  uint64_t ctx_clock = 0;
+  long ctx_hits = 0, ctx_misses = 0;
+  void ctx_clear() {
+    for (auto& e : ctx_store) {
+      if (e.last) (void)hipStreamSynchronize(e.last);
+      for (auto* q : e.k) if (q) (void)hipFree(q);
+      for (auto* q : e.vt) if (q) (void)hipFree(q);
+      if (e.ev) (void)hipEventDestroy(e.ev);
+    }
+    ctx_store.clear();
+  }
+  ~mx_unet() { ctx_clear(); }
 };
 
 namespace {
@@ -78,6 +103,17 @@ struct Arena {
   size_t mark() const { return top; }
   void release(size_t m) { top = m; }
 };
+
+// (attention width, cross-attention layers of that width) in execution order of first use: the layout of the hoisted K / V^T buffers
+static std::vector<std::pair<int, int>> kv_widths(const mx_unet_config& c) {
+  const int nlev = c.n_levels;
+  std::vector<std::pair<int, int>> widths;
+  auto add = [&](int dim, int n) { for (auto& wv : widths) if (wv.first == dim) { wv.second += n; return; } widths.push_back({dim, n}); };
+  for (int i = 0; i < nlev; ++i) if (c.down_has_attn[i]) add(c.block_out_channels[i], c.layers_per_block * c.transformer_layers[i]);
+  add(c.block_out_channels[nlev - 1], c.transformer_layers[nlev - 1]);
+  for (int i = 0; i < nlev; ++i) { const int lv = nlev - 1 - i; if (c.down_has_attn[lv]) add(c.block_out_channels[lv], (c.layers_per_block + 1) * c.transformer_layers[lv]); }
+  return widths;
+}
 
 struct Plan {
   mx_unet* u;
@@ -252,6 +288,8 @@ struct Plan {
   float* temb_all = nullptr; int temb_total = 0; int temb_off = 0;
   struct KV { bf16_t* k; bf16_t* vt; int ldk; int ldvt; long vt_bstride; int next; int dim; };
   std::vector<KV> kv;       // one per distinct attention width
+  mx_unet::CtxEntry* ctx_e = nullptr;   // the composition's stored K / V^T (forward_impl: ctx_prepare); ctx_hit: already computed
+  bool ctx_hit = false;
 
   bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
 
@@ -356,6 +394,8 @@ struct Plan {
   struct RowStats { float* buf = nullptr; int slabs = 0; float* fin = nullptr; unsigned* cnt = nullptr; };
   unsigned* ln_cnt = nullptr;     // panel tickets of the finalising producers: zeroed once per run, every launch leaves them zero
   static constexpr int kLnCnt = 4096;
+  unsigned* tail_sync = nullptr;  // work tickets of the chained attention-tail launches (mx_attn_tail): zeroed once per run, every launch leaves them zero
+  long tail_rows = 0;             // rows tail_sync is sized for
   // launch d; the statistics of its output rows go to st (from the epilogue when the chosen kernel can, else a pass over the output)
   bool gemm_with_stats(mx_gemm_desc& d, RowStats& st, bool finalise = false) {
     if (!ok()) return false;
@@ -654,6 +694,17 @@ struct Plan {
     }
     if (fin1) pass1 = false;
     if (fin3) pass3 = false;
+    // Round 5: the ATTENTION TAIL (attn1.to_out + residual -> attn2.to_q with norm2 folded -> the cross-attention -> attn2.to_out + residual) as ONE
+    // chained launch where its three linears take 256 x 160 tiles (mx_attn_tail; attn_tail.hip): the four launches' results bit for bit.  Its hand-offs
+    // need the cross-attention output and the first projection's row statistics in buffers of their own.
+    bool tail = !pc && !is_pp() && ng == 1 && !pass2 && tail_sync != nullptr && M <= tail_rows && L % 256 == 0;
+    bf16_t* ao2 = nullptr;
+    RowStats stA;
+    if (tail) {
+      ao2 = alloc<bf16_t>((size_t)M * C);
+      stA.buf = (float*)ar.alloc((size_t)M * MX_STATS_PITCH(C / 64) * 2 * sizeof(float));
+      if (!stA.buf) fail("workspace too small");
+    }
     bf16_t* pqc = nullptr; bf16_t* paoc = nullptr; bf16_t* ptc = nullptr;     // patch-unit cache: compact queries / attention output / projection output
     if (pc) { pqc = alloc<bf16_t>((size_t)M * C); paoc = alloc<bf16_t>((size_t)M * C); ptc = alloc<bf16_t>((size_t)M * C); }
     auto normalise = [&]() {      // ln = (y - mean) * rstd, no affine (it lives in the folded weights)
@@ -767,26 +818,60 @@ struct Plan {
       } else {
         attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
       }
-      linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, pass2 ? nullptr : &st);
-      // cross-attention (K/V of encoder_hidden_states precomputed for all layers of this width; norm2 in to_q)
-      if (pass2) normalise();
-      linear(pass2 ? ln : y, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f), nullptr, 0,
-             pass2 ? nullptr : &st);
-      if (ok()) {
-        const int li = kvp->next++;
-        if (ng > 1) {                       // the hoisted K / V^T are per sample: group g reads the rows of its samples
-          mx_attn_problem pr[MX_MAX_SEGS];
-          for (int g = 0; g < ng; ++g) {
-            pr[g].q = q2 + gr0[g] * C; pr[g].k = kvp->k + (size_t)li * C + (size_t)gb0[g] * ctx_len * kvp->ldk;
-            pr[g].vt = kvp->vt + (size_t)li * C * kvp->ldvt + (size_t)gb0[g] * kvp->vt_bstride; pr[g].o = ao + gr0[g] * C;
-            pr[g].vt_batch_stride = kvp->vt_bstride; pr[g].B = gB[g]; pr[g].Lq = gL[g]; pr[g].Lk = ctx_len; pr[g].ldvt = kvp->ldvt;
-          }
-          attention_grouped(pr, C, kvp->ldk, C, heads);
-        } else
-        attention(q2, C, kvp->k + (size_t)li * C, kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, kvp->ldvt, kvp->vt_bstride,
-                  ao, C, heads, L, ctx_len);
+      bool chained = false;
+      if (tail && ok()) {
+        auto lin_d = [&](const bf16_t* a_, const std::string& stem, void* c_, const void* res) {
+          mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+          d.a = a_; d.lda = C; d.w = wb(stem + ".weight", (size_t)C * C); d.bias = wf(stem + ".bias", C); d.c = c_; d.ldc = C; d.M = M; d.N = C; d.K = C;
+          d.residual = res; d.ldr = res ? C : 0;
+          return d;
+        };
+        mx_attn_tail_desc td; std::memset(&td, 0, sizeof(td));
+        td.out1 = lin_d(ao, b + ".attn1.to_out.0", y, y);
+        td.out1.stats_out = stA.buf;
+        const int slabs = mx_gemm_stats_slabs(&td.out1);
+        td.to_q = lin_d(y, b + ".attn2.to_q", q2, nullptr);
+        td.to_q.out_scale = MX_ATTN_QSCALE(0.125f);
+        td.to_q.ln_stats = stA.buf; td.to_q.ln_slabs = slabs; td.to_q.ln_colsum = wf(b + ".attn2.to_q.colsum", C); td.to_q.ln_eps = u->cfg.layer_norm_eps;
+        td.out2 = lin_d(ao2, b + ".attn2.to_out.0", y, y);
+        if (!pass3) {
+          td.out2.stats_out = st.buf;
+          if (fin3) { td.out2.ln_final_out = st.fin; td.out2.ln_final_cnt = st.cnt; td.out2.ln_eps = u->cfg.layer_norm_eps; }
+        }
+        const int li = kvp->next;
+        td.k = kvp->k + (size_t)li * C; td.ldk = kvp->ldk; td.vt = kvp->vt + (size_t)li * C * kvp->ldvt; td.ldvt = kvp->ldvt; td.vt_batch_stride = kvp->vt_bstride;
+        td.B = B; td.heads = heads; td.L = L; td.ctx_len = ctx_len; td.sync = tail_sync;
+        if (ok() && slabs > 0 && (quiet() || mx_attn_tail_supported(&td) != 0)) {     // (a dry walk has no operands to validate: it sizes for either form)
+          chained = true;
+          ++kvp->next;
+          if (!pass3) st.slabs = slabs;
+          if (!quiet() && mx_attn_tail(stream, &td)) fail(std::string("attn_tail: ") + mx_last_error());
+        } else {
+          tail = false;        // (the same answer for every layer of this transformer: ask once)
+        }
       }
-      linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, pass3 ? nullptr : &st, false, fin3);
+      if (!chained) {
+        linear(ao, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, pass2 ? nullptr : &st);
+        // cross-attention (K/V of encoder_hidden_states precomputed for all layers of this width; norm2 in to_q)
+        if (pass2) normalise();
+        linear(pass2 ? ln : y, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f), nullptr, 0,
+               pass2 ? nullptr : &st);
+        if (ok()) {
+          const int li = kvp->next++;
+          if (ng > 1) {                       // the hoisted K / V^T are per sample: group g reads the rows of its samples
+            mx_attn_problem pr[MX_MAX_SEGS];
+            for (int g = 0; g < ng; ++g) {
+              pr[g].q = q2 + gr0[g] * C; pr[g].k = kvp->k + (size_t)li * C + (size_t)gb0[g] * ctx_len * kvp->ldk;
+              pr[g].vt = kvp->vt + (size_t)li * C * kvp->ldvt + (size_t)gb0[g] * kvp->vt_bstride; pr[g].o = ao + gr0[g] * C;
+              pr[g].vt_batch_stride = kvp->vt_bstride; pr[g].B = gB[g]; pr[g].Lq = gL[g]; pr[g].Lk = ctx_len; pr[g].ldvt = kvp->ldvt;
+            }
+            attention_grouped(pr, C, kvp->ldk, C, heads);
+          } else
+          attention(q2, C, kvp->k + (size_t)li * C, kvp->ldk, kvp->vt + (size_t)li * C * kvp->ldvt, kvp->ldvt, kvp->vt_bstride,
+                    ao, C, heads, L, ctx_len);
+        }
+        linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", y, C, M, C, C, y, C, 0, 0.f, nullptr, 0, nullptr, pass3 ? nullptr : &st, false, fin3);
+      }
       // GEGLU feed-forward (norm3 in the GEGLU projection)
       if (pass3) normalise();
       linear(pass3 ? ln : y, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU, 0.f, nullptr, 0,
@@ -814,6 +899,12 @@ struct Plan {
     // panel tickets of the producers that finalise LayerNorm statistics (transformer()): zero once, every launch leaves them zero
     ln_cnt = (unsigned*)ar.alloc((size_t)kLnCnt * sizeof(unsigned));
     if (ok() && !quiet() && ln_cnt && hipMemsetAsync(ln_cnt, 0, (size_t)kLnCnt * sizeof(unsigned), stream) != hipSuccess) fail("ln tickets: memset failed");
+    tail_rows = rows();              // (level 0: no attention level has more rows)
+    if (tail_rows > 0 && tail_rows < 2147483647L) {
+      const size_t nb = mx_attn_tail_sync_bytes((int)tail_rows);
+      tail_sync = (unsigned*)ar.alloc(nb);
+      if (ok() && !quiet() && tail_sync && hipMemsetAsync(tail_sync, 0, nb, stream) != hipSuccess) fail("attention tail tickets: memset failed");
+    }
     // ---- time / added-condition embeddings (unet.py:314-341) ----
     bf16_t* tsin = alloc<bf16_t>((size_t)B * C0);
     bf16_t* addin = alloc<bf16_t>((size_t)B * addw);
@@ -845,22 +936,22 @@ struct Plan {
     // ---- cross-attention K / V^T of encoder_hidden_states for every layer, one GEMM per width ----
     kv.clear();
     {
-      std::vector<std::pair<int, int>> widths;  // (dim, layer count) in execution order of first use
-      auto add = [&](int dim, int n) { for (auto& wv : widths) if (wv.first == dim) { wv.second += n; return; } widths.push_back({dim, n}); };
-      for (int i = 0; i < nlev; ++i) if (c.down_has_attn[i]) add(c.block_out_channels[i], c.layers_per_block * c.transformer_layers[i]);
-      add(c.block_out_channels[nlev - 1], c.transformer_layers[nlev - 1]);
-      for (int i = 0; i < nlev; ++i) { const int lv = nlev - 1 - i; if (c.down_has_attn[lv]) add(c.block_out_channels[lv], (c.layers_per_block + 1) * c.transformer_layers[lv]); }
+      const std::vector<std::pair<int, int>> widths = kv_widths(c);
       const int ldvt = MX_VT_LD(ctx_len);
+      size_t wi = 0;
       for (auto& wv : widths) {
         const int dim = wv.first, nl = wv.second;
         KV e; e.dim = dim; e.next = 0; e.ldk = nl * dim; e.ldvt = ldvt; e.vt_bstride = (long)nl * dim * ldvt;
-        e.k = alloc<bf16_t>((size_t)B * ctx_len * nl * dim);
-        e.vt = alloc<bf16_t>((size_t)B * nl * dim * ldvt);
-        mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
-        d.a = ehs; d.lda = ctx; d.w = wb("attn2_kv_all." + std::to_string(dim) + ".weight", (size_t)nl * 2 * dim * ctx);
-        d.c = e.k; d.ldc = nl * dim; d.M = B * ctx_len; d.N = nl * 2 * dim; d.K = ctx; d.flags = MX_EPI_QKV; d.seg = dim; d.period = 2;
-        d.vt = e.vt; d.ldvt = ldvt; d.rows_per_batch = ctx_len;
-        gemm(d, false);
+        if (ctx_e && !dry) { e.k = ctx_e->k[wi]; e.vt = ctx_e->vt[wi]; }        // the composition's own buffers (mx_unet_set_context_key)
+        else { e.k = alloc<bf16_t>((size_t)B * ctx_len * nl * dim); e.vt = alloc<bf16_t>((size_t)B * nl * dim * ldvt); }
+        ++wi;
+        if (!(ctx_e && ctx_hit && !dry)) {
+          mx_gemm_desc d; std::memset(&d, 0, sizeof(d));
+          d.a = ehs; d.lda = ctx; d.w = wb("attn2_kv_all." + std::to_string(dim) + ".weight", (size_t)nl * 2 * dim * ctx);
+          d.c = e.k; d.ldc = nl * dim; d.M = B * ctx_len; d.N = nl * 2 * dim; d.K = ctx; d.flags = MX_EPI_QKV; d.seg = dim; d.period = 2;
+          d.vt = e.vt; d.ldvt = ldvt; d.rows_per_batch = ctx_len;
+          gemm(d, false);
+        }
         kv.push_back(e);
       }
     }
@@ -1191,6 +1282,43 @@ int check_cfg(const mx_unet_config* c) {
   return 0;
 }
 
+// The stored K / V^T entry of the composition u->ctx_key for a forward of `B` samples on `stream` (nullptr: the store is off or could not be had -- the
+// forward then projects into its workspace as before).  hit: the entry already holds this composition's projection.  The forward's stream waits for
+// whichever stream touched the entry last.  Host side only; allocations run with the thread's capture mode relaxed (never reached with MX_GRAPH on).
+mx_unet::CtxEntry* ctx_prepare(mx_unet* u, hipStream_t stream, int B, int ctx_len, bool& hit) {
+  hit = false;
+  if (u->ctx_key == 0 || mx::GraphCache::env_on()) return nullptr;
+  constexpr size_t kMaxEntries = 4;
+  mx_unet::CtxEntry* e = nullptr;
+  for (auto& q : u->ctx_store) if (q.valid && q.key == u->ctx_key && q.B == B && q.ctx_len == ctx_len) { e = &q; hit = true; break; }
+  if (!e) {
+    if (u->ctx_store.size() < kMaxEntries) { u->ctx_store.reserve(kMaxEntries); u->ctx_store.emplace_back(); e = &u->ctx_store.back(); }
+    else { e = &u->ctx_store[0]; for (auto& q : u->ctx_store) if (q.stamp < e->stamp) e = &q; }
+    e->valid = false;
+    const std::vector<std::pair<int, int>> widths = kv_widths(u->cfg);
+    const int ldvt = MX_VT_LD(ctx_len);
+    if (!e->ev && hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e->ev = nullptr; return nullptr; }
+    e->k.resize(widths.size(), nullptr); e->vt.resize(widths.size(), nullptr); e->k_bytes.resize(widths.size(), 0); e->vt_bytes.resize(widths.size(), 0);
+    for (size_t i = 0; i < widths.size(); ++i) {
+      const size_t kb = (size_t)B * ctx_len * widths[i].second * widths[i].first * sizeof(bf16_t);
+      const size_t vb = (size_t)B * widths[i].second * widths[i].first * ldvt * sizeof(bf16_t);
+      if (e->k_bytes[i] < kb || e->vt_bytes[i] < vb) {
+        if (e->last) (void)hipStreamSynchronize(e->last);       // (the old buffers may still be read)
+        if (e->k[i]) (void)hipFree(e->k[i]);
+        if (e->vt[i]) (void)hipFree(e->vt[i]);
+        e->k[i] = nullptr; e->vt[i] = nullptr; e->k_bytes[i] = e->vt_bytes[i] = 0;
+        if (hipMalloc(&e->k[i], kb) != hipSuccess || hipMalloc(&e->vt[i], vb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e->k_bytes[i] = kb; e->vt_bytes[i] = vb;
+      }
+    }
+    e->key = u->ctx_key; e->B = B; e->ctx_len = ctx_len;
+  }
+  if (e->recorded && e->last != stream && hipStreamWaitEvent(stream, e->ev, 0) != hipSuccess) { (void)hipGetLastError(); hit = false; return nullptr; }
+  e->stamp = ++u->ctx_clock;
+  if (hit) ++u->ctx_hits; else ++u->ctx_misses;
+  return e;
+}
+
 int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, const float* timesteps, const void* ehs,
                  const void* text_embeds, const float* time_ids, void* out, int batch, int H, int W, int ctx_len, int gn_patch,
                  void* workspace, size_t workspace_bytes, const char* stage, void* stage_out, size_t stage_bytes, bool dry,
@@ -1230,9 +1358,18 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
   }
   std::string err;
   size_t plan_peak = 0;
+  // the composition's stored cross-attention K / V^T (mx_unet_set_context_key): plain and mixed forwards; not patch-parallel (its ranks hold row bands)
+  bool ctx_hit = false;
+  mx_unet::CtxEntry* ctx_e = nullptr;
+  if (!dry && !pp) {
+    int Btot = batch;
+    if (groups) { Btot = 0; for (int g = 0; g < n_groups; ++g) Btot += groups[g].batch; }
+    ctx_e = ctx_prepare(u, (hipStream_t)stream, Btot, ctx_len, ctx_hit);
+  }
   auto enqueue = [&](hipStream_t s) {
     Plan p;
     p.u = u; p.stream = s; p.ctx_len = ctx_len;
+    p.ctx_e = ctx_e; p.ctx_hit = ctx_hit;
     p.set_single(batch, H, W, latents, out);
     bool patch_covers_all = gn_patch >= H && gn_patch >= W;
     if (groups) {
@@ -1281,6 +1418,12 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
     okr = u->graphs.run((hipStream_t)stream, key, enqueue, /*capture_on_miss=*/n_groups <= 1);
   }
   if (peak) *peak = plan_peak;
+  if (ctx_e) {                  // the entry belongs to this stream until the event: later forwards on other streams wait for it
+    ctx_e->valid = okr;
+    ctx_e->last = (hipStream_t)stream;
+    ctx_e->recorded = hipEventRecord(ctx_e->ev, (hipStream_t)stream) == hipSuccess;
+    if (!ctx_e->recorded) { (void)hipGetLastError(); (void)hipStreamSynchronize((hipStream_t)stream); }
+  }
   if (!okr) { mx::set_error(err); return 1; }
   return 0;
 }
@@ -1296,9 +1439,22 @@ extern "C" mx_unet* mx_unet_create(const mx_unet_config* cfg) {
 
 extern "C" void mx_unet_destroy(mx_unet* u) { delete u; }
 
+extern "C" int mx_unet_set_context_key(mx_unet* u, uint64_t key) {
+  MX_CHECK(u != nullptr, "unet_set_context_key: null handle");
+  u->ctx_key = key;
+  return 0;
+}
+extern "C" int mx_unet_context_stats(const mx_unet* u, long* hits, long* misses) {
+  MX_CHECK(u != nullptr, "unet_context_stats: null handle");
+  if (hits) *hits = u->ctx_hits;
+  if (misses) *misses = u->ctx_misses;
+  return 0;
+}
+
 extern "C" int mx_unet_set_weights(mx_unet* u, const void* blob, uint64_t blob_bytes, const mx_weight_entry* table, int n) {
   MX_CHECK(u && blob && table && n > 0, "unet_set_weights: bad arguments");
   u->graphs.clear();    // captured graphs hold addresses resolved through the old table
+  u->ctx_clear();       // stored projections were made with the old weights
   u->table.clear();
   for (int i = 0; i < n; ++i) {
     MX_CHECK(table[i].name != nullptr, "unet_set_weights: null name");

@@ -52,6 +52,13 @@ class GemmDesc(C.Structure):
     ]
 
 
+class AttnTailDesc(C.Structure):
+    """mx_attn_tail_desc"""
+    _fields_ = [("out1", GemmDesc), ("to_q", GemmDesc), ("out2", GemmDesc),
+                ("k", C.c_void_p), ("ldk", C.c_int), ("vt", C.c_void_p), ("ldvt", C.c_int), ("vt_batch_stride", C.c_int64),
+                ("B", C.c_int), ("heads", C.c_int), ("L", C.c_int), ("ctx_len", C.c_int), ("sync", C.c_void_p)]
+
+
 class AttnProblem(C.Structure):
     """mx_attn_problem"""
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p), ("vt_batch_stride", C.c_int64),
@@ -157,6 +164,11 @@ SYMBOLS = {
     "mx_row_stats": (_i, [_vp, _vp, _i, _vp, _i, _i]),
     "mx_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _f]),
     "mx_attention_prescaled": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i]),
+    "mx_attention_cross_prescaled": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i]),
+    "mx_attn_tail_sync_bytes": (_sz, [_i]),
+    "mx_attn_tail_supported": (_i, [C.POINTER(AttnTailDesc)]),
+    "mx_attn_tail": (_i, [_vp, C.POINTER(AttnTailDesc)]),
+    "mx_attn_tail_status": (_i, [_vp, _vp, C.POINTER(C.c_uint)]),
     "mx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "mx_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mx_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
@@ -171,6 +183,8 @@ SYMBOLS = {
     "mx_mmdit_forward_mixed": (_i, [_vp, _vp, C.POINTER(UNetGroup), _i, _i, _vp, _vp, _vp, _i, _vp, _sz]),
     "mx_unet_create": (_vp, [C.POINTER(UNetConfigC)]),
     "mx_unet_destroy": (None, [_vp]),
+    "mx_unet_set_context_key": (_i, [_vp, C.c_uint64]),
+    "mx_unet_context_stats": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "mx_unet_set_weights": (_i, [_vp, _vp, C.c_uint64, C.POINTER(WeightEntry), _i]),
     "mx_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_unet_validate": (_i, [_vp, _i, _i, _i, _i]),
@@ -184,6 +198,7 @@ SYMBOLS = {
     "mx_unet_forward_pp_stale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "mx_unet_block_cache_bytes": (_sz, [_vp, _i, _i, _i]),
     "mx_gemm_splitk": (_i, [_vp, _i]),
+    "mx_gemm_release_scratch": (None, [_vp, _i]),
     "mx_gemm_ln_final_supported": (_i, [C.POINTER(GemmDesc)]),
     "mx_gemm_launches": (_i, [C.POINTER(GemmDesc)]),
     "mx_gemm_gn_partials_supported": (_i, [C.POINTER(GemmDesc), _i]),

@@ -197,6 +197,73 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, lq
     return o
 
 
+def attn_tail(ao: torch.Tensor, y: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, wq: torch.Tensor, bq: torch.Tensor, colsum_q: torch.Tensor,
+              k: torch.Tensor, vt: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, heads: int, L: int, ctx_len: int, ln_eps: float = 1e-5,
+              chained: bool = True, finalise: bool = True, sync: Optional[torch.Tensor] = None):
+    """The attention tail of a BasicTransformerBlock on the hidden state ``y`` [M, C] (a copy is updated and returned):
+    y1 = ao w1^T + b1 + y;  q2 = norm2(y1) wq^T + bq (wq / bq / colsum_q LayerNorm-folded, prescaled);  ao2 = cross-attention(q2, k, vt);
+    y2 = ao2 w2^T + b2 + y1.  ``chained`` = ONE launch (mx_attn_tail); else the four launches with the SAME descriptors (the results must be equal bit
+    for bit).  k [B * ctx_len, ldk >= C], vt [B, C, MX_VT_LD(ctx_len)].  Returns (y2, (slab statistics, slabs) of y2, finalised statistics [M, 2] or None,
+    q2, ao2)."""
+    l = _lib.load()
+    for t_ in (ao, y, w1, wq, w2, k, vt):
+        _bf16(t_)
+    m, c = y.shape
+    b = m // L
+    dev = y.device
+    y = y.clone()
+    q2 = torch.empty_like(y)
+    ao2 = torch.empty_like(y)
+    td = _lib.AttnTailDesc()
+
+    def lin(d, a_, w_, bias, c_, res):
+        d.a, d.w, d.c, d.bias = a_.data_ptr(), w_.data_ptr(), c_.data_ptr(), bias.data_ptr()
+        d.M, d.N, d.K, d.lda, d.ldc = m, c, c, c, c
+        if res is not None:
+            d.residual, d.ldr = res.data_ptr(), c
+    lin(td.out1, ao, w1, b1, y, y)
+    lin(td.to_q, y, wq, bq, q2, None)
+    lin(td.out2, ao2, w2, b2, y, y)
+    td.out1.stats_out = 16                       # (shape query below: which operands exist)
+    slabs = l.mx_gemm_stats_slabs(C.byref(td.out1))
+    assert slabs > 0, "out1 cannot write slab statistics at this shape"
+    st1 = torch.full((m, stats_pitch(slabs), 2), float("nan"), dtype=torch.float32, device=dev)
+    st2 = torch.full((m, stats_pitch(slabs), 2), float("nan"), dtype=torch.float32, device=dev)
+    td.out1.stats_out = st1.data_ptr()
+    td.to_q.ln_stats, td.to_q.ln_colsum, td.to_q.ln_slabs, td.to_q.ln_eps = st1.data_ptr(), colsum_q.data_ptr(), slabs, ln_eps
+    td.to_q.out_scale = ATTN_QSCALE
+    td.out2.stats_out = st2.data_ptr()
+    final = cnt = None
+    if finalise:
+        final = torch.full((m, 2), float("nan"), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((m + 255) // 256, dtype=torch.int32, device=dev)
+        td.out2.ln_final_out, td.out2.ln_final_cnt, td.out2.ln_eps = final.data_ptr(), cnt.data_ptr(), ln_eps
+    td.k, td.ldk, td.vt, td.ldvt, td.vt_batch_stride = k.data_ptr(), k.shape[1], vt.data_ptr(), vt.shape[2], vt.shape[1] * vt.shape[2]
+    td.B, td.heads, td.L, td.ctx_len = b, heads, L, ctx_len
+    stream = _lib.current_stream()
+    if chained:
+        if sync is None:
+            sync = torch.zeros(l.mx_attn_tail_sync_bytes(m) // 4, dtype=torch.int32, device=dev)
+        td.sync = sync.data_ptr()
+        assert l.mx_attn_tail_supported(C.byref(td)), "mx_attn_tail cannot serve this shape"
+        _lib.check(l.mx_attn_tail(stream, C.byref(td)), "mx_attn_tail")
+    else:
+        _lib.check(l.mx_gemm(stream, C.byref(td.out1)), "mx_gemm")
+        _lib.check(l.mx_gemm(stream, C.byref(td.to_q)), "mx_gemm")
+        _lib.check(l.mx_attention_cross_prescaled(stream, q2.data_ptr(), c, k.data_ptr(), k.shape[1], vt.data_ptr(), vt.shape[2], vt.shape[1] * vt.shape[2],
+                                                  ao2.data_ptr(), c, b, heads, L, ctx_len), "mx_attention_cross_prescaled")
+        _lib.check(l.mx_gemm(stream, C.byref(td.out2)), "mx_gemm")
+    return y, (st2, slabs), final, q2, ao2, sync
+
+
+def attn_tail_status(sync: torch.Tensor) -> int:
+    """the error word of an mx_attn_tail sync buffer (0 = every wait ended); synchronises"""
+    l = _lib.load()
+    w = C.c_uint(0)
+    _lib.check(l.mx_attn_tail_status(_lib.current_stream(), sync.data_ptr(), C.byref(w)), "mx_attn_tail_status")
+    return w.value
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     l = _lib.load()
     _bf16(x)

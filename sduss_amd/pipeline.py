@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .step_state import StepCache
+from .step_state import StepCache, new_uid
 from .unet import MxUNet
 
 
@@ -157,7 +157,7 @@ class SDXLDenoiser:
             cat = tuple(torch.cat([p[2].cond[k] for p in parts], dim=0) for k in range(3))
             if len(self._mixed_cond) > 32:
                 self._mixed_cond.clear()
-            hit = self._mixed_cond[key] = ([p[2] for p in parts], cat)
+            hit = self._mixed_cond[key] = ([p[2] for p in parts], cat, new_uid())
         ehs, pooled, tids = hit[1]
         if cached:        # the model slot's own entry: the dict of all resolutions with the request ids the caches are keyed by (:369-380)
             out = self.unet.forward({p[0]: p[7] for p in parts}, torch.cat([p[6] for p in parts]), ehs, added_cond_kwargs={"text_embeds": pooled, "time_ids": tids},
@@ -165,6 +165,7 @@ class SDXLDenoiser:
                                     input_indices={p[0]: [str(r.request_id) for r in p[1]] for p in parts})[0]
             noise = [out[p[0]] for p in parts]
         else:
+            self.unet.set_context_key(hit[2])       # the composition's text embeddings are fixed: K / V^T of all layers once per composition
             noise = self.unet.forward_mixed([p[7] for p in parts], torch.cat([p[6] for p in parts]), ehs, pooled, tids,
                                             gn_patch=(patch_size // 8 if is_sliced else 0))
         g = self.guidance_scale if do_classifier_free_guidance else 0.0
@@ -200,6 +201,7 @@ class SDXLDenoiser:
         rows = 2 * n if do_classifier_free_guidance else n
         ts2 = torch.cat([ts, ts], dim=0) if do_classifier_free_guidance else ts
         x_in = ops.euler_scale_input(lat, sig, rows)                     # :357-360 (+ the cat of :327)
+        self.unet.set_context_key(e.uid)         # the composition's text embeddings are fixed: K / V^T of all layers once per composition
         noise = self.unet.forward({res: x_in}, ts2, ehs, added_cond_kwargs={"text_embeds": pooled, "time_ids": tids},
                                   return_dict=False, is_sliced=is_sliced, patch_size=patch_size,
                                   input_indices={res: [str(r.request_id) for r in reqs]})[0][res]   # :369-380

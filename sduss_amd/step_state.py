@@ -25,7 +25,15 @@ def _upload(host: torch.Tensor, device) -> torch.Tensor:
 
 
 class _Entry:
-    __slots__ = ("cond", "table", "idx", "rows", "host_idx", "lat", "limit")
+    __slots__ = ("cond", "table", "idx", "rows", "host_idx", "lat", "limit", "uid")
+
+_next_uid = [0]
+
+
+def new_uid() -> int:
+    """a process-wide, never reused, non-zero name for a batch composition (MxUNet.set_context_key)"""
+    _next_uid[0] += 1
+    return _next_uid[0]
 
 
 class StepCache:
@@ -40,6 +48,7 @@ class StepCache:
             self._entries.move_to_end(key)
             return e
         e = _Entry()
+        e.uid = new_uid()
         e.cond = build_cond()
         n = len(reqs)
         s_max = max(len(r.timesteps) for r in reqs)

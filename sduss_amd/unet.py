@@ -64,6 +64,7 @@ class MxUNet:
         self.max_mixed_groups = _lib.MAX_SEGS
         self._ws_by_stream: Dict[int, Optional[torch.Tensor]] = {}
         self._ws_need = {}
+        self._next_ctx_key = 0             # set_context_key: names the batch composition of the NEXT forward only
         self.config = _Config(in_channels=cfg.in_channels, time_cond_proj_dim=None,
                               addition_time_embed_dim=cfg.addition_time_embed_dim,
                               projection_class_embeddings_input_dim=cfg.projection_class_embeddings_input_dim,
@@ -77,6 +78,23 @@ class MxUNet:
 
     def to(self, *args, **kwargs):
         return self
+
+    def set_context_key(self, key: int) -> None:
+        """Name the batch composition of the NEXT forward (mx_unet_set_context_key): forwards announced with the same non-zero key receive
+        encoder_hidden_states of identical content, so the cross-attention K / V^T of all 70 layers are projected once per composition instead
+        of once per step (the reference re-concatenates and re-projects them every step: pipeline_..._esymred.py:287-339, attention.py:59-110).
+        One-shot: a forward that is not announced projects as before."""
+        self._next_ctx_key = int(key)
+
+    def _apply_ctx_key(self) -> None:
+        key, self._next_ctx_key = self._next_ctx_key, 0
+        _lib.check(self._lib.mx_unet_set_context_key(self._handle, key), "mx_unet_set_context_key")
+
+    def context_stats(self):
+        """(hits, misses) of the per-composition K / V^T store since the handle was created"""
+        h, m = C.c_long(0), C.c_long(0)
+        _lib.check(self._lib.mx_unet_context_stats(self._handle, C.byref(h), C.byref(m)), "mx_unet_context_stats")
+        return h.value, m.value
 
     # -------------------------------------------------------------------------------------------------
     def _workspace(self, batch: int, h: int, w: int, ctx_len: int, stream: int) -> torch.Tensor:
@@ -116,6 +134,7 @@ class MxUNet:
         stream = _lib.current_stream()
         ws = self._workspace(b, h, w, ctx_len, int(stream or 0))
         if stage is None:
+            self._apply_ctx_key()
             _lib.check(self._lib.mx_unet_forward(self._handle, stream, sample.data_ptr(), code, ts.data_ptr(), ehs.data_ptr(),
                                                  te.data_ptr(), ti.data_ptr(), out.data_ptr(), b, h, w, ctx_len, gn_patch,
                                                  ws.data_ptr(), ws.numel()), "mx_unet_forward")
@@ -168,6 +187,7 @@ class MxUNet:
             ws = self._ws_by_stream[sk] = torch.empty(need, dtype=torch.uint8, device=self.device)
         code = _lib.torch_dtype_code(dt)
         if stage is None:
+            self._apply_ctx_key()
             _lib.check(self._lib.mx_unet_forward_mixed(self._handle, stream, groups, len(samples), code, ts.data_ptr(), ehs.data_ptr(), te.data_ptr(),
                                                        ti.data_ptr(), ctx_len, gn_patch, ws.data_ptr(), ws.numel()), "mx_unet_forward_mixed")
             return outs
@@ -271,6 +291,7 @@ class MxUNet:
         text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
         out: Dict[str, torch.Tensor] = {}
         row = 0
+        ctx_key, self._next_ctx_key = self._next_ctx_key, 0      # set_context_key names THIS call; it reaches the library only where the call is one forward
         keys = [k for k in sample if sample[k] is not None and sample[k].shape[0] > 0]
         if not is_sliced:
             keys = keys[:1]  # the reference's unsliced branch runs the first resolution only (unet.py:268-272)
@@ -289,6 +310,7 @@ class MxUNet:
         if is_sliced and len(keys) > 1 and len(keys) <= _lib.MAX_SEGS and getattr(self, "_block_caches", None) is None and self.mixed_one_sequence:
             # the resolutions of a mixed batch as ONE launch sequence (the reference: one patch batch, unet.py:242-260)
             assert patch_size is not None and all(int(k) % patch_size == 0 for k in keys)
+            self._next_ctx_key = ctx_key
             res = self.forward_mixed([sample[k] for k in keys], timestep, encoder_hidden_states, text_embeds, time_ids, gn_patch=patch_size // 8)
             return (dict(zip(keys, res)),)
         for key in keys:
@@ -312,6 +334,8 @@ class MxUNet:
                 out[key] = self.forward_one_cached(bc, x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl], gn_patch=gn_patch,
                                                    row_ids=_row_ids(ids, n))
             else:
+                if len(keys) == 1:
+                    self._next_ctx_key = ctx_key
                 out[key] = self.forward_one(x, ts, encoder_hidden_states[sl], text_embeds[sl], time_ids[sl], gn_patch)
             row += n
         return (out,)

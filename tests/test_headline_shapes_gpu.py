@@ -24,7 +24,7 @@ from oracle import sd3_mmdit_ref, sdxl_unet_ref as ref  # noqa: E402  (checker o
 
 # profiler kinds (csrc/common.h ProfKind)
 KIND = {0: "gemm128", 1: "gemm64", 2: "conv128", 3: "conv64", 4: "attn", 5: "norm", 6: "gemm_v2_160", 7: "conv_v2_160",
-        8: "gemm_v2_128", 9: "conv_v2_128", 10: "gemm_256x256", 11: "attn_cross"}
+        8: "gemm_v2_128", 9: "conv_v2_128", 10: "gemm_256x256", 11: "attn_cross", 12: "attn_tail"}
 LARGE_GEMM = {"gemm_256x256"}
 LARGE_CONV = {"conv_v2_160", "conv_v2_128"}
 
@@ -276,6 +276,57 @@ def test_sdxl_base_forward_1024(full_width_sdxl, sdxl_1024_oracle):
     _check_forward(got, want_orig, "SDXL-base 1024^2 forward, batch 2, original weights", max_rel=0.05, l2_rel=0.03)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# CALIBRATED tolerance (round 5).  north_star: "within a stated fp16 L-inf tolerance".  The absolute bounds above (2.5-3 % rel L2, 4-5 % of range)
+# come from this repo's own error-growth model; what they do not say is how much of that error ANY bf16 / fp16 evaluation of the same graph makes.
+# Here the oracle's own graph is evaluated by STOCK torch ops on the GPU box (hipBLASLt / MIOpen / SDPA) in bf16 and in fp16 (the reference's dtype),
+# same weights and inputs, and the statement becomes a ratio:
+#     err(HIP vs fp32 oracle)  <=  1.5 x err(stock bf16 vs fp32 oracle)          in relative L2 AND in L-inf (fraction of the output range)
+# so a kernel that loses 2x the accuracy a stock bf16 pipeline keeps fails whatever the absolute level is.  The fp16 figure is printed next to it.
+# The fp32 oracle evaluated on the GPU by the same code (compute_dtype fp32, device cuda) must agree with the CPU oracle to 1e-3: the longer loop
+# tests use that form of the oracle (seconds instead of half a minute per forward).
+# ----------------------------------------------------------------------------------------------------------------------
+CALIBRATION_RATIO = 1.5
+
+
+def _err2(got, want):
+    got = got.float().cpu()
+    want = want.float().cpu()
+    return ((got - want).norm() / want.norm()).item(), ((got - want).abs().max() / want.abs().max()).item()
+
+
+def _calibrate(what, got_hip, want, lowp):
+    """lowp(dtype, sdpa) -> the oracle graph by stock torch ops at that dtype on the GPU"""
+    with torch.inference_mode():
+        o32 = lowp(torch.float32, False)
+        l2, mx = _err2(o32, want)
+        print(f"{what}: fp32 oracle on the GPU (stock ops) vs the CPU oracle: rel L2 {l2:.2e}, max {mx:.2e} of range")
+        assert l2 <= 1e-3 and mx <= 2e-3, f"{what}: the oracle evaluated on the GPU in fp32 differs from the CPU oracle (rel L2 {l2})"
+        del o32
+        res = {}
+        for name, dt, sdpa in (("bf16 sdpa", torch.bfloat16, True), ("bf16 math", torch.bfloat16, False), ("fp16 sdpa", torch.float16, True)):
+            y = lowp(dt, sdpa)
+            res[name] = _err2(y, want) if torch.isfinite(y.float()).all() else (float("inf"), float("inf"))
+            del y
+            torch.cuda.empty_cache()
+    hip = _err2(got_hip, want)
+    print(f"{what}: vs the fp32 oracle -- HIP rel L2 {hip[0]:.4f} max {hip[1]:.4f} of range | " +
+          " | ".join(f"stock {k} rel L2 {v[0]:.4f} max {v[1]:.4f}" for k, v in res.items()) +
+          f" | HIP / stock bf16 sdpa = {hip[0] / res['bf16 sdpa'][0]:.2f} (L2) {hip[1] / res['bf16 sdpa'][1]:.2f} (L-inf)")
+    ref_l2, ref_mx = res["bf16 sdpa"]
+    assert hip[0] <= CALIBRATION_RATIO * ref_l2, f"{what}: HIP rel L2 {hip[0]:.4f} > {CALIBRATION_RATIO} x stock bf16 {ref_l2:.4f}"
+    assert hip[1] <= CALIBRATION_RATIO * ref_mx, f"{what}: HIP L-inf {hip[1]:.4f} of range > {CALIBRATION_RATIO} x stock bf16 {ref_mx:.4f}"
+
+
+def test_sdxl_base_forward_1024_tolerance_calibrated(full_width_sdxl, sdxl_1024_oracle):
+    """SDXL-base 1024^2, UNet batch 2, ORIGINAL weights: the HIP forward may lose at most 1.5 x what a stock bf16 evaluation of the oracle's graph loses."""
+    ocfg, P, _held, net = full_width_sdxl
+    (s, t, e, te, ti), want_orig, _want_held0 = sdxl_1024_oracle
+    got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
+    _calibrate("SDXL-base 1024^2 forward, batch 2", got, want_orig,
+               lambda dt, sdpa: ref.unet_forward(P, ocfg, s, t, e, te, ti, compute_dtype=dt, device="cuda", sdpa=sdpa))
+
+
 def test_sdxl_base_forward_1024_headline_batch8_rows(full_width_sdxl, sdxl_1024_oracle):
     """The HEADLINE batch itself (BASELINE configs[1]: 4 requests under CFG = UNet batch 8 at 128 x 128 latents -- the launch shapes bench.py
     times: 256-row tiles everywhere, the 256 x 256 ping-pong kernel for QKV / GEGLU, the normalisation pass in front of it).  Samples are
@@ -320,12 +371,9 @@ def test_sdxl_base_mixed_forward_512_768_1024_one_sequence(full_width_sdxl):
     _check_forward(got[0], want, "SDXL-base mixed 512/768/1024, 512 px group vs the literal patch pipeline (weights as held)", max_rel=0.05, l2_rel=0.03)
 
 
-def test_sd35_medium_forward_1024(cuda_device):
-    """SD3.5-medium (24 joint blocks, 13 dual) on 128 x 128 latents with 333 text tokens: BASELINE configs[2].  The fp32 CPU oracle of this
-    forward costs 75 s per sample, so ONE oracle sample serves two comparisons: the batch-1 forward, and -- round 4 -- ROW 7 OF THE HEADLINE
-    BATCH OF 8 (4 requests under CFG: the launch shapes bench.py's `sd3` block times, 256 x 256 tiles for every image-stream GEMM and the 64-row
-    joint attention), whose other rows carry different latents / timesteps / embeddings so that a row mix-up cannot pass; row 0 of the batch of 8
-    is compared with the batch-1 HIP forward of its own inputs (two bf16 evaluations with different tile selections)."""
+@pytest.fixture(scope="module")
+def sd35_1024(cuda_device):
+    """SD3.5-medium at full width: parameters, ONE 1024^2 sample with its CPU fp32 oracle answer (~40-75 s of host time) and the packed model"""
     from sduss_amd.config import MMDiTConfig
     from sduss_amd.transformer_sd3 import MxSD3Transformer
     ocfg = sd3_mmdit_ref.MMDiTConfig.sd35_medium()
@@ -334,6 +382,26 @@ def test_sd35_medium_forward_1024(cuda_device):
     with torch.inference_mode():
         want = sd3_mmdit_ref.mmdit_forward(P, ocfg, lat, t, e, p)
     net = MxSD3Transformer(MMDiTConfig.sd35_medium(), P, device="cuda:0")
+    yield ocfg, P, (lat, t, e, p), want, net
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_sd35_medium_forward_1024_tolerance_calibrated(sd35_1024):
+    """SD3.5-medium 1024^2, one sample: the HIP forward may lose at most 1.5 x what a stock bf16 evaluation of the oracle's graph loses."""
+    ocfg, P, (lat, t, e, p), want, net = sd35_1024
+    got = net.forward_one(lat.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), p.cuda())
+    _calibrate("SD3.5-medium 1024^2 forward, batch 1", got, want,
+               lambda dt, sdpa: sd3_mmdit_ref.mmdit_forward(P, ocfg, lat, t, e, p, compute_dtype=dt, device="cuda", sdpa=sdpa))
+
+
+def test_sd35_medium_forward_1024(sd35_1024):
+    """SD3.5-medium (24 joint blocks, 13 dual) on 128 x 128 latents with 333 text tokens: BASELINE configs[2].  The fp32 CPU oracle of this
+    forward costs 75 s per sample, so ONE oracle sample serves two comparisons: the batch-1 forward, and -- round 4 -- ROW 7 OF THE HEADLINE
+    BATCH OF 8 (4 requests under CFG: the launch shapes bench.py's `sd3` block times, 256 x 256 tiles for every image-stream GEMM and the 64-row
+    joint attention), whose other rows carry different latents / timesteps / embeddings so that a row mix-up cannot pass; row 0 of the batch of 8
+    is compared with the batch-1 HIP forward of its own inputs (two bf16 evaluations with different tile selections)."""
+    ocfg, _P, (lat, t, e, p), want, net = sd35_1024
     got = net.forward_one(lat.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), p.cuda())
     _check_forward(got, want, "SD3.5-medium 1024^2 forward, batch 1")
     lat8, t8, e8, p8 = sd3_mmdit_ref.make_inputs(ocfg, 8, 128, ctx_len=333, seed=4242)

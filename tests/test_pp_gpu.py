@@ -23,10 +23,22 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _join(rank, world, port, backend):
+    """gloo: every rank on cuda:0 of the one-GPU test box, exchanging through host memory.  nccl (= RCCL): one device per rank, device to device --
+    the branch of patch_parallel.py the one-GPU pool never runs (tests *_rccl below: skipped unless the box has >= 2 GPUs)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.set_num_threads(8)                 # several ranks share the host: 128 torch threads each made the world-4 run take 190 s
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dev
+
+
+def _worker(rank, world, port, q, backend="gloo"):
+    dev = _join(rank, world, port, backend)
     try:
         from oracle import sdxl_unet_ref as ref
         from sduss_amd.config import UNetConfig
@@ -34,7 +46,7 @@ def _worker(rank, world, port, q):
         from sduss_amd.unet import MxUNet
         ocfg = ref.UNetConfig.tiny()
         P = ref.init_params(ocfg)
-        net = MxUNet(UNetConfig.tiny(), P, device="cuda:0")
+        net = MxUNet(UNetConfig.tiny(), P, device=dev)
         s, t, e, te, ti = ref.make_inputs(ocfg, 2, 64)
         x = s.cuda().to(torch.bfloat16)
         log = CommLog()
@@ -54,13 +66,31 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _need_gpus(n):
+    if torch.cuda.device_count() < n:
+        pytest.skip(f"needs {n} GPUs (one rank per device over RCCL); this box has {torch.cuda.device_count()}")
+
+
 @pytest.mark.timeout(300)
-def test_two_ranks_equal_one_rank(cuda_device):
+def test_two_ranks_equal_one_rank_rccl(cuda_device):
+    """the same over RCCL with one device per rank: inert on the one-GPU pool, live on a multi-GPU node without anyone editing code"""
+    _need_gpus(2)
+    test_two_ranks_equal_one_rank(cuda_device, backend="nccl")
+
+
+@pytest.mark.timeout(300)
+def test_stale_async_steps_rccl(cuda_device):
+    _need_gpus(2)
+    test_stale_async_steps(cuda_device, backend="nccl")
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_rank(cuda_device, backend="gloo"):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))
@@ -95,10 +125,8 @@ def test_four_ranks_equal_one_rank(cuda_device):
     assert dmax <= 0.03 * scale and oerr <= 0.04 * oscale and ncalls > 40
 
 
-def _stale_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.set_num_threads(8)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _stale_worker(rank, world, port, q, backend="gloo"):
+    dev = _join(rank, world, port, backend)
     try:
         from oracle import sdxl_unet_ref as ref
         from sduss_amd import lib
@@ -106,7 +134,7 @@ def _stale_worker(rank, world, port, q):
         from sduss_amd.patch_parallel import PatchParallelUNet
         from sduss_amd.unet import MxUNet
         ocfg = ref.UNetConfig.tiny()
-        net = MxUNet(UNetConfig.tiny(), ref.init_params(ocfg), device="cuda:0")
+        net = MxUNet(UNetConfig.tiny(), ref.init_params(ocfg), device=dev)
         s, t, e, te, ti = ref.make_inputs(ocfg, 2, 64)
         x0 = s.cuda().to(torch.bfloat16)
         g = torch.Generator().manual_seed(5)
@@ -150,7 +178,7 @@ def _stale_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_stale_async_steps(cuda_device):
+def test_stale_async_steps(cuda_device, backend="gloo"):
     """mx_unet_forward_pp_stale: a warm-up step is the synchronous step; a stale step with unchanged inputs reproduces it bit for bit
     (every stale slot equals the fresh one); with moved inputs it lands between: closer to the synchronous result of the new inputs than the
     old output is, and one more step on the same inputs removes most of the lag (only second-order staleness inside the network is left)."""
@@ -158,7 +186,7 @@ def test_stale_async_steps(cuda_device):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_stale_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_stale_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))

@@ -294,3 +294,44 @@ def test_unet_per_stage_error_budget(tiny):
         prev = l2
     print("per-stage rel L2:", ", ".join(f"{n.split('.')[-3] if n.count('.') > 2 else n}={v:.4f}" for n, v in rows[:6]), "...", f"{rows[-1][0]}={rows[-1][1]:.4f}")
     assert len(rows) >= 20
+
+
+def test_unet_context_key_store_is_bit_identical(tiny):
+    """mx_unet_set_context_key: a forward announced with a composition key reads the cross-attention K / V^T its first forward stored -- the same
+    bits as projecting them again; a new key (new embeddings) projects anew; an unannounced forward never reads the store; two streams may share an entry."""
+    ocfg, P, net = tiny
+    s, t, e, te, ti = ref.make_inputs(ocfg, 2, 32, seed=5)
+    _s2, _t2, e2, _te2, _ti2 = ref.make_inputs(ocfg, 2, 32, seed=6)
+    sc, tc, tec, tic = s.cuda().to(torch.bfloat16), t.cuda(), te.cuda(), ti.cuda()
+    ec, e2c = e.cuda().to(torch.bfloat16), e2.cuda().to(torch.bfloat16)
+
+    def fwd(ehs, key=0, sample=sc):
+        net.set_context_key(key)
+        return net.forward({"256": sample}, tc, ehs, added_cond_kwargs={"text_embeds": tec, "time_ids": tic}, return_dict=False,
+                           is_sliced=False, patch_size=256, input_indices={"256": ["0", "1"]})[0]["256"].clone()
+    h0, m0 = net.context_stats()
+    plain, plain2 = fwd(ec), fwd(e2c)
+    assert net.context_stats() == (h0, m0), "an unannounced forward must not touch the store"
+    assert not torch.equal(plain, plain2)
+    first = fwd(ec, key=1001)            # miss: projects into the store
+    # the hit must not read encoder_hidden_states at all: hand it garbage under the SAME key (the caller's promise is what the key means)
+    again = fwd(torch.full_like(ec, float("nan")), key=1001)
+    assert net.context_stats() == (h0 + 1, m0 + 1)
+    assert torch.equal(first, plain) and torch.equal(again, plain)
+    other = fwd(e2c, key=1002)           # a new composition
+    assert torch.equal(other, plain2)
+    assert torch.equal(fwd(ec, key=1001), plain), "the first composition is still stored (4 entries)"
+    # a different sample under a stored key: only the conditioning is reused
+    s3 = (sc.float() * 0.5).to(torch.bfloat16)
+    assert torch.equal(fwd(ec, key=1001, sample=s3), fwd(ec, sample=s3))
+    # another stream reads the entry the first one wrote
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        on_side = fwd(ec, key=1001)
+    side.synchronize()
+    assert torch.equal(on_side, plain)
+    # more compositions than entries: the least recently used one is projected again, results unchanged
+    for k in range(2001, 2006):
+        assert torch.equal(fwd(e2c, key=k), plain2)
+    assert torch.equal(fwd(ec, key=1001), plain)

@@ -15,7 +15,7 @@ from sduss_amd.pipeline import SDXLDenoiser, synthetic_request  # noqa: E402
 from sduss_amd.unet import MxUNet  # noqa: E402
 from sduss_amd.weights import synthetic_params  # noqa: E402
 
-KINDS = ["gemm128", "gemm64", "conv128", "conv64", "attn", "gnorm", "gemm_v2_160", "conv_v2_160", "gemm_v2_128", "conv_v2_128", "gemm_256", "attn_cross"]
+KINDS = ["gemm128", "gemm64", "conv128", "conv64", "attn", "gnorm", "gemm_v2_160", "conv_v2_160", "gemm_v2_128", "conv_v2_128", "gemm_256", "attn_cross", "attn_tail"]
 
 
 def main():
