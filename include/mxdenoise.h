@@ -246,7 +246,9 @@ void mx_gemm_release_scratch(void* stream, int all);
  * three descriptors are EXACTLY those of the separate launches (mx_gemm(out1); mx_gemm(to_q); mx_attention_cross_prescaled; mx_gemm(out2)) and the results
  * equal theirs bit for bit: the same tiles of the same kernels in the same order of summation.  mx_attn_tail_supported tells whether a descriptor can be
  * served (plain C x C linears on 256 x 160 tiles over M = B * L rows, L % 256 == 0, C = heads * 64, ctx_len <= 96; to_q reads out1's output and slab
- * statistics; ao / y / q2 / ao2 four different buffers, the two statistics buffers different; MX_ATTN_TAIL=0 in the environment switches it off).
+ * statistics; ao / y / q2 / ao2 four different buffers, the two statistics buffers different).  mx_attn_tail_preferred: 1 when the step plans should
+ * take it where it is supported -- MX_ATTN_TAIL=1 in the environment; the DEFAULT IS 0: measured on MI355X the chained launch ties with the four launches
+ * in isolation and is 2 % slower inside the SDXL step, so it ships as an option, not as the plan's path.
  * sync: mx_attn_tail_sync_bytes(M) bytes of device memory, ZERO before the first launch; every launch leaves them zero (except the error word read by
  * mx_attn_tail_status: != 0 when a wait inside a launch gave up after ~2^22 polls instead of hanging the device -- that launch's output is invalid). ---- */
 typedef struct mx_attn_tail_desc {
@@ -258,6 +260,7 @@ typedef struct mx_attn_tail_desc {
 } mx_attn_tail_desc;
 size_t mx_attn_tail_sync_bytes(int M);
 int mx_attn_tail_supported(const mx_attn_tail_desc* d);
+int mx_attn_tail_preferred(void);
 int mx_attn_tail(void* stream, const mx_attn_tail_desc* d);
 int mx_attn_tail_status(void* stream, const unsigned* sync, unsigned* word);
 
@@ -387,11 +390,11 @@ int mx_unet_set_weights(mx_unet* u, const void* blob, uint64_t blob_bytes,
                         const mx_weight_entry* table, int n_entries);
 /* PER-COMPOSITION store of the cross-attention K / V^T (round 5).  The text embeddings of a request do not change over its steps, yet the
  * reference's step re-concatenates them and every forward projects them again for all 70 transformer layers (pipeline_stable_diffusion_xl_esymred.py:
- * 287-339; attention.py:59-110 to_kv).  A caller that knows the batch composition names it: key != 0 promises that every forward issued while
- * this key is set receives encoder_hidden_states with the same CONTENT and row order as the first one did (same batch, same ctx_len).  The first
- * such forward projects into library-owned device buffers, later ones read them -- the same GEMM's output, bit for bit -- until the key changes
- * (up to 4 compositions are kept, least recently used first out; ~26 MB per sample row at SDXL-base width).  key = 0 (the default) projects at every
- * forward.  Applies to mx_unet_forward / _forward_mixed (not to the patch-parallel or block-cache entry points, nor under MX_GRAPH=1);
+ * 287-339; attention.py:59-110 to_kv).  A caller that knows the batch composition names it before each forward: key != 0 announces that the NEXT
+ * forward of this handle (ONE call: the key is consumed by it) receives encoder_hidden_states with the same CONTENT and row order as every earlier
+ * forward announced with this key did (same batch, same ctx_len).  The first such forward projects into library-owned device buffers, later ones
+ * read them -- the same GEMM's output, bit for bit (up to 4 compositions are kept, least recently used first out; ~26 MB per sample row at SDXL-base
+ * width).  A forward that was not announced projects as before.  Applies to mx_unet_forward / _forward_mixed (not to the patch-parallel or block-cache entry points, nor under MX_GRAPH=1);
  * mx_unet_set_weights drops every stored projection.  Entries are handed between streams through events: forwards of one handle may be issued on
  * several streams, from one host thread. */
 int mx_unet_set_context_key(mx_unet* u, uint64_t key);

@@ -22,10 +22,11 @@
 //     read it earlier in the launch (the two statistics buffers and ao / ao2 are distinct: mx_attn_tail_supported), so stale L2 lines cannot arise under
 //     any placement;
 //   * arithmetic: the GEMM stages run gemm_v5_tile (gemm_v5_body.h) on the instantiation the separate launches take, the attention stage
-//     attn_cross_wave (attn_cross_body.h): same tiles, same order of summation, same epilogues -- the launch's results equal the four launches' BIT FOR BIT
+//     xk_block (attn_cross_body.h): same tiles, same order of summation, same epilogues -- the launch's results equal the four launches' BIT FOR BIT
 //     (tests/test_attn_tail_gpu.py; mx_attention_cross_prescaled is the separate form of stage 2);
 //   * the counters are left zero by the last workgroup to leave (every launch finds and leaves them zero); a poll that does not end within ~2^22
 //     sleeps sets the error word and the workgroup abandons its waits (mx_attn_tail_status) instead of hanging the device.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -54,17 +55,90 @@ struct TailArgs {
   unsigned* sync;
   int mt, nt, G;          // 256-row panels, tiles (= work items) per panel and stage, panels per round of a queue
   int L;                  // tokens per sample (a panel lies inside one sample: L % 256 == 0)
-  int xunits;             // (64-query block, head) units per panel = 4 * heads
 };
 
-static_assert(sizeof(TailArgs) <= 4096, "kernel arguments are limited to 4 KB");
+ static_assert(sizeof(TailArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+// Stage 2 of a panel: the 77-key cross-attention of the panel's 256 rows for the heads == tile (mod nt) -- at most three.  The workgroup's eight waves take one
+// 32-query block of the panel each, for every one of those heads.  The heads' K / V^T fragments (24 x 1 KB per head, in the MFMA operand layout, masked:
+// xk_kfrag / xk_vfrag) are fetched ONCE per workgroup -- each wave a ninth of them -- and staged in LDS; the queries of all the wave's blocks are requested
+// at the same time: one memory round trip per item, then register / LDS work only.  A function of its own (not inlined): inside the kernel body the register
+// allocator, holding the GEMM stage's loop invariants, spilled the query fragments to scratch and this stage took 19 us per item.
+// (First forms: a (head, 64-query) unit per wave and turn as the stand-alone kernel's waves do, 15.9 us per item; a head per turn shared by the eight waves
+// through the CU's L1, 14.1 us: both pay a fragment fetch per head and wave, and nothing hides it.)
+__device__ __attribute__((noinline)) void tail_xattn(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int ldq, int ldk, int ldvt, int ldo, long vt_bstride,
+                                                     int B, int H, int Lq, int Lk, int panel, int tile, int nt, int L, unsigned lds_base) {
+  AttnArgs x;
+  x.q = q; x.k = k; x.vt = vt; x.o = o; x.ldq = ldq; x.ldk = ldk; x.ldvt = ldvt; x.ldo = ldo; x.vt_bstride = vt_bstride; x.B = B; x.H = H; x.Lq = Lq; x.Lk = Lk;
+  x.scale_log2 = 1.0f; x.xcd_map = 0; x.key_chunk = 0; x.k_bstride = 0; x.k_cstride = 0; x.vt_cstride = 0; x.causal = 0; x.bias = nullptr; x.ldb = 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int NF = XK_KFRAGS + XK_VFRAGS;
+  lds_char* const frags = reinterpret_cast<lds_char*>((uintptr_t)lds_base);
+  char* const patch = (char*)(frags + 3 * NF * 1024 + wave * 4096);       // (generic pointer: xk_block's patch accesses become flat_ accesses of LDS)
+  const int row0 = panel * 256;
+  const int b = row0 / L;
+  const int q0 = row0 - b * L + wave * 32;
+  const int nh = (H - tile + nt - 1) / nt;                  // heads of this item (<= 3: tail_prepare)
+  bf16x8 qf[3][4];
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) if (sl < nh) xk_load_q(x, b, tile + sl * nt, q0, lane, qf[sl]);
+  // the wave's ninth of the fragments: ALL requested before the first is written to LDS (a load-then-store loop serialised nine memory round trips:
+  // 7.7 us per head)
+  constexpr int NMY = 3 * NF / 8;
+  static_assert(3 * NF % 8 == 0, "the fragments of three heads are dealt to eight waves");
+  bf16x8 mine[NMY];
+#pragma unroll
+  for (int j = 0; j < NMY; ++j) {
+    const int i = wave + 8 * j;
+    if (i < nh * NF) {
+      const int sl = i / NF, f = i - sl * NF, head = tile + sl * nt;
+      mine[j] = f < XK_KFRAGS ? xk_kfrag(x, b, head, f >> 2, f & 3, lane) : xk_vfrag(x, b, head, (f - XK_KFRAGS) >> 1, (f - XK_KFRAGS) & 1, lane);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NMY; ++j) {
+    const int i = wave + 8 * j;
+    if (i < nh * NF) *reinterpret_cast<__attribute__((address_space(3))) bf16x8*>(frags + (i * 64 + lane) * 16) = mine[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    if (sl < nh) {
+      const lds_char* fb = frags + (sl * NF * 64 + lane) * 16;
+      // all of the head's fragments up front (24 LDS reads in flight), then the block on registers
+      bf16x8 kf[XK_MAXBLK][4], vf[2 * XK_MAXBLK][2];
+#pragma unroll
+      for (int kb = 0; kb < XK_MAXBLK; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(fb + (kb * 4 + ks) * 1024);
+#pragma unroll
+      for (int st = 0; st < 2 * XK_MAXBLK; ++st)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) vf[st][db] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(fb + (XK_KFRAGS + st * 2 + db) * 1024);
+      xk_block<true, true>(x, b, tile + sl * nt, q0, qf[sl], [&](int kb, int ks) __attribute__((always_inline)) { return kf[kb][ks]; },
+                           [&](int st, int db) __attribute__((always_inline)) { return vf[st][db]; }, patch, lane);
+    }
+  }
+}
+
+#ifdef MX_TAIL_STAMPS   // diagnostic build (tools/exp/tail_timeline.py): wall-clock stamps (100 MHz) per workgroup and work item
+__device__ unsigned long long g_tail_stamps[256 * 16 * 6];
+#define TAIL_STAMP(slot, val) do { if (tid == 0 && blockIdx.x < 256 && n_item < 16) g_tail_stamps[(blockIdx.x * 16 + n_item) * 6 + (slot)] = (val); } while (0)
+#define TAIL_NOW() __builtin_amdgcn_s_memrealtime()
+extern "C" int mx_debug_tail_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_stamps), sizeof(g_tail_stamps)); }
+#else
+#define TAIL_STAMP(slot, val) do {} while (0)
+#define TAIL_NOW() 0ull
+#endif
 
 __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs t) {
   constexpr int STAGE_ELEMS = (256 + kTailBN) * BK5;
   __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE5 * STAGE_ELEMS];
   __shared__ int s_ctl[4];      // [0] ticket, [1] abandon flag
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int queue = blockIdx.x & 7;
   const int np_q = t.mt > queue ? (t.mt - queue + 7) >> 3 : 0;           // panels queue, queue + 8, ...
@@ -75,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs t) {
   unsigned* const done = t.sync + kTailDone;
   if (tid == 0) s_ctl[1] = 0;
   bool abandoned = false;
+  [[maybe_unused]] int n_item = 0;
   for (;;) {
     __syncthreads();                            // (the control words of the previous item have been read by everyone)
     if (tid == 0) s_ctl[0] = (int)__hip_atomic_fetch_add(qticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -89,6 +164,8 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs t) {
     const int tile = idx % t.nt;
     if (pl >= np_q) continue;                   // (the last round of a queue may be short)
     const int panel = queue + 8 * pl;
+    TAIL_STAMP(0, ((unsigned long long)panel << 16) | (unsigned long long)(stage << 8) | (unsigned long long)tile);
+    TAIL_STAMP(1, TAIL_NOW());
     if (stage > 0 && !abandoned) {
       // ---- wait for stage - 1 of this panel: ONE lane polls relaxed, ONE acquire, then the workgroup ----
       if (tid == 0) {
@@ -110,24 +187,24 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs t) {
       __syncthreads();
       abandoned = s_ctl[1] != 0;
     }
+    TAIL_STAMP(2, TAIL_NOW());
     if (!abandoned) {
       if (stage == 2) {
-        // ---- the 77-key cross-attention of the panel's rows: unit u = (head u >> 2, 64-query block u & 3); this item takes u == tile (mod nt), one per wave and turn ----
-        const int row0 = panel * 256;
-        const int b = row0 / t.L;
-        const int q0 = row0 - b * t.L;
-        char* patch = reinterpret_cast<char*>(smem) + wave * 4096;
-        for (int u = tile + t.nt * wave; u < t.xunits; u += t.nt * 8)
-          attn_cross_wave<true, true>(t.x, b, u >> 2, q0 + (u & 3) * XK_QPW, patch, lane);
+        tail_xattn(t.x.q, t.x.k, t.x.vt, t.x.o, t.x.ldq, t.x.ldk, t.x.ldvt, t.x.ldo, t.x.vt_bstride, t.x.B, t.x.H, t.x.Lq, t.x.Lk, panel, tile, t.nt, t.L,
+                   (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
       } else {
         const GemmArgs& pk = t.g[stage == 3 ? 2 : stage];     // (ONE dynamically indexed read of the kernel-argument segment: a select of three references loads all three)
         gemm_v5_tile<kTailBN, 4, false, 0, false, false, true>(pk, panel, tile, smem);
       }
     }
     // ---- publish: every storing wave drains, the workgroup barriers, one lane signals ----
+    TAIL_STAMP(3, TAIL_NOW());
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TAIL_STAMP(4, TAIL_NOW());
     if (tid == 0) __hip_atomic_fetch_add(done + panel * kTailStages + stage, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TAIL_STAMP(5, TAIL_NOW());
+    ++n_item;
   }
   // ---- the last workgroup to leave zeroes the counters (everyone else is past its last poll) ----
   __syncthreads();                              // (every wave has read its last ticket)
@@ -141,8 +218,11 @@ __global__ __launch_bounds__(512, 2) void attn_tail_kernel(const TailArgs t) {
 }
 
 // ---- host side ----
+// The step plans take the chained launch only when asked to (MX_ATTN_TAIL=1): measured on MI355X it is a tie per layer against the four launches in
+// isolation and 1.2 ms per SDXL step SLOWER inside the step (profiles/r05_c_attn_tail_*.txt) -- the per-panel waits and drains cost what
+// the three kernel boundaries cost, and the write-through hand-offs take the hidden state out of the L2s for the launches that follow.
 static bool tail_enabled() {
-  static const bool on = [] { const char* e = getenv("MX_ATTN_TAIL"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = getenv("MX_ATTN_TAIL"); return e && e[0] == '1'; }();
   return on;
 }
 
@@ -155,6 +235,7 @@ static int tail_prepare(void* stream, const mx_attn_tail_desc* d, TailArgs& t, s
   if (M <= 0 || C <= 0 || C % kTailBN != 0 || C % 64 != 0) return no("the width must be a multiple of 160 and of 64");
   if (d->heads * 64 != C || d->B <= 0 || d->L <= 0 || d->L % 256 != 0 || (long)d->B * d->L != M) return no("heads * 64 == C, M == B * L and L % 256 == 0 are required");
   if (d->ctx_len <= 0 || d->ctx_len > 32 * XK_MAXBLK) return no("the short-key attention serves at most 96 keys");
+  if (d->heads > 3 * (C / kTailBN)) return no("an attention item stages at most three heads");
   if (!d->k || !d->vt || !d->sync || d->ldk < C || d->ldvt < MX_VT_LD(d->ctx_len) || d->ldvt % 8 != 0 || d->ldk % 8 != 0) return no("bad K / V^T / sync operands");
   for (int i = 0; i < 3; ++i) {
     const mx_gemm_desc& g = *gd[i];
@@ -185,7 +266,7 @@ static int tail_prepare(void* stream, const mx_attn_tail_desc* d, TailArgs& t, s
   t.sync = d->sync;
   t.mt = cdiv(M, 256); t.nt = C / kTailBN;
   t.G = std::max(1, (cu_count() / 8) / t.nt);
-  t.L = d->L; t.xunits = 4 * d->heads;
+  t.L = d->L;
   return 0;
 }
 
@@ -196,10 +277,15 @@ extern "C" size_t mx_attn_tail_sync_bytes(int M) {
   return ((size_t)(mx::kTailDone + mx::cdiv(M, 256) * mx::kTailStages) * sizeof(unsigned) + 255) & ~(size_t)255;
 }
 
+extern "C" int mx_attn_tail_preferred(void) { return mx::tail_enabled() ? 1 : 0; }
+
 extern "C" int mx_attn_tail_supported(const mx_attn_tail_desc* d) {
-  if (!mx::tail_enabled()) return 0;
   mx::TailArgs t;
-  return mx::tail_prepare(nullptr, d, t, nullptr) == 0;
+  static const bool dbg = getenv("MX_ATTN_TAIL_DEBUG") != nullptr;
+  std::string why;
+  const bool ok = mx::tail_prepare(nullptr, d, t, dbg ? &why : nullptr) == 0;
+  if (dbg && !ok) fprintf(stderr, "[mx attn_tail] not served: %s\n", why.c_str());
+  return ok;
 }
 
 extern "C" int mx_attn_tail(void* stream, const mx_attn_tail_desc* d) {

@@ -85,6 +85,11 @@ __device__ __forceinline__ int gemm_select_seg(GemmArgs& q, const GemmArgs& p, i
 // m-tiles of the whole launch for tiles of `rows` rows
 __device__ __forceinline__ int gemm_m_tiles(const GemmArgs& p, int rows) { return p.nseg > 0 ? p.mt_total : (p.M + rows - 1) / rows; }
 
+// a * s + c on four lanes' worth of values as explicit fused multiply-adds (the functions below switch the compiler's own contraction off)
+__device__ __forceinline__ f32x4 fma4(const f32x4 a, const float s, const f32x4 c) {
+  return f32x4{fmaf(a[0], s, c[0]), fmaf(a[1], s, c[1]), fmaf(a[2], s, c[2]), fmaf(a[3], s, c[3])};
+}
+
 // sum over the four lanes of a token (lane bits 4 and 5) without the LDS crossbar: v_permlane16_swap / v_permlane32_swap exchange
 // 16-lane rows / wave halves between two registers (inline asm: the builtins fold their two results when both inputs are one value)
 __device__ __forceinline__ float sum_over_fq(float x) {
@@ -104,6 +109,8 @@ __device__ __forceinline__ float sum_over_fq(float x) {
 template <int NI, int MI>
 __device__ __forceinline__ void gemm_ln_init(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0, const int fr,
                                              const int fq, float (&rstd)[MI]) {
+#pragma clang fp contract(off)      // (round 5) every fused multiply-add below is written out: two compilations of this function -- the stand-alone kernels and the chained
+                                    // launch of attn_tail.hip -- must round identically, and the contraction the compiler picks depends on the code around it
   // statistics layout: row m holds its slabs side by side, ln_stats[(m * pitch + slab) * 2 + {0, 1}], pitch = slabs rounded up to 4: lane
   // (token, fq) reads slabs 4 fq .. 4 fq + 3 (of every group of 16) as two 16-byte loads -- one round trip for up to 16 slabs
   const int slabs = p.ln_slabs;
@@ -136,7 +143,7 @@ __device__ __forceinline__ void gemm_ln_init(const GemmArgs& p, f32x4 (&acc)[NI]
   for (int j = 0; j < MI; ++j) {
     const float a = sum_over_fq(s1[j]), b = sum_over_fq(s2[j]);
     const float mean = a * inv;
-    const float var = fmaxf(b * inv - mean * mean, 0.f);
+    const float var = fmaxf(fmaf(-mean, mean, b * inv), 0.f);
     rstd[j] = rsqrtf(var + p.ln_eps);
     nmean[j] = -mean;
   }
@@ -152,6 +159,7 @@ __device__ __forceinline__ void gemm_ln_init(const GemmArgs& p, f32x4 (&acc)[NI]
 // one row: (rstd, rstd * mean) of row m from the slabs of partial sums.  Called by all 64 lanes; the four lanes of a token
 // (lane & 15 equal) split the slabs and combine by shuffles.
 __device__ __forceinline__ void gemm_ln_row(const GemmArgs& p, const int m, const int fq, float& rstd, float& rm) {
+#pragma clang fp contract(off)
   const int mc = m < p.M ? m : p.M - 1;
   const int pitch = (p.ln_slabs + 3) & ~3;
   float s1 = 0.f, s2 = 0.f;
@@ -163,7 +171,7 @@ __device__ __forceinline__ void gemm_ln_row(const GemmArgs& p, const int m, cons
   s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
   const float inv = 1.0f / (float)p.K;
   const float mean = s1 * inv;
-  const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+  const float var = fmaxf(fmaf(-mean, mean, s2 * inv), 0.f);
   rstd = rsqrtf(var + p.ln_eps);
   rm = rstd * mean;
 }
@@ -205,6 +213,7 @@ __device__ __forceinline__ void gemm_gn_partials(const GemmArgs& p, const f32x4 
 // LAST of the panel's N / BN workgroups reads the panel's slabs back (sc1 loads), adds them in slab order and leaves (mean, rstd) per row.  No
 // fence (an L2 write-back of the whole tile's output) and no acquire: the same hand-off as split-K below.  Every thread of the workgroup calls. ----
 __device__ __forceinline__ void gemm_ln_finalize(const GemmArgs& p, const int tm, const int nt, volatile int* ticket_word) {
+#pragma clang fp contract(off)
   const int tid = threadIdx.x;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -229,7 +238,7 @@ __device__ __forceinline__ void gemm_ln_finalize(const GemmArgs& p, const int tm
   if (!(tid & 1) && m < p.M) {
     const float inv = 1.0f / (float)p.N;
     const float mean = (a + a2) * inv;
-    const float var = fmaxf((q + q2) * inv - mean * mean, 0.f);
+    const float var = fmaxf(fmaf(-mean, mean, (q + q2) * inv), 0.f);
     *reinterpret_cast<f32x2*>(p.ln_final_out + (long)m * 2) = f32x2{mean, rsqrtf(var + p.ln_eps)};
   }
 }
@@ -240,6 +249,7 @@ __device__ __forceinline__ void gemm_ln_finalize(const GemmArgs& p, const int tm
 template <int NI, int MI, bool KEEP>
 __device__ __forceinline__ void gemm_ln_init_final(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0, const int fr,
                                                    const int fq, float (&rstd)[MI]) {
+#pragma clang fp contract(off)
   f32x2 st[MI];
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
@@ -550,6 +560,7 @@ __host__ __device__ inline int gemm_epi_features(int flags) {
 template <int NI, int MI, bool GEGLU, bool VEC = true, bool VPF = true, bool STATS = true, int FEAT = EPI_F_ALL, bool EMIT = STATS, bool RSTD_LOAD = false, bool WT = false>
 __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&acc)[NI][MI], const int m_wave0, const int wave_n0,
                                                    const int fr, const int fq, const float (&ln_rstd_a)[MI]) {
+#pragma clang fp contract(off)      // (round 5) fused multiply-adds are written out (fma4 / fmaf): every instantiation and every translation unit rounds alike
   constexpr int NIO = GEGLU ? NI / 2 : NI;     // output blocks per wave
   constexpr int NP = NIO / 2;                  // exchanged pairs
   constexpr bool ODD = (NIO & 1) != 0;         // a last block stored from the accumulator layout
@@ -621,7 +632,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
           const float rs = RSTD_LOAD ? rs_cur : STATS ? ln_rstd_a[j] : 1.0f;
 #pragma unroll
           for (int i = 0; i < NIO; ++i) {
-            const f32x4 t = STATS ? acc[i][j] * rs + bias_r[i] : acc[i][j] + bias_r[i];
+            const f32x4 t = STATS ? fma4(acc[i][j], rs, bias_r[i]) : acc[i][j] + bias_r[i];
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[(long)(i * 16 + q) * p.ldvt] = f32_to_bf16(t[q]);
           }
@@ -755,16 +766,16 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const float t = acc[i][j][q] + bias_r[i][q]; ss += t * t; }
+        for (int q = 0; q < 4; ++q) { const float t = acc[i][j][q] + bias_r[i][q]; ss = fmaf(t, t, ss); }
       ss += __shfl_xor(ss, 16, 64);
       ss += __shfl_xor(ss, 32, 64);
-      rms_mul = rsqrtf(ss * (1.0f / 64.0f) + p.rms_eps) * ((seg_pos == 0 && p.out_scale != 0.f) ? p.out_scale : 1.0f);
+      rms_mul = rsqrtf(fmaf(ss, 1.0f / 64.0f, p.rms_eps)) * ((seg_pos == 0 && p.out_scale != 0.f) ? p.out_scale : 1.0f);
     }
 #pragma unroll
     for (int i = 0; i < NIO; ++i) {
-      f32x4 t = STATS ? acc[i][j] * ln_rstd + bias_r[i] : acc[i][j] + bias_r[i];
+      f32x4 t = STATS ? fma4(acc[i][j], ln_rstd, bias_r[i]) : acc[i][j] + bias_r[i];
       if constexpr (GEGLU) {
-        const f32x4 g = STATS ? acc[i + NI / 2][j] * ln_rstd + bias_r[i + NI / 2] : acc[i + NI / 2][j] + bias_r[i + NI / 2];
+        const f32x4 g = STATS ? fma4(acc[i + NI / 2][j], ln_rstd, bias_r[i + NI / 2]) : acc[i + NI / 2][j] + bias_r[i + NI / 2];
         if (ACT && (flags & MX_EPI_GEGLU_TANH)) {  // (GEGLU: ACT = the tanh form is compiled in)
 #pragma unroll
           for (int q = 0; q < 4; ++q) t[q] = t[q] * gelu_tanh_f(g[q]);
@@ -808,7 +819,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       }
       if (stats) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { st1 += o[q]; st2 += o[q] * o[q]; }
+        for (int q = 0; q < 8; ++q) { st1 += o[q]; st2 = fmaf(o[q], o[q], st2); }
       }
     };
     if constexpr (fullmode) {
@@ -879,7 +890,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       }
       if (stats) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { st1 += o[q]; st2 += o[q] * o[q]; }
+        for (int q = 0; q < 4; ++q) { st1 += o[q]; st2 = fmaf(o[q], o[q], st2); }
       }
       if (m < p.M) store_c8(row_own(j), col0 + NP * 32 + fq * 4, u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])});
     }

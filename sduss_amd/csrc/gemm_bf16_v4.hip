@@ -104,6 +104,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   MX_STAMP(0);
   [[maybe_unused]] int stamp_i = 1;
 
+  // (Round 5, measured and removed: walking the feature panels of the fused q | k | v projection last to first, so that the V panels' 2-byte V^T stores
+  //  drain behind the q / k panels' K loops instead of at the launch's end -- 83.2 us against 81.9 us for the plain order, same box: nil.)
+  auto tile_of = [&](const int t, int& tm, int& tn) __attribute__((always_inline)) { gemm_tile_of_block(t, mt, nt, pk.xcd_map, tm, tn); };
   // ---- issue side: four cursors, one per half-tile kind (0 XH0, 1 WH0, 2 WH1, 3 XH1 = stream order inside a K tile).  Cursor c
   //      points at the next (tile, K tile) of its kind, holds ready-made per-thread byte offsets (the chooser guarantees they fit
   //      32 bits) and the ring slot of its next half-tile (stream index mod 10: + 4 per issue). ----
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   unsigned c_off[4][2];
   auto setup = [&](const int c, const int t) __attribute__((always_inline)) {
     int tm, tn;
-    gemm_tile_of_block(t, mt, nt, pk.xcd_map, tm, tn);
+    tile_of(t, tm, tn);
     // the X half-tiles belong to the tile's problem: its rows, its base (as a byte offset from abase), its joint-sequence remap
     int seg_m = pk.M, rpb = pk.rows_per_batch, abr = pk.a_batch_rows, aro = pk.a_row_off;
     unsigned abyte = 0;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
   [[maybe_unused]] f32x4 pcs[NI];
   auto ln_prefetch = [&](const int t, const bool with_cs) __attribute__((always_inline)) {
     int tm_i, tn_i;
-    gemm_tile_of_block(t, mt, nt, pk.xcd_map, tm_i, tn_i);
+    tile_of(t, tm_i, tn_i);
     if (!with_cs) {
 #pragma unroll
       for (int j = 0; j < MI; ++j) {
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
         for (int j = 0; j < MI; ++j) acc[i][j] = pcs[i] * (-pst[j][0]);
     } else if constexpr (LN) {
       int tm_i, tn_i;
-      gemm_tile_of_block(tile, mt, nt, pk.xcd_map, tm_i, tn_i);
+      tile_of(tile, tm_i, tn_i);
       gemm_ln_init_final<NI, MI, FEAT != EPI_F_QKV>(pk, acc, tm_i * BM4 + wm * 16 * MI, tn_i * BN4 + wn * 16 * NI, fr, fq, ln_rstd);
     }
 
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const GemmArgs pk) {
     if (wm == 0) MX_BAR();                     // re-align the two wave rows
 
     int tm, tn;
-    gemm_tile_of_block(tile, mt, nt, pk.xcd_map, tm, tn);
+    tile_of(tile, tm, tn);
     GemmArgs p = pk;
     gemm_select_seg(p, pk, tm);
     const int m0 = tm * BM4, n0 = tn * BN4;

@@ -71,7 +71,7 @@ struct mx_unet {
     std::vector<bf16_t*> k, vt; std::vector<size_t> k_bytes, vt_bytes;
     hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool recorded = false;
   };
-  uint64_t ctx_key = 0;                 // 0 = off: every forward projects encoder_hidden_states again
+  uint64_t ctx_key = 0;                 // the NEXT forward's composition (mx_unet_set_context_key; consumed by that forward); 0 = project encoder_hidden_states again
   std::vector<CtxEntry> ctx_store;
   uint64_t ctx_clock = 0;
   long ctx_hits = 0, ctx_misses = 0;
@@ -696,8 +696,12 @@ struct Plan {
     if (fin3) pass3 = false;
     // Round 5: the ATTENTION TAIL (attn1.to_out + residual -> attn2.to_q with norm2 folded -> the cross-attention -> attn2.to_out + residual) as ONE
     // chained launch where its three linears take 256 x 160 tiles (mx_attn_tail; attn_tail.hip): the four launches' results bit for bit.  Its hand-offs
-    // need the cross-attention output and the first projection's row statistics in buffers of their own.
-    bool tail = !pc && !is_pp() && ng == 1 && !pass2 && tail_sync != nullptr && M <= tail_rows && L % 256 == 0;
+    // need the cross-attention output and the first projection's row statistics in buffers of their own.  OPT-IN (MX_ATTN_TAIL=1): measured 2 % slower
+    // per SDXL step than the four launches (mx_attn_tail_preferred).
+    bool tail = mx_attn_tail_preferred() != 0 && !pc && !is_pp() && ng == 1 && !pass2 && tail_sync != nullptr && M <= tail_rows && L % 256 == 0;
+    if (getenv("MX_ATTN_TAIL_DEBUG") && !quiet())
+      fprintf(stderr, "[mx attn_tail] transformer %s: tail %d (pc %d pp %d ng %d pass2 %d sync %p M %d rows %ld L %d)\n", p.c_str(), (int)tail, (int)pc, (int)is_pp(), ng,
+              (int)pass2, (void*)tail_sync, M, tail_rows, L);
     bf16_t* ao2 = nullptr;
     RowStats stA;
     if (tail) {
@@ -847,6 +851,7 @@ struct Plan {
           if (!pass3) st.slabs = slabs;
           if (!quiet() && mx_attn_tail(stream, &td)) fail(std::string("attn_tail: ") + mx_last_error());
         } else {
+          if (getenv("MX_ATTN_TAIL_DEBUG")) fprintf(stderr, "[mx attn_tail] layer %s: slabs %d -> separate launches\n", b.c_str(), slabs);
           tail = false;        // (the same answer for every layer of this transformer: ask once)
         }
       }
@@ -899,7 +904,8 @@ struct Plan {
     // panel tickets of the producers that finalise LayerNorm statistics (transformer()): zero once, every launch leaves them zero
     ln_cnt = (unsigned*)ar.alloc((size_t)kLnCnt * sizeof(unsigned));
     if (ok() && !quiet() && ln_cnt && hipMemsetAsync(ln_cnt, 0, (size_t)kLnCnt * sizeof(unsigned), stream) != hipSuccess) fail("ln tickets: memset failed");
-    tail_rows = rows();              // (level 0: no attention level has more rows)
+    tail_rows = 0;                   // rows at level 0: no attention level has more
+    for (int g = 0; g < ng; ++g) tail_rows += (long)gB[g] * gH[g] * gW[g];
     if (tail_rows > 0 && tail_rows < 2147483647L) {
       const size_t nb = mx_attn_tail_sync_bytes((int)tail_rows);
       tail_sync = (unsigned*)ar.alloc(nb);
@@ -1366,6 +1372,7 @@ int forward_impl(mx_unet* u, void* stream, const void* latents, int io_dtype, co
     if (groups) { Btot = 0; for (int g = 0; g < n_groups; ++g) Btot += groups[g].batch; }
     ctx_e = ctx_prepare(u, (hipStream_t)stream, Btot, ctx_len, ctx_hit);
   }
+  if (!dry) u->ctx_key = 0;     // the key names ONE forward: a later call that does not announce itself (a trace, another caller of the handle) projects afresh
   auto enqueue = [&](hipStream_t s) {
     Plan p;
     p.u = u; p.stream = s; p.ctx_len = ctx_len;

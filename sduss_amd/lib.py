@@ -167,6 +167,7 @@ SYMBOLS = {
     "mx_attention_cross_prescaled": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i]),
     "mx_attn_tail_sync_bytes": (_sz, [_i]),
     "mx_attn_tail_supported": (_i, [C.POINTER(AttnTailDesc)]),
+    "mx_attn_tail_preferred": (_i, []),
     "mx_attn_tail": (_i, [_vp, C.POINTER(AttnTailDesc)]),
     "mx_attn_tail_status": (_i, [_vp, _vp, C.POINTER(C.c_uint)]),
     "mx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),

@@ -27,7 +27,7 @@ def bench(fn, iters=30, warm=5):
 
 
 def main():
-    for b, heads, L in ((8, 20, 1024), (8, 10, 4096), (12, 20, 1024)):
+    for b, heads, L in ((8, 20, 1024), (8, 10, 4096), (16, 20, 1024)):
         _host, args = _problem(b, heads, L)
         ref = ops.attn_tail(**args, chained=False)
         got = ops.attn_tail(**args, chained=True)

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from sduss_amd import ops  # noqa: E402
 
 SHAPES = [  # (kind, M, N, K or (hw, cin))
-    ("gemm", 8192, 1280, 1280), ("gemm", 8192, 1280, 5120), ("gemm", 8192, 3840, 1280), ("geglu", 8192, 10240, 1280),
+    ("gemm", 8192, 1280, 1280), ("gemm", 8192, 1280, 5120), ("gemm", 8192, 3840, 1280), ("qkv", 8192, 3840, 1280), ("qkv", 32768, 1920, 640), ("geglu", 8192, 10240, 1280),
     ("gemm", 32768, 640, 640), ("geglu", 32768, 5120, 640), ("gemm", 32768, 640, 2560),
     ("conv", 8, 1280, (32, 1280)), ("conv", 8, 320, (128, 320)), ("conv", 8, 640, (64, 640)),
     # more launches of several rounds of 256 x 160 tiles (the 64 x 64 and 128 x 128 levels)
@@ -59,7 +59,10 @@ def main():
             a = torch.randn(m, k, device=dev, generator=g).to(torch.bfloat16)
             w = (torch.randn(n, k, device=dev, generator=g) * k ** -0.5).to(torch.bfloat16)
             bias = torch.randn(n, device=dev, generator=g)
-            if kind == "geglu":
+            if kind == "qkv":                    # the fused q | k | v projection with its V^T epilogue (tokens per image: 1024 at 1280, 4096 at 640)
+                rpb = 1024 if n == 3840 else 4096
+                t = bench(lambda: ops.gemm_qkv(a, w, n // 3, 3, rpb, q_scale=ops.ATTN_QSCALE, bias=bias))
+            elif kind == "geglu":
                 t = bench(lambda: ops.gemm(a, w, bias, geglu=True))
             else:
                 r = torch.randn(m, n, device=dev, generator=g).to(torch.bfloat16)
