@@ -158,8 +158,12 @@ def run_stream(den, cfg, args, device, shared, rate_per_gpu, n_per_gpu, rank, wo
         r.arrival = float(a)
     active, done = [], []
     t0 = time.perf_counter()
+    last_note = 0.0
     while pending or active:
         now = time.perf_counter() - t0
+        if rank == 0 and now - last_note > 60.0:          # a full-protocol leg (500 requests) runs for minutes: stay visibly alive
+            last_note = now
+            progress(f"stream {rate_per_gpu} req/s: {len(done)} of {len(mine)} requests finished, {len(active)} active")
         while pending and len(active) < args.batch and pending[0].arrival <= now:
             r = pending.pop(0)
             r.start = now

@@ -138,11 +138,28 @@ def test_unet_full_width_sdxl_batch8(full_width_sdxl):
         want_orig = ref.unet_forward(P, ocfg, s[rows], t[rows], e[rows], te[rows], ti[rows])
     got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
     assert (got[1].float() - got[0].float()).abs().max() > 0.05 * got[0].float().abs().max()       # the rows differ: a row mix-up cannot pass
+    _calibrated_all_rows(got, P, ocfg, (s, t, e, te, ti), "unet full width 32x32 batch 8")
     got = got[rows]
     _check(got, want, "unet full width 32x32 batch 8", max_rel=0.05, l2_rel=0.03)
     # ... and against the ORIGINAL weights: real checkpoints have gamma != 1, so the fold's one extra weight rounding (bf16(W * gamma)) belongs
     # inside the stated end-to-end tolerance too (1.9 % -> 2.4 % rel L2 on the full forward)
     _check(got, want_orig, "unet full width 32x32 batch 8, original weights", max_rel=0.06, l2_rel=0.035)
+
+
+def _calibrated_all_rows(got, P, ocfg, inputs, what, ratio=1.5):
+    """Round 5 (advisor: "the oracle now checks only the first and last rows"; verdict: calibrate the tolerances): EVERY row against the fp32 oracle evaluated on
+    the GPU (the oracle's code by stock torch ops: seconds; agrees with the CPU oracle to 1e-5, tests/test_headline_shapes_gpu.py), and the bound is relative to
+    what a stock bf16 evaluation of the same graph loses on the same inputs: rel L2 per row <= ratio x the stock bf16 figure of that row."""
+    s, t, e, te, ti = inputs
+    with torch.inference_mode():
+        o32 = ref.unet_forward(P, ocfg, s, t, e, te, ti, device="cuda").cpu()
+        b16 = ref.unet_forward(P, ocfg, s, t, e, te, ti, compute_dtype=torch.bfloat16, device="cuda", sdpa=True).float().cpu()
+    g = got.float().cpu()
+    for r in range(s.shape[0]):
+        l2 = ((g[r] - o32[r]).norm() / o32[r].norm()).item()
+        sl2 = ((b16[r] - o32[r]).norm() / o32[r].norm()).item()
+        print(f"{what} row {r}: HIP rel L2 {l2:.4f}, stock bf16 {sl2:.4f}, ratio {l2 / sl2:.2f}")
+        assert l2 <= ratio * sl2, f"{what} row {r}: HIP rel L2 {l2:.4f} > {ratio} x stock bf16 {sl2:.4f}"
 
 
 @pytest.mark.parametrize("batch,hw", [(3, 24), (5, 40), (1, 48)])
@@ -156,7 +173,9 @@ def test_unet_full_width_sdxl_ragged(full_width_sdxl, batch, hw):
     with torch.inference_mode():
         want = ref.unet_forward(held, ocfg, s[rows], t[rows], e[rows], te[rows], ti[rows])
         want_orig = ref.unet_forward(P, ocfg, s[rows], t[rows], e[rows], te[rows], ti[rows])
-    got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())[rows]
+    got_all = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
+    _calibrated_all_rows(got_all, P, ocfg, (s, t, e, te, ti), f"unet full width {hw}x{hw} batch {batch}")
+    got = got_all[rows]
     _check(got, want, f"unet full width {hw}x{hw} batch {batch}", max_rel=0.05, l2_rel=0.03)
     # (round 4: 3.4 % -> 3.53 % at 48 x 48 batch 1 when the small convs of this shape moved to split-K -- another summation order; bound 4 %)
     _check(got, want_orig, f"unet full width {hw}x{hw} batch {batch}, original weights", max_rel=0.06, l2_rel=0.04)

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
 export TMPDIR=/tmp
-COMMON="--stream-requests 0 --mix 0 --no-cpu-baseline --no-roofline --no-sd3 --no-stages --no-parity"
+COMMON="--stream-requests 0 --mix 0 --no-cpu-baseline --no-roofline --no-sd3 --no-stages --no-parity --no-cached-mix --no-two-model"
 for M in sdxl sd3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$M -o $M -- python3 $R/bench.py --model $M --steps 5 --warmup 2 $COMMON > $OUT/stats_$M.log 2>&1
   echo "stats $M done"
