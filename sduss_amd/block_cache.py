@@ -280,32 +280,49 @@ class PatchSkipCache:
         self.desc.predict = self._cb
         self._slot_of, self._cap, self._patch, self._pending = {}, 0, None, None
         self._keys = []                                      # patch keys of the forward in flight, in the library's row order
-        self.previous = {}                                   # block -> {patch key: consecutive reuses}
+        self._prev = {}                                      # block -> int64[len(_keys)]: consecutive reuses per patch, aligned with _keys (remapped by bind())
         self.decisions, self.features, self.history = [], [], []
         self.record_features = False
         self.error: Optional[BaseException] = None
         self.patches_asked = self.patches_total = 0
 
+    @property
+    def previous(self):
+        """block -> {patch key: consecutive reuses} (the reference's per-key dictionaries, cache_manager.py:128,150); kept as arrays aligned with the forward's
+        patch order, because this callback runs seven times per forward on the critical path (the GPU idles while it decides)"""
+        return {blk: {k: int(v) for k, v in zip(self._keys, arr)} for blk, arr in self._prev.items()}
+
+    @previous.setter
+    def previous(self, value):
+        pos = {k: i for i, k in enumerate(self._keys)}
+        self._prev = {}
+        for blk, counts in value.items():
+            arr = np.zeros(len(self._keys), dtype=np.int64)
+            for k, v in counts.items():
+                if k in pos:
+                    arr[pos[k]] = v
+            self._prev[blk] = arr
+
     def _predict(self, _ctx, block, is_up, n, nf, timesteps, mse, run_out):
         try:
-            ts = np.ctypeslib.as_array(timesteps, shape=(n,)).astype(np.float64)
-            m = np.ctypeslib.as_array(mse, shape=(n, nf)).astype(np.float64)
-            feats = np.concatenate([np.full((n, 1), float(block)), ts[:, None], m], axis=1)
+            ts = np.ctypeslib.as_array(timesteps, shape=(n,))
+            m = np.ctypeslib.as_array(mse, shape=(n, nf))
+            feats = np.empty((n, 2 + nf), dtype=np.float64)
+            feats[:, 0] = float(block); feats[:, 1] = ts; feats[:, 2:] = m
             if self.record_features:
                 self.features.append(feats.copy())
-            keys = self._keys
-            assert len(keys) == n
-            uncached = m[:, 0] >= MSE_UNCACHED * 0.5
-            counts = self.previous.get(block, {})
-            prev = np.array([0 if uncached[i] else counts.get(keys[i], 0) for i in range(n)], dtype=np.int64)     # cache_manager.py:128,150
+            assert len(self._keys) == n
+            uncached = feats[:, 2] >= MSE_UNCACHED * 0.5
+            prev = self._prev.get(block)
+            if prev is None or len(prev) != n:
+                prev = np.zeros(n, dtype=np.int64)
+            prev = np.where(uncached, 0, prev)               # "0 if not in the cache else previous" (cache_manager.py:128,150)
             raw = np.asarray((self.up if is_up else self.down).predict(feats))
             run, new_prev = decide(raw, prev, self.forced_after)
             run = run | uncached                              # nothing cached: nothing to reuse
-            new_prev = np.where(uncached, 0, new_prev)
-            self.previous[block] = {keys[i]: int(new_prev[i]) for i in range(n)}
+            self._prev[block] = np.where(uncached, 0, new_prev)
             self.decisions.append((int(block), run.copy()))
-            for i in range(n):
-                run_out[i] = 1 if run[i] else 0
+            np.ctypeslib.as_array(run_out, shape=(n,))[:] = run
             return 0
         except BaseException as e:                           # never unwind through the C frame
             self.error = e
@@ -353,10 +370,12 @@ class PatchSkipCache:
                 else:
                     keys += [f"{row_ids[i]}-{k}" for k in range((h // gn_patch) * (w // gn_patch))]
                 i += 1
-        self._keys = keys
-        alive = set(keys)
-        for blk, counts in list(self.previous.items()):
-            self.previous[blk] = {k: v for k, v in counts.items() if k in alive}
+        if keys != self._keys:                                 # a new composition: the counters follow their patches, patches that left are forgotten
+            old_pos = {k: i for i, k in enumerate(self._keys)}
+            idx = np.array([old_pos.get(k, -1) for k in keys], dtype=np.int64)
+            for blk, arr in list(self._prev.items()):
+                self._prev[blk] = np.where(idx >= 0, arr[np.maximum(idx, 0)] if len(arr) else 0, 0).astype(np.int64)
+            self._keys = keys
         self._slots_arr = (C.c_int32 * n)(*[keep[r] for r in row_ids])
         self._valid_arr = (C.c_ubyte * n)(*valid)
         d = self.desc

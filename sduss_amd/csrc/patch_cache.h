@@ -11,6 +11,8 @@ struct PcRange { long long row0; int rows, slot, srow0; };     // rows [row0, ro
 
 int launch_pc_image_copy(hipStream_t st, void* batch, void* state, const void* samp, int B, int level, int C, long state_row_elems, int to_batch,
                          const float* vec, int ldvec, const void* residual, long max_image_elems, int gate = 0);
+int launch_pc_rows_load_stats(hipStream_t st, void* batch, const void* state, const void* samp, int B, int level, int C, long state_row_elems, const void* residual,
+                              float* stats1, float* fin, float eps, long max_image_rows);
 int launch_pc_range_copy(hipStream_t st, void* batch, void* state, long state_row_elems, int C, const void* ranges, int n, int to_batch, long max_range_elems);
 int launch_pc_range_sq_diff(hipStream_t st, const void* x, const void* state, long state_row_elems, int C, const void* ranges, int n, double* partial);
 int launch_pc_gather(hipStream_t st, const void* src, int ld_src, int C, void* dst, const void* list, int n, const void* samp, int level, int p, int halo_lo,

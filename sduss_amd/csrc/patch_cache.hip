@@ -48,6 +48,47 @@ __global__ __launch_bounds__(256) void pc_image_copy_kernel(bf16_t* batch, bf16_
   }
 }
 
+// state -> batch with a residual, TOKEN ROW by token row (round 5): one wave per row, so that the row statistics of the merged hidden state come with it --
+// the slab form the folded LayerNorm of the 256 / 128-row GEMMs reads (stats1[m][4][2]: one slab (sum, sum of squares)) and / or the finalised form of the
+// 256 x 256 kernel (fin[m] = (mean, rstd)) -- and the (x - mean) * rstd passes in front of attn2.to_q and the GEGLU projection disappear from the cached
+// forward (2.2 ms of its 64 at 8 x 1024^2: profiles/r05_e_cache_breakdown.txt).  Statistics of the bf16 values as stored (what the pass read).
+__global__ __launch_bounds__(256) void pc_rows_load_stats_kernel(bf16_t* batch, const bf16_t* __restrict__ state, const PcSample* __restrict__ samp, int level, int C,
+                                                                 long state_row_elems, const bf16_t* residual, float* __restrict__ stats1, float* __restrict__ fin, float eps) {
+  const PcSample s = samp[blockIdx.y];
+  const int rows = (s.h >> level) * (s.w >> level);
+  const long r0 = s.row0 >> (2 * level);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cv = C >> 3;                       // 16-byte vectors per row
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const u32x4* ps = reinterpret_cast<const u32x4*>(state + (long)s.slot * state_row_elems + (long)r * C);
+    const u32x4* pr = reinterpret_cast<const u32x4*>(residual + (r0 + r) * C);
+    u32x4* pb = reinterpret_cast<u32x4*>(batch + (r0 + r) * C);
+    float a = 0.f, q = 0.f;
+    for (int v = lane; v < cv; v += 64) {
+      u32x4 x = ps[v];
+      const u32x4 rr = pr[v];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned w = pack_bf16x2(bf16lo_to_f32(x[e]) + bf16lo_to_f32(rr[e]), bf16hi_to_f32(x[e]) + bf16hi_to_f32(rr[e]));
+        const float lo = bf16lo_to_f32(w), hi = bf16hi_to_f32(w);
+        a += lo + hi; q += lo * lo + hi * hi;
+        x[e] = w;
+      }
+      pb[v] = x;
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if (lane == 0) {
+      const long m = r0 + r;
+      if (stats1) *reinterpret_cast<f32x2*>(stats1 + m * 8) = f32x2{a, q};
+      if (fin) {
+        const float mean = a / (float)C;
+        const float var = fmaxf(q / (float)C - mean * mean, 0.f);
+        *reinterpret_cast<f32x2*>(fin + m * 2) = f32x2{mean, rsqrtf(var + eps)};
+      }
+    }
+  }
+}
+
 // one block per (output pixel row of the halo'd patch, compact patch): P = p + halo_lo + halo_hi pixels of C channels
 __global__ __launch_bounds__(256) void pc_gather_kernel(const bf16_t* __restrict__ src, int ld_src, int C, bf16_t* __restrict__ dst, const PcPatch* __restrict__ list,
                                                         const PcSample* __restrict__ samp, int level, int p, int halo_lo, int halo_hi, int up) {
@@ -192,6 +233,15 @@ int launch_pc_image_copy(hipStream_t st, void* batch, void* state, const void* s
   const int gx = (int)std::max<long>(1, std::min<long>((max_image_elems / 8 + 255) / 256, 128));
   hipLaunchKernelGGL(pc_image_copy_kernel, dim3(gx, B), dim3(256), 0, st, (bf16_t*)batch, (bf16_t*)state, (const PcSample*)samp, level, C, state_row_elems,
                      to_batch, vec, ldvec, (const bf16_t*)residual, gate);
+  MX_LAUNCH_CHECK();
+  return 0;
+}
+int launch_pc_rows_load_stats(hipStream_t st, void* batch, const void* state, const void* samp, int B, int level, int C, long state_row_elems, const void* residual,
+                              float* stats1, float* fin, float eps, long max_image_rows) {
+  MX_CHECK(C % 8 == 0 && B > 0 && residual != nullptr && (stats1 || fin), "pc_rows_load_stats: bad arguments");
+  const int gx = (int)std::max<long>(1, std::min<long>((max_image_rows + 3) / 4, 256));
+  hipLaunchKernelGGL(pc_rows_load_stats_kernel, dim3(gx, B), dim3(256), 0, st, (bf16_t*)batch, (const bf16_t*)state, (const PcSample*)samp, level, C, state_row_elems,
+                     (const bf16_t*)residual, stats1, fin, eps);
   MX_LAUNCH_CHECK();
   return 0;
 }

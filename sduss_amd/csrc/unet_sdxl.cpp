@@ -199,6 +199,16 @@ struct Plan {
     if (mx::launch_pc_image_copy(stream, t, reg, pc_dsamp, B, level, C, pc_row_elems(level, C), 1, vec, ldvec, residual, pc_max_image(level, C))) return fail(mx_last_error());
     return true;
   }
+  // t = state + residual, token row by token row, leaving the row statistics of t (round 5: patch_cache.hip pc_rows_load_stats): stats1 = the one-slab form
+  // ([rows][4][2] floats: sum, sum of squares) read by the folded LayerNorm of the 256 / 128-row GEMMs, fin = (mean, rstd) per row for the 256 x 256 kernel
+  bool pc_load_stats(bf16_t* t, char* reg, int level, int C, const bf16_t* residual, float* stats1, float* fin) {
+    if (!ok()) return false;
+    if (dry || mute) return true;
+    long max_rows = 0;
+    for (int g = 0; g < ng; ++g) max_rows = std::max(max_rows, (long)(gH[g] >> level) * (gW[g] >> level));
+    if (mx::launch_pc_rows_load_stats(stream, t, reg, pc_dsamp, B, level, C, pc_row_elems(level, C), residual, stats1, fin, u->cfg.layer_norm_eps, max_rows)) return fail(mx_last_error());
+    return true;
+  }
   const mx::PcPatch* pc_list() const { return pc_partial ? pc_dask : pc_dall; }
   int pc_count() const { return pc_partial ? pc_nask : pc_np; }
   // rows of the asking patches of a token-major tensor (row stride ld, C columns taken) <-> compact [n_ask * p^2, C]
@@ -674,13 +684,15 @@ struct Plan {
       mx_gemm_desc d3 = lin_desc(y, ff, 4 * C, 8 * C, MX_EPI_GEGLU, 0.f);
       pass1 = mx_gemm_ln_prefers_pass(&d1) != 0; pass2 = mx_gemm_ln_prefers_pass(&d2) != 0; pass3 = mx_gemm_ln_prefers_pass(&d3) != 0;
     }
-    if (pc) pass1 = pass2 = pass3 = true;   // the hidden state of a masked layer is produced by the state-merge kernel, which leaves no row statistics
+    // Patch-unit cache: the hidden state in front of norm2 / norm3 is produced by the state-merge kernel.  Round 5: that kernel leaves the row statistics
+    // (pc_load_stats), so the folded LayerNorms work as on the exact path; only a PARTIAL mask keeps a pass in front of attn2.to_q -- over the asking rows alone.
+    const bool pass3_shape = pass3;
     // Round 4: where the consumer runs on the 256 x 256 kernel (pass1 / pass3) and the launches that write the hidden state in front of it can
     // FINALISE the row statistics (256-row tiles: mx_gemm_ln_final_supported), the pass disappears as well: the producer's last workgroup per
     // panel leaves (mean, rstd) per row and the consumer starts its accumulators from those 8 bytes (mx_gemm_desc.ln_final).  No patch cache, not
     // patch-parallel (their hidden states come from other kernels / are compared bit for bit with the unsplit run).
     bool fin1 = false, fin3 = false;
-    if (!pc && !is_pp() && ln_cnt != nullptr && (M + 255) / 256 <= kLnCnt) {
+    if (!is_pp() && ln_cnt != nullptr && (M + 255) / 256 <= kLnCnt) {
       auto can_finalise = [&](int K, bool residual) {
         mx_gemm_desc d = lin_desc(y, y, C, C, 0, 0.f);
         d.K = K; d.lda = K; if (residual) { d.residual = y; d.ldr = C; }
@@ -690,8 +702,10 @@ struct Plan {
       //  norm3's consumer is a per-token linear over all rows, one ordinary launch whatever the mix)
       fin1 = ng == 1 && pass1 && can_finalise(C, false) && (layers == 1 || can_finalise(4 * C, true));
       fin3 = pass3 && can_finalise(C, true);
-      if (fin1 || fin3) { st.fin = (float*)ar.alloc((size_t)M * 2 * sizeof(float)); st.cnt = ln_cnt; if (!st.fin) fail("workspace too small"); }
+      if (pc) fin3 = false;                  // (norm3's statistics come from the merge kernel, not from a finalising GEMM)
+      if (fin1 || fin3 || (pc && pass3_shape)) { st.fin = (float*)ar.alloc((size_t)M * 2 * sizeof(float)); st.cnt = ln_cnt; if (!st.fin) fail("workspace too small"); }
     }
+    const bool pc_fin3 = pc && pass3_shape && st.fin != nullptr;      // GEGLU on the 256 x 256 kernel: (mean, rstd) from the merge kernel
     if (fin1) pass1 = false;
     if (fin3) pass3 = false;
     // Round 5: the ATTENTION TAIL (attn1.to_out + residual -> attn2.to_q with norm2 folded -> the cross-attention -> attn2.to_out + residual) as ONE
@@ -746,8 +760,12 @@ struct Plan {
             attention_grouped(pr, 2 * C, 2 * C, C, heads);
           } else attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, (long)C * ldvt, ao, C, heads, L, L);
         };
-        normalise();
-        { mx_gemm_desc d = qkv_desc(b, ln); wf(b + ".attn1.to_qkv.colsum", 3 * C); gemm(d, false); }
+        {   // norm1 folded into the fused q | k | v projection exactly as on the exact path (its producers are ordinary GEMMs)
+          if (pass1) normalise();
+          mx_gemm_desc d = qkv_desc(b, pass1 ? ln : y);
+          if (!pass1) { use_ln(d, st, b + ".attn1.to_qkv.colsum", fin1); if (!fin1) use_ln_grouped(d, st); } else wf(b + ".attn1.to_qkv.colsum", 3 * C);
+          gemm(d, false);
+        }
         char* reg1 = pc_region(level, C);
         if (!pc_partial) {
           self_attention_all();
@@ -759,12 +777,15 @@ struct Plan {
           linear(paoc, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", ptc, C, Mc, C, C);
           pc_scatter_rows(ptc, C, reg1, level);
         }
-        pc_load(y, reg1, level, C, nullptr, 0, y);
-        normalise();
+        // y += attn1's (fresh or cached) output; norm2's statistics come with the merge when to_q runs over all rows
+        const bool stats2 = !pc_partial && !pass2;
+        if (stats2) { pc_load_stats(y, reg1, level, C, y, st.buf, nullptr); st.slabs = 1; }
+        else pc_load(y, reg1, level, C, nullptr, 0, y);
         char* reg2 = pc_region(level, C);
         const int li = ok() ? kvp->next++ : 0;
         if (!pc_partial) {
-          linear(ln, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f));
+          if (!stats2) normalise();
+          linear(stats2 ? y : ln, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, M, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f), nullptr, 0, stats2 ? &st : nullptr);
           if (ok()) {
             if (ng > 1) {
               mx_attn_problem pr[MX_MAX_SEGS];
@@ -779,7 +800,9 @@ struct Plan {
           linear(ao, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", ptc, C, M, C, C);
           pc_store(ptc, reg2, level, C);
         } else {
-          pc_gather_rows(ln, C, C, pqc, level);
+          // the asking rows alone are normalised (the pass over all M rows in front of this gather cost as much as attn2 saved)
+          pc_gather_rows(y, C, C, paoc, level);
+          if (ok() && !quiet() && mx_layernorm(stream, paoc, pqc, nullptr, nullptr, Mc, C, u->cfg.layer_norm_eps)) fail(std::string("layernorm: ") + mx_last_error());
           linear(pqc, C, b + ".attn2.to_q.weight", b + ".attn2.to_q.bias", q2, C, Mc, C, C, nullptr, 0, 0, MX_ATTN_QSCALE(0.125f));
           if (ok()) {
             std::vector<long> cvt_off(B); std::vector<int> cld(B, kvp->ldvt), clk(B, ctx_len);
@@ -790,10 +813,18 @@ struct Plan {
           linear(paoc, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", ptc, C, Mc, C, C);
           pc_scatter_rows(ptc, C, reg2, level);
         }
-        pc_load(y, reg2, level, C, nullptr, 0, y);
-        normalise();
-        linear(ln, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU);
-        linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C);
+        // y += attn2's output; norm3's statistics with the merge: finalised for the 256 x 256 GEGLU kernel, one slab for the others
+        if (pc_fin3) pc_load_stats(y, reg2, level, C, y, nullptr, st.fin);
+        else if (!pass3) { pc_load_stats(y, reg2, level, C, y, st.buf, nullptr); st.slabs = 1; }
+        else pc_load(y, reg2, level, C, nullptr, 0, y);
+        if (pass3 && !pc_fin3) normalise();
+        {
+          const bool folded = pc_fin3 || !pass3;
+          linear(folded ? y : ln, C, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", ff, 4 * C, M, 8 * C, C, nullptr, 0, MX_EPI_GEGLU, 0.f, nullptr, 0,
+                 folded ? &st : nullptr, nullptr, pc_fin3);
+        }
+        linear(ff, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", y, C, M, C, 4 * C, y, C, 0, 0.f, nullptr, 0, nullptr,
+               (k + 1 < layers && !pass1) ? &st : nullptr, false, fin1 && k + 1 < layers);
         continue;
       }
       // self-attention (norm1 in the fused q / k / v projection)
