@@ -202,3 +202,42 @@ def test_ln_final_is_refused_where_the_256x256_kernel_does_not_run(cuda_device):
     fin = torch.zeros(512, 2, device="cuda"); cs = torch.zeros(1920, device="cuda")
     with pytest.raises(lib.MxError, match="ln_final"):
         ops.gemm(y, w, None, ln_final=fin, ln_colsum=cs)
+
+
+def test_inlaunch_handoffs_long_run_under_uneven_load(cuda_device):
+    """Advisor (round 4): the finalised row statistics and the split-K combine hand data between workgroups INSIDE a launch (relaxed agent-scope tickets, write-through
+    stores, no fence) and rely on every launch leaving its tickets at zero.  A long run under an uneven load on a second stream (launches of changing size, so that
+    the last arriver, the CUs and their L1 contents change from launch to launch): 60 finalising launches and 60 split launches, every one bit-identical to the first
+    and to the slab / unsplit form, tickets zero at the end."""
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(2025)
+    m, k, n = 8192, 1280, 1280
+    a = _rt(torch.randn(m, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5); bias = torch.randn(n, generator=g)
+    res = _hidden(g, m, n)
+    ag, wg, bg, rg = _bf(a).cuda(), _bf(w).cuda(), bias.cuda(), _bf(res).cuda()
+    final = torch.full((m, 2), float("nan"), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros((m + 255) // 256, dtype=torch.int32, device="cuda")
+    y0, (st0, slabs), f0 = ops.gemm(ag, wg, bg, residual=rg, want_stats=True, want_final=True, ln_eps=1e-5)
+    # the finalised pair must be what the slabs add up to (slab order), not only what an earlier launch left
+    s = st0[:, :slabs].double().sum(dim=1)
+    mean = s[:, 0] / n
+    rstd = ((s[:, 1] / n - mean * mean).clamp_min(0) + 1e-5).rsqrt()
+    assert (f0[:, 0].double() - mean).abs().max().item() < 1e-5 and ((f0[:, 1].double() - rstd).abs() / rstd).max().item() < 1e-5
+    ms, ks = 2048, 5120                                     # a split-K shape (one request's ff.net.2)
+    a2 = _bf(_rt(torch.randn(ms, ks, generator=g))).cuda(); w2 = _bf(_rt(torch.randn(n, ks, generator=g) * ks ** -0.5)).cuda(); r2 = _bf(_hidden(g, ms, n)).cuda()
+    s0 = ops.gemm(a2, w2, bg, residual=r2, splitk=2)
+    u0 = ops.gemm(a2, w2, bg, residual=r2, splitk=1)
+    assert ((s0.float() - u0.float()).abs().max() <= 2.0 ** -6 * u0.float().abs().max()).item()
+    side = torch.cuda.Stream()
+    noise = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    for it in range(60):
+        with torch.cuda.stream(side):
+            for j in range(1 + it % 3):
+                q = 512 * (1 + (it + 3 * j) % 8)
+                (noise[:q, :q] @ noise[:q, :q]).sum()
+        y, _st, f = ops.gemm(ag, wg, bg, residual=rg, want_stats=True, want_final=True, ln_eps=1e-5, final_buffers=(final, cnt))
+        assert torch.equal(f.view(torch.int32), f0.view(torch.int32)) and torch.equal(y, y0), f"finalising launch {it} differs"
+        sk = ops.gemm(a2, w2, bg, residual=r2, splitk=2)
+        assert torch.equal(sk, s0), f"split launch {it} differs"
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0, "the panel tickets must be zero after every launch"
