@@ -825,3 +825,51 @@ def test_patch_unit_cache_sizing_walks_on_host(tiny):
     assert ws >= l.mx_unet_workspace_bytes_mixed(h, groups, 2, 77)
     assert l.mx_unet_workspace_bytes_cached_mixed(h, groups, 2, 77, 0) == 0 and b"is_sliced" in l.mx_last_error()
     l.mx_unet_destroy(h)
+
+
+def test_attn_tail_capability_query_and_patch_skip_counters_on_host():
+    """Round 5, host-only parts.  (1) mx_attn_tail_supported is a pure host query: yes for the two transformer widths of the headline batch (and only where the
+    three linears take 256 x 160 tiles and a panel of 256 rows lies inside one sample), the sync buffer is sized per 256-row panel, and the step plans do not prefer
+    the chained launch unless MX_ATTN_TAIL=1 (measured 2 % slower per step: DESIGN.md section 4).  (2) PatchSkipCache keeps its per-patch reuse counters as arrays
+    aligned with the forward's patch order: they follow the patches through a change of composition exactly as the reference's per-key dictionaries do
+    (cache_manager.py:128-131, 150-153)."""
+    import ctypes as C
+    import numpy as np
+    from sduss_amd import lib
+    from sduss_amd.block_cache import PatchSkipCache, ThresholdPredictor
+    l = lib.load()
+
+    def desc(b, heads, L):
+        c, m = heads * 64, b * L
+        td = lib.AttnTailDesc()
+        for d, a, w, out, res in ((td.out1, 0x10000, 0x20000, 0x30000, 0x30000), (td.to_q, 0x30000, 0x40000, 0x50000, 0), (td.out2, 0x60000, 0x70000, 0x30000, 0x30000)):
+            d.a, d.w, d.c, d.bias, d.M, d.N, d.K, d.lda, d.ldc = a, w, out, 0x5000, m, c, c, c, c
+            if res:
+                d.residual, d.ldr = res, c
+        td.out1.stats_out = 0x80000
+        td.to_q.ln_stats, td.to_q.ln_colsum, td.to_q.ln_slabs, td.to_q.ln_eps = 0x80000, 0x90000, l.mx_gemm_stats_slabs(C.byref(td.out1)), 1e-5
+        td.out2.stats_out = 0xa0000
+        td.k, td.ldk, td.vt, td.ldvt, td.vt_batch_stride = 0xb0000, c, 0xc0000, 80, c * 80
+        td.B, td.heads, td.L, td.ctx_len, td.sync = b, heads, L, 77, 0xd0000
+        return td
+    assert l.mx_attn_tail_supported(C.byref(desc(8, 20, 1024))) == 1 and l.mx_attn_tail_supported(C.byref(desc(8, 10, 4096))) == 1
+    assert l.mx_attn_tail_supported(C.byref(desc(2, 20, 1024))) == 0          # one request: 128-row tiles
+    assert l.mx_attn_tail_supported(C.byref(desc(8, 20, 384))) == 0           # a 256-row panel would straddle two samples
+    bad = desc(8, 20, 1024); bad.out2.stats_out = bad.out1.stats_out
+    assert l.mx_attn_tail_supported(C.byref(bad)) == 0                        # the two statistics buffers must differ
+    assert l.mx_attn_tail_sync_bytes(8192) >= (8 * 32 + 32 + 32 * 4) * 4 and l.mx_attn_tail_sync_bytes(0) == 0
+    assert l.mx_attn_tail_preferred() == (1 if os.environ.get("MX_ATTN_TAIL") == "1" else 0)
+
+    pc = PatchSkipCache(ThresholdPredictor(0.5), forced_after=4)
+    pc._keys = ["a-0-0", "a-0-1", "b-0-0"]
+    pc.previous = {3: {"a-0-0": 2, "b-0-0": 4, "gone": 1}}
+    assert pc.previous == {3: {"a-0-0": 2, "a-0-1": 0, "b-0-0": 4}}
+    n = 3
+    ts = (C.c_float * n)(500.0, 500.0, 500.0)
+    mse = (C.c_float * n)(0.1, 0.9, 0.1)                                      # patch 1 exceeds the threshold; patch 2 has reused four times: forced
+    out = (C.c_ubyte * n)()
+    ptr = lambda a, t: C.cast(a, C.POINTER(t))             # the library hands the callback plain pointers
+    rc = pc._predict(None, 3, 0, n, 1, ptr(ts, C.c_float), ptr(mse, C.c_float), ptr(out, C.c_ubyte))
+    assert rc == 0 and pc.error is None, repr(pc.error)
+    assert list(out) == [0, 1, 1]
+    assert pc.previous[3] == {"a-0-0": 3, "a-0-1": 0, "b-0-0": 0}
