@@ -138,7 +138,7 @@ def test_unet_full_width_sdxl_batch8(full_width_sdxl):
         want_orig = ref.unet_forward(P, ocfg, s[rows], t[rows], e[rows], te[rows], ti[rows])
     got = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
     assert (got[1].float() - got[0].float()).abs().max() > 0.05 * got[0].float().abs().max()       # the rows differ: a row mix-up cannot pass
-    _calibrated_all_rows(got, P, ocfg, (s, t, e, te, ti), "unet full width 32x32 batch 8")
+    _calibrated_all_rows(got, held, ocfg, (s, t, e, te, ti), "unet full width 32x32 batch 8")
     got = got[rows]
     _check(got, want, "unet full width 32x32 batch 8", max_rel=0.05, l2_rel=0.03)
     # ... and against the ORIGINAL weights: real checkpoints have gamma != 1, so the fold's one extra weight rounding (bf16(W * gamma)) belongs
@@ -149,7 +149,11 @@ def test_unet_full_width_sdxl_batch8(full_width_sdxl):
 def _calibrated_all_rows(got, P, ocfg, inputs, what, ratio=1.5):
     """Round 5 (advisor: "the oracle now checks only the first and last rows"; verdict: calibrate the tolerances): EVERY row against the fp32 oracle evaluated on
     the GPU (the oracle's code by stock torch ops: seconds; agrees with the CPU oracle to 1e-5, tests/test_headline_shapes_gpu.py), and the bound is relative to
-    what a stock bf16 evaluation of the same graph loses on the same inputs: rel L2 per row <= ratio x the stock bf16 figure of that row."""
+    what a stock bf16 evaluation of the same graph loses on the same inputs: rel L2 per row <= ratio x the stock bf16 figure of that row.
+    P = the weights AS THE DEVICE HOLDS THEM (weights.params_as_held: the folded linears carry bf16(W * gamma), rounded once), handed to the oracle and to the stock
+    evaluation alike: the synthetic parameters are bf16-exact, so on the ORIGINAL ones the stock path would multiply by rounding-free weights -- an advantage no real
+    checkpoint gives it -- while the HIP path's one rounding of W * gamma acts as a coherent perturbation that the final conv_out amplifies (measured on this batch,
+    tools/exp/stage_calibration.py: per stage the HIP path is 0.6-0.9 x the stock error up to the last resnet, and 0.36-1.01 x at the output on equal weights)."""
     s, t, e, te, ti = inputs
     with torch.inference_mode():
         o32 = ref.unet_forward(P, ocfg, s, t, e, te, ti, device="cuda").cpu()
@@ -174,7 +178,7 @@ def test_unet_full_width_sdxl_ragged(full_width_sdxl, batch, hw):
         want = ref.unet_forward(held, ocfg, s[rows], t[rows], e[rows], te[rows], ti[rows])
         want_orig = ref.unet_forward(P, ocfg, s[rows], t[rows], e[rows], te[rows], ti[rows])
     got_all = net.forward_one(s.cuda().to(torch.bfloat16), t.cuda(), e.cuda(), te.cuda(), ti.cuda())
-    _calibrated_all_rows(got_all, P, ocfg, (s, t, e, te, ti), f"unet full width {hw}x{hw} batch {batch}")
+    _calibrated_all_rows(got_all, held, ocfg, (s, t, e, te, ti), f"unet full width {hw}x{hw} batch {batch}")
     got = got_all[rows]
     _check(got, want, f"unet full width {hw}x{hw} batch {batch}", max_rel=0.05, l2_rel=0.03)
     # (round 4: 3.4 % -> 3.53 % at 48 x 48 batch 1 when the small convs of this shape moved to split-K -- another summation order; bound 4 %)
