@@ -17,6 +17,8 @@ from sduss_amd import lib, ops  # noqa: E402
 SHAPES = [  # (label, M, N, K, geglu, residual)  -- label starting with "QKV": the fused q | k | v projection with its V^T epilogue
     ("QKV epilogue (256x256)", 8192, 3840, 1280, False, False),
     ("to_qkv  (256x256)", 8192, 3840, 1280, False, False),
+    ("LN to_qkv plain epilogue, LayerNorm from finalised statistics (256x256)", 8192, 3840, 1280, False, False),
+    ("LN QKV epilogue + LayerNorm from finalised statistics (256x256)", 8192, 3840, 1280, False, False),
     ("GEGLU   (256x256)", 8192, 10240, 1280, True, False),
     ("GEGLU 64x64 level (256x256)", 32768, 5120, 640, True, False),
     ("ff.out  (256x160)", 8192, 1280, 5120, False, True),
@@ -49,6 +51,14 @@ def main():
         run = lambda: ops.gemm(a, w, bias, geglu=geglu, residual=r)  # noqa: E731
         if label.startswith("QKV"):
             run = lambda: ops.gemm_qkv(a, w, n // 3, 3, 1024, q_scale=0.125, bias=bias)  # noqa: E731
+        if label.startswith("LN"):
+            x = a.float()
+            fin = torch.stack([x.mean(dim=1), torch.rsqrt(x.var(dim=1, unbiased=False) + 1e-5)], dim=1).contiguous()
+            colsum = w.float().sum(dim=1).contiguous()
+            if "QKV" in label:
+                run = lambda: ops.gemm_qkv(a, w, n // 3, 3, 1024, q_scale=0.125, bias=bias, ln_final=fin, ln_colsum=colsum)  # noqa: E731
+            else:
+                run = lambda: ops.gemm(a, w, bias, ln_final=fin, ln_colsum=colsum)  # noqa: E731
         us = event_us(run)
         torch.cuda.synchronize()
         run(); torch.cuda.synchronize()
