@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnGroup ga) 
 //     Q rows are fetched while the current one computes.
 // The launch is bound by its HBM traffic (Q read + O write); K / V^T stay in L2.
 // ----------------------------------------------------------------------------------------------------------------------
-template <bool PRE>
+template <bool PRE, int LK = 0>
 __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnGroup ga) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 4096];       // one 32 x 64 bf16 patch per wave
   const int tid = threadIdx.x;
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnGroup ga) 
   int qb, bh;
   const AttnArgs& p = attn_locate<4 * XK_QPW>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
   if (qb < 0) return;
-  attn_cross_wave<PRE>(p, bh / p.H, bh % p.H, qb * (4 * XK_QPW) + wave * XK_QPW, smem + wave * 4096, lane);
+  attn_cross_wave<PRE, LK>(p, bh / p.H, bh % p.H, qb * (4 * XK_QPW) + wave * XK_QPW, smem + wave * 4096, lane);
 }
 
 }  // namespace mx
@@ -1081,7 +1081,9 @@ static int launch_attention_group(void* stream, mx::AttnGroup& ga, bool pre, boo
   // (at Lq 1024 the general kernel is 7 % faster than the short-key one: both are latency-bound)
   enum { K_GENERAL, K_CROSS, K_W64, K_DMA } kind = K_GENERAL;
   if (force_cross) MX_CHECK(all_short && plain && o8, "attention: the short-key kernel needs Lk <= 96, no mask / bias / key chunks and ldo % 8 == 0");
-  if (all_short && (maxLq >= 2048 || force_cross) && plain && o8) kind = K_CROSS;          // short key sequence: every wave keeps K / V^T in registers
+  bool all77 = true;                           // the text encoders' 77 keys: the short-key kernel has a compile-time form for them (attn_cross_body.h, LK), which beats the
+  for (int i = 0; i < n; ++i) all77 = all77 && ga.g[i].Lk == 77;      // general kernel at every query length (round 5: 15.7 vs 18.8 us at B8 H20 Lq 1024, profiles/r05_l_cross77_ab.txt)
+  if (all_short && (maxLq >= 2048 || force_cross || (all77 && pre)) && plain && o8) kind = K_CROSS;          // short key sequence: every wave keeps K / V^T in registers
   else if (extra) kind = K_GENERAL;                                       // the masked / biased forms live in the register-staged kernel
   else if (pre && all_long_k && maxLq >= 2048 && o8) kind = K_W64;        // 64 query rows per wave (a tie with the 32-row kernels at Lq 1024)
   else if (whole_tiles) kind = K_DMA;                                     // whole tiles: LDS-DMA staging two tiles ahead
@@ -1101,9 +1103,12 @@ static int launch_attention_group(void* stream, mx::AttnGroup& ga, bool pre, boo
   const AttnArgs& a0 = ga.g[0];
   prof_begin(st, kind == K_CROSS ? PROF_ATTN_CROSS : PROF_ATTN, flops, bytes, n == 1 ? a0.B * a0.H : n, maxLq, a0.Lk);
   switch (kind) {
-    case K_CROSS:
-      if (pre) hipLaunchKernelGGL(attn_cross_kernel<true>, grid, block, 0, st, ga); else hipLaunchKernelGGL(attn_cross_kernel<false>, grid, block, 0, st, ga);
+    case K_CROSS: {
+      if (pre && all77) hipLaunchKernelGGL((attn_cross_kernel<true, 77>), grid, block, 0, st, ga);
+      else if (pre) hipLaunchKernelGGL(attn_cross_kernel<true>, grid, block, 0, st, ga);
+      else hipLaunchKernelGGL(attn_cross_kernel<false>, grid, block, 0, st, ga);
       break;
+    }
     case K_W64: hipLaunchKernelGGL(attn_fwd64_kernel, grid, block, 0, st, ga); break;
     case K_DMA:
       if (pre) hipLaunchKernelGGL(attn_fwd_dma_kernel<true>, grid, block, 0, st, ga); else hipLaunchKernelGGL(attn_fwd_dma_kernel<false>, grid, block, 0, st, ga);

@@ -48,29 +48,36 @@ constexpr int XK_KFRAGS = XK_MAXBLK * 4;       // K fragments of a head: [32-key
 constexpr int XK_VFRAGS = 2 * XK_MAXBLK * 2;   // V^T fragments: [16-key step][32-feature half]
 
 // K fragment (A operand of S^T): K[32 kb + r][16 ks + 8 hh ..]; rows >= Lk are zero
+// LK > 0: the key count is that compile-time constant (the launcher dispatches LK = 77, the text encoders' sequence length, when every problem has it): block and
+// step counts, the masks of the ragged last block and the exponentials of its all-padding elements are then resolved at compile time -- the runtime form spends
+// ~150 selects and ~140 moves per 32-query block on them, against ~210 essential vector instructions.  LK = 0: runtime p.Lk.
+template <int LK = 0>
 __device__ __forceinline__ bf16x8 xk_kfrag(const AttnArgs& p, const int b, const int head, const int kb, const int ks, const int lane) {
   const int r = lane & 31, hh = lane >> 5;
-  const int nblk = (p.Lk + 31) >> 5;
+  const int Lk = LK > 0 ? LK : p.Lk;
+  const int nblk = (Lk + 31) >> 5;
   const int key = kb * 32 + r;
-  const bf16_t* kp = p.k + ((long)b * p.Lk + (key < p.Lk ? key : 0)) * p.ldk + head * 64 + hh * 8;
-  return (kb < nblk && key < p.Lk) ? *reinterpret_cast<const bf16x8*>(kp + ks * 16) : __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+  const bf16_t* kp = p.k + ((long)b * Lk + (key < Lk ? key : 0)) * p.ldk + head * 64 + hh * 8;
+  return (kb < nblk && key < Lk) ? *reinterpret_cast<const bf16x8*>(kp + ks * 16) : __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
 }
 // V^T fragment (A operand of O^T): vt[64 head + 32 db + r][16 st + 8 hh ..] (MX_VT_POS order); keys >= Lk zeroed, the pad of a V^T row may hold anything
+template <int LK = 0>
 __device__ __forceinline__ bf16x8 xk_vfrag(const AttnArgs& p, const int b, const int head, const int st, const int db, const int lane) {
   const int r = lane & 31, hh = lane >> 5;
-  const int nst = (p.Lk + 15) >> 4;
+  const int Lk = LK > 0 ? LK : p.Lk;
+  const int nst = (Lk + 15) >> 4;
   u32x4 v = {0u, 0u, 0u, 0u};
   if (st < nst) {
     v = *reinterpret_cast<const u32x4*>(p.vt + (long)b * p.vt_bstride + ((long)head * 64 + db * 32 + r) * p.ldvt + st * 16 + hh * 8);
     // element e of the word is position 16 st + 8 hh + e = key 16 st + 4 hh + (e & 3) + 8 (e >> 2)   (MX_VT_POS swaps bits 2 and 3)
     const int kbase = st * 16 + 4 * hh;
-    if (kbase + 12 > p.Lk) {                   // some element may be past the end (only in the last step)
+    if (kbase + 12 > Lk) {                     // some element may be past the end (only in the last step)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k0 = kbase + 2 * (e & 1) + 8 * (e >> 1);
         unsigned w = v[e];
-        if (k0 >= p.Lk) w &= 0xffff0000u;
-        if (k0 + 1 >= p.Lk) w &= 0x0000ffffu;
+        if (k0 >= Lk) w &= 0xffff0000u;
+        if (k0 + 1 >= Lk) w &= 0x0000ffffu;
         v[e] = w;
       }
     }
@@ -90,15 +97,16 @@ __device__ __forceinline__ void xk_load_q(const AttnArgs& p, const int b, const 
 // One 32-query block: S^T = K Q^T, single-pass softmax, O^T = V^T P^T, O through the wave's 4-KB LDS patch as whole rows.  kf(kb, ks) / vf(st, db) hand out
 // the fragments (registers or LDS).  WT: O leaves as write-through (sc1) buffer stores (a chained launch hands it to other workgroups; the launcher keeps
 // O below 2 GB).
-template <bool PRE, bool WT, class KF, class VF>
+template <bool PRE, bool WT, int LK = 0, class KF, class VF>
 __device__ __forceinline__ void xk_block(const AttnArgs& p, const int b, const int head, const int q0, const bf16x8 (&qf)[4], KF&& kf, VF&& vf, char* const patch,
                                          const int lane) {
 #pragma clang fp contract(off)      // the stand-alone kernel and the chained launch must round identically (no multiply-add pair below is meant to fuse)
   const int r = lane & 31;
   const int hh = lane >> 5;
   const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.o, 0, WT ? (int)((long)p.B * p.Lq * p.ldo * 2) : 0, 0x00020000);
-  const int nblk = (p.Lk + 31) >> 5;           // <= XK_MAXBLK (launcher)
-  const int nst = (p.Lk + 15) >> 4;
+  const int Lk = LK > 0 ? LK : p.Lk;
+  const int nblk = (Lk + 31) >> 5;             // <= XK_MAXBLK (launcher)
+  const int nst = (Lk + 15) >> 4;
   const float c = PRE ? 1.0f : p.scale_log2;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // ---- S^T = K Q^T ----
@@ -119,8 +127,9 @@ __device__ __forceinline__ void xk_block(const AttnArgs& p, const int b, const i
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (LK > 0 && kb * 32 + (e & 3) + 8 * (e >> 2) >= LK) { s[kb][e] = -INFINITY; continue; }       // past the end for both half-waves: known at compile time
       float v = s[kb][e] * c;
-      if ((kb + 1) * 32 > p.Lk && key >= p.Lk) v = -INFINITY;
+      if ((kb + 1) * 32 > Lk && key >= Lk) v = -INFINITY;
       s[kb][e] = v;
       mx_ = fmaxf(mx_, v);
     }
@@ -132,6 +141,7 @@ __device__ __forceinline__ void xk_block(const AttnArgs& p, const int b, const i
     if (kb >= nblk) continue;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
+      if (LK > 0 && kb * 32 + (e & 3) + 8 * (e >> 2) >= LK) { s[kb][e] = 0.f; continue; }             // exp2(-inf) = 0 exactly: the same value, no instruction
       const float pe = __builtin_amdgcn_exp2f(s[kb][e] - mx_);
       s[kb][e] = pe;
       psum += pe;
@@ -175,18 +185,18 @@ __device__ __forceinline__ void xk_block(const AttnArgs& p, const int b, const i
 }
 
 // the stand-alone kernel's wave: the head's fragments in registers, XK_QPW queries in 32-query blocks, the next block's queries fetched while one computes
-template <bool PRE>
+template <bool PRE, int LK = 0>
 __device__ __forceinline__ void attn_cross_wave(const AttnArgs& p, const int b, const int head, const int q_wave0, char* const patch, const int lane) {
   bf16x8 kf[XK_MAXBLK][4];
 #pragma unroll
   for (int kb = 0; kb < XK_MAXBLK; ++kb)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = xk_kfrag(p, b, head, kb, ks, lane);
+    for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = xk_kfrag<LK>(p, b, head, kb, ks, lane);
   bf16x8 vf[2 * XK_MAXBLK][2];
 #pragma unroll
   for (int st = 0; st < 2 * XK_MAXBLK; ++st)
 #pragma unroll
-    for (int db = 0; db < 2; ++db) vf[st][db] = xk_vfrag(p, b, head, st, db, lane);
+    for (int db = 0; db < 2; ++db) vf[st][db] = xk_vfrag<LK>(p, b, head, st, db, lane);
   bf16x8 qf[4], qn[4];
   xk_load_q(p, b, head, q_wave0, lane, qf);
 #pragma unroll
@@ -194,7 +204,7 @@ __device__ __forceinline__ void attn_cross_wave(const AttnArgs& p, const int b, 
     const int q0 = q_wave0 + blk * 32;
     if (q0 >= p.Lq) break;                     // wave-uniform
     if (blk + 1 < XK_QPW / 32) xk_load_q(p, b, head, q0 + 32, lane, qn);
-    xk_block<PRE, false>(p, b, head, q0, qf, [&](int kb, int ks) __attribute__((always_inline)) { return kf[kb][ks]; },
+    xk_block<PRE, false, LK>(p, b, head, q0, qf, [&](int kb, int ks) __attribute__((always_inline)) { return kf[kb][ks]; },
                          [&](int st, int db) __attribute__((always_inline)) { return vf[st][db]; }, patch, lane);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
