@@ -40,6 +40,7 @@ struct GnProb {
   GnGeom g;
   const bf16_t* x; bf16_t* y;
   float* part; float* coef;
+  float* gpart;     // round 5: per (image, spatial tile, GROUP) sums instead of `part` (exact statistics only): the apply pass folds them itself, no fold launch
   long y_img;       // elements between the images of y
   int ppb;          // pixels per workgroup of the apply pass
   int patch;        // sliced statistics: patch edge in this problem's pixels (0 = exact)
@@ -63,8 +64,8 @@ __device__ __forceinline__ const bf16_t* gn_src(const bf16_t* x, const GnGeom& g
   return ch < g.C1 ? x + pix * g.C1 + ch : g.x2 + pix * (g.C - g.C1) + (ch - g.C1);
 }
 
-__global__ void gn_stats_kernel(const GnGroup G) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [L][C][2]
+__global__ void gn_stats_kernel(const GnGroup G, const int groups) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [L][C][2], then [C][2] of channel sums (gpart form)
   const int t = threadIdx.x;
   int local;
   const GnProb& P = gn_locate(G, local);
@@ -100,11 +101,23 @@ __global__ void gn_stats_kernel(const GnGroup G) {
     }
   }
   __syncthreads();
+  float* __restrict__ gpart = P.gpart;         // (uniform over the workgroup)
+  float* chs = red + (long)g.L * g.C * 2;
   for (int c = t; c < g.C; c += blockDim.x) {
     float a = 0.f, q = 0.f;
     for (int l = 0; l < g.L; ++l) { a += red[((long)l * g.C + c) * 2]; q += red[((long)l * g.C + c) * 2 + 1]; }
+    if (gpart != nullptr) { chs[2 * c] = a; chs[2 * c + 1] = q; continue; }
     float* dst = part + (((long)b * (g.tiles_y * g.tiles_x) + tile) * g.C + c) * 2;
     dst[0] = a; dst[1] = q;
+  }
+  if (gpart != nullptr) {                      // the tile's sums per GROUP, channels in order: what gn_apply_kernel<.., true> folds
+    __syncthreads();
+    const int cpg = g.C / groups;
+    for (int gi = t; gi < groups; gi += blockDim.x) {
+      float a = 0.f, q = 0.f;
+      for (int i = 0; i < cpg; ++i) { a += chs[(gi * cpg + i) * 2]; q += chs[(gi * cpg + i) * 2 + 1]; }
+      *reinterpret_cast<float2*>(gpart + (((long)b * ntl + tile) * groups + gi) * 2) = float2{a, q};
+    }
   }
 }
 
@@ -185,8 +198,12 @@ __global__ __launch_bounds__(kFoldThreads) void gn_fold_kernel(const GnGroup G, 
   }
 }
 
-template <bool SILU>
-__global__ void gn_apply_kernel(const GnGroup G) {
+// FOLD (round 5): exact statistics whose pass left per-(image, tile, group) sums (GnProb::gpart).  Every workgroup folds its image's sums itself -- fp64, a
+// FIXED order (eight strided sub-sums per group, then those in order), so every workgroup of every launch arrives at the same bits -- and derives the
+// scale / shift of its own channels: the separate fold launch (46 a step, 6.6 us + a launch boundary each) goes.  <= kFoldGroups groups.
+constexpr int kFoldGroups = 64;
+template <bool SILU, bool FOLD>
+__global__ void gn_apply_kernel(const GnGroup G, const float* __restrict__ gamma, const float* __restrict__ beta, const int groups, const float eps) {
   const int t = threadIdx.x;
   int local;
   const GnProb& P = gn_locate(G, local);
@@ -201,11 +218,50 @@ __global__ void gn_apply_kernel(const GnGroup G) {
   const int pblk = local - b * nblk;
   const int cv = t % g.tpr;
   const int pl = t / g.tpr;
-  if (pl >= g.L) return;
   float sc[8], sf[8];
-  const float* cf = coef + ((long)b * g.C + cv * 8) * 2;
+  if constexpr (FOLD) {
+    __shared__ double fsub[kFoldGroups][8][2];
+    __shared__ double mr[kFoldGroups][2];
+    const int ntl = g.tiles_y * g.tiles_x;
+    const float* __restrict__ gp = P.gpart + (long)b * ntl * groups * 2;
+    for (int it = t; it < groups * 8; it += blockDim.x) {
+      const int gi = it >> 3, sub = it & 7;
+      double s = 0.0, q = 0.0;
+      for (int tl = sub; tl < ntl; tl += 8) {
+        const float2 v = *reinterpret_cast<const float2*>(gp + ((long)tl * groups + gi) * 2);
+        s += (double)v.x; q += (double)v.y;
+      }
+      fsub[gi][sub][0] = s; fsub[gi][sub][1] = q;
+    }
+    __syncthreads();
+    const int cpg = g.C / groups;
+    const double cnt = (double)g.H * g.W * cpg;
+    for (int gi = t; gi < groups; gi += blockDim.x) {
+      double s = 0.0, q = 0.0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { sc[e] = cf[2 * e]; sf[e] = cf[2 * e + 1]; }
+      for (int sub = 0; sub < 8; ++sub) { s += fsub[gi][sub][0]; q += fsub[gi][sub][1]; }
+      const double mean = s / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      mr[gi][0] = mean;
+      mr[gi][1] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    if (pl >= g.L) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = cv * 8 + e;
+      const int gi = ch / cpg;
+      const double rg = mr[gi][1] * (double)gamma[ch];
+      sc[e] = (float)rg;
+      sf[e] = (float)((double)beta[ch] - rg * mr[gi][0]);
+    }
+  } else {
+    if (pl >= g.L) return;
+    const float* cf = coef + ((long)b * g.C + cv * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = cf[2 * e]; sf[e] = cf[2 * e + 1]; }
+  }
   const int hw = g.H * g.W;
   const int p0 = pblk * pix_per_block;
   const int p1 = min(p0 + pix_per_block, hw);
@@ -330,6 +386,7 @@ static size_t gn_fill(GnGroup& G, int i, const void* x, int C1, const void* x2, 
   const size_t ntiles = (size_t)P.g.tiles_y * P.g.tiles_x;
   P.x = (const bf16_t*)x; P.y = (bf16_t*)y; P.y_img = y_img; P.patch = patch;
   P.part = (float*)ws;
+  P.gpart = nullptr;
   P.coef = P.part + (size_t)B * ntiles * C * 2;
   const int hw = H * W;
   P.ppb = P.g.L * 8 > hw ? hw : P.g.L * 8;
@@ -344,24 +401,37 @@ static void gn_prefix(GnGroup& G, int which, int groups) {      // which: 0 stat
   }
   for (int i = G.n; i <= MX_MAX_SEGS; ++i) G.blk0[i] = (int)t;
 }
-static int gn_launch_stats(hipStream_t s, GnGroup& G, int C) {
+// groups > 0: the per-group form (GnProb::gpart set on every problem)
+static int gn_launch_stats(hipStream_t s, GnGroup& G, int C, int groups = 0) {
   const GnGeom& g = G.p[0].g;
   const int threads = ((g.tpr * g.L + 63) / 64) * 64;
-  const size_t smem = (size_t)g.L * C * 2 * sizeof(float);
+  const size_t smem = ((size_t)g.L * C * 2 + (groups > 0 ? (size_t)C * 2 : 0)) * sizeof(float);
   MX_CHECK(smem <= 160 * 1024, "groupnorm: LDS budget exceeded");
   gn_prefix(G, 0, 0);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(G.blk0[MX_MAX_SEGS]), dim3(threads), smem, s, G);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(G.blk0[MX_MAX_SEGS]), dim3(threads), smem, s, G, groups);
   MX_LAUNCH_CHECK();
   return 0;
 }
-static int gn_launch_apply(hipStream_t s, GnGroup& G, int silu) {
+// fold: the workgroups fold the per-group sums themselves (gn_apply_kernel<.., true>); otherwise the coefficients a fold launch left are read
+static int gn_launch_apply(hipStream_t s, GnGroup& G, int silu, bool fold = false, const float* gamma = nullptr, const float* beta = nullptr, int groups = 0, float eps = 0.f) {
   const GnGeom& g = G.p[0].g;
   const int threads = ((g.tpr * g.L + 63) / 64) * 64;
   gn_prefix(G, 2, 0);
-  if (silu) hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(G.blk0[MX_MAX_SEGS]), dim3(threads), 0, s, G);
-  else hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(G.blk0[MX_MAX_SEGS]), dim3(threads), 0, s, G);
+  const dim3 grid(G.blk0[MX_MAX_SEGS]), block(threads);
+  if (fold) {
+    if (silu) hipLaunchKernelGGL((gn_apply_kernel<true, true>), grid, block, 0, s, G, gamma, beta, groups, eps);
+    else hipLaunchKernelGGL((gn_apply_kernel<false, true>), grid, block, 0, s, G, gamma, beta, groups, eps);
+  } else {
+    if (silu) hipLaunchKernelGGL((gn_apply_kernel<true, false>), grid, block, 0, s, G, gamma, beta, groups, eps);
+    else hipLaunchKernelGGL((gn_apply_kernel<false, false>), grid, block, 0, s, G, gamma, beta, groups, eps);
+  }
   MX_LAUNCH_CHECK();
   return 0;
+}
+// MX_GN_FOLD=0: the three-launch form everywhere (A/B, tools/exp)
+static bool gn_fold_in_apply() {
+  static const bool on = [] { const char* e = getenv("MX_GN_FOLD"); return !(e && e[0] == '0'); }();
+  return on;
 }
 }  // namespace mx
 
@@ -396,6 +466,16 @@ extern "C" int mx_groupnorm_nhwc_grouped(void* stream, const mx_gn_problem* prob
   }
   hipStream_t s = (hipStream_t)stream;
   prof_begin(s, PROF_NORM, 0.0, bytes);
+  // exact statistics everywhere (the sliced form averages patch statistics: gn_fold_kernel): statistics per group, folded by the apply pass itself
+  bool fold = gn_fold_in_apply() && groups <= kFoldGroups;
+  for (int i = 0; i < n; ++i) fold = fold && G.p[i].patch == 0;
+  if (fold) {
+    for (int i = 0; i < n; ++i) G.p[i].gpart = G.p[i].part;      // (groups <= C: the per-group sums fit where the per-channel ones would go)
+    if (gn_launch_stats(s, G, C, groups)) return 1;
+    if (gn_launch_apply(s, G, silu, true, gamma, beta, groups, eps)) return 1;
+    prof_end(s);
+    return 0;
+  }
   if (gn_launch_stats(s, G, C)) return 1;
   gn_prefix(G, 1, groups);
   hipLaunchKernelGGL(gn_fold_kernel, dim3(G.blk0[MX_MAX_SEGS]), dim3(kFoldThreads), 0, s, G, gamma, beta, groups, eps);
