@@ -59,6 +59,7 @@ struct AttnGroup {
 // head's K / V^T (rocprofv3 FETCH_SIZE: 4.4x the algorithmic bytes at Lk = 4429).  When the number of (batch, head) pairs of a problem is a
 // multiple of 8, XCD x instead owns the pairs == x (mod 8) and walks their query blocks consecutively (its workgroup count is then a multiple
 // of 8 as well, so the next problem starts on XCD 0 again).
+// ROWS == 0: the short-key kernel's deal -- (xq_wpb + 3) / 4 workgroups per (batch, head), see launch_attention_group
 template <int ROWS>
 __device__ __forceinline__ const AttnArgs& attn_locate(const AttnGroup& ga, int& qb, int& bh) {
   int lin = blockIdx.x;
@@ -68,7 +69,7 @@ __device__ __forceinline__ const AttnArgs& attn_locate(const AttnGroup& ga, int&
   const AttnArgs& p = ga.g[s];
   lin -= ga.blk0[s];
   if (lin >= ga.nblk[s]) { qb = -1; bh = 0; return p; }      // padding up to the next problem's 8-aligned start
-  const int gx = (p.Lq + ROWS - 1) / ROWS;
+  const int gx = ROWS > 0 ? (p.Lq + ROWS - 1) / (ROWS > 0 ? ROWS : 1) : (p.xq_wpb + 3) >> 2;
   if (p.xcd_map) {
     const int local = lin >> 3;
     qb = local % gx;
@@ -1018,9 +1019,15 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(const AttnGroup ga) 
   const int lane = tid & 63;
   const int wave = tid >> 6;
   int qb, bh;
-  const AttnArgs& p = attn_locate<4 * XK_QPW>(ga, qb, bh);      // (problem of a grouped launch, query block, batch * H + head)
+  const AttnArgs& p = attn_locate<0>(ga, qb, bh);      // (problem of a grouped launch, workgroup of the pair, batch * H + head)
   if (qb < 0) return;
-  attn_cross_wave<PRE, LK>(p, bh / p.H, bh % p.H, qb * (4 * XK_QPW) + wave * XK_QPW, smem + wave * 4096, lane);
+  // the pair's 32-query blocks are dealt to its xq_wpb waves, the first `rem` taking one more: every wave of the launch works on base or base + 1 blocks
+  const int w = __builtin_amdgcn_readfirstlane(qb * 4 + wave);
+  if (w >= p.xq_wpb) return;                   // (waves work alone: no barrier in this kernel)
+  const int nb = (p.Lq + 31) >> 5;
+  const int base = nb / p.xq_wpb, rem = nb - base * p.xq_wpb;
+  const int first = w * base + (w < rem ? w : rem);
+  attn_cross_wave<PRE, LK>(p, bh / p.H, bh % p.H, first * 32, base + (w < rem ? 1 : 0), smem + wave * 4096, lane);
 }
 
 }  // namespace mx
@@ -1053,6 +1060,7 @@ static int fill_attention_args(mx::AttnArgs& a, const void* q, int ldq, const vo
   if (causal) MX_CHECK(Lq == Lk && key_chunk == 0 && Lk <= 4096, "attention: causal form is for Lq == Lk <= 4096, one key range");
   a.key_chunk = key_chunk; a.k_bstride = key_chunk > 0 ? (long)k_bstride : (long)Lk * ldk; a.k_cstride = (long)k_cstride; a.vt_cstride = (long)vt_cstride;
   a.xcd_map = ((B * H) % 8 == 0) ? 1 : 0;
+  a.xq_wpb = 0;
   return 0;
 }
 
@@ -1087,12 +1095,31 @@ static int launch_attention_group(void* stream, mx::AttnGroup& ga, bool pre, boo
   else if (extra) kind = K_GENERAL;                                       // the masked / biased forms live in the register-staged kernel
   else if (pre && all_long_k && maxLq >= 2048 && o8) kind = K_W64;        // 64 query rows per wave (a tie with the 32-row kernels at Lq 1024)
   else if (whole_tiles) kind = K_DMA;                                     // whole tiles: LDS-DMA staging two tiles ahead
-  const int rows = kind == K_CROSS ? 4 * XK_QPW : kind == K_W64 ? 256 : 128;
+  const int rows = kind == K_W64 ? 256 : 128;
+  if (kind == K_CROSS) {
+    // The short-key kernel is latency-bound: a wave pays ~3 us to fetch its head's 24 fragments and ~2.5 us per 32-query block, two workgroups per CU.  With a fixed
+    // 64 queries per wave the step's shapes were 1.25 rounds (B8 H20 Lq1024: 640 workgroups on 512 slots) or 2.5 (Lq4096).  Deal the blocks instead: every wave of
+    // a (batch, head) takes `per` or `per - 1` consecutive blocks, `per` chosen to minimise rounds x (3 + 2.5 per) -- one round whenever the pairs fit the chip.
+    const long slots = 2L * cu_count();
+    int best_per = 1; double best_t = 0;
+    int max_nb = 1;
+    for (int i = 0; i < n; ++i) max_nb = std::max(max_nb, cdiv(ga.g[i].Lq, 32));
+    for (int per = 1; per <= max_nb; ++per) {
+      long wgs = 0;
+      for (int i = 0; i < n; ++i) wgs += (long)cdiv(cdiv(cdiv(ga.g[i].Lq, 32), per), 4) * ga.g[i].H * ga.g[i].B;
+      const double t = (double)cdiv64(wgs, slots) * (3.0 + 2.5 * per);
+      if (best_t == 0 || t < best_t - 1e-9) { best_t = t; best_per = per; }
+      if (wgs <= slots) break;                 // one round: a larger share only lengthens it
+    }
+    static const bool fixed64 = [] { const char* e = getenv("MX_XQ_FIXED"); return e && e[0] == '1'; }();      // A/B: the former 64 queries per wave
+    if (fixed64) best_per = 2;
+    for (int i = 0; i < n; ++i) ga.g[i].xq_wpb = cdiv(cdiv(ga.g[i].Lq, 32), best_per);
+  }
   long blocks = 0;
   for (int i = 0; i < n; ++i) {
     blocks = (blocks + 7) & ~7L;
     ga.blk0[i] = (int)blocks;
-    ga.nblk[i] = cdiv(ga.g[i].Lq, rows) * ga.g[i].H * ga.g[i].B;
+    ga.nblk[i] = (kind == K_CROSS ? cdiv(ga.g[i].xq_wpb, 4) : cdiv(ga.g[i].Lq, rows)) * ga.g[i].H * ga.g[i].B;
     blocks += ga.nblk[i];
   }
   for (int i = n; i < MX_MAX_SEGS; ++i) ga.nblk[i] = 0;

@@ -21,6 +21,7 @@ struct AttnArgs {
   int causal;        // 1: key j counts for query i only when j <= i (text encoders; attn_fwd_kernel only)
   const float* bias; // additive score bias [H][Lq][ldb], already in the kernel's log2 domain (T5 relative position bias; attn_fwd_kernel only)
   int ldb;
+  int xq_wpb;        // short-key kernel: waves that share the 32-query blocks of one (batch, head) (launch_attention_group deals them so that the launch is ONE round)
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -185,8 +186,9 @@ __device__ __forceinline__ void xk_block(const AttnArgs& p, const int b, const i
 }
 
 // the stand-alone kernel's wave: the head's fragments in registers, XK_QPW queries in 32-query blocks, the next block's queries fetched while one computes
+// the wave's share: `nblocks` consecutive 32-query blocks from query q_wave0 (wave-uniform)
 template <bool PRE, int LK = 0>
-__device__ __forceinline__ void attn_cross_wave(const AttnArgs& p, const int b, const int head, const int q_wave0, char* const patch, const int lane) {
+__device__ __forceinline__ void attn_cross_wave(const AttnArgs& p, const int b, const int head, const int q_wave0, const int nblocks, char* const patch, const int lane) {
   bf16x8 kf[XK_MAXBLK][4];
 #pragma unroll
   for (int kb = 0; kb < XK_MAXBLK; ++kb)
@@ -199,11 +201,10 @@ __device__ __forceinline__ void attn_cross_wave(const AttnArgs& p, const int b, 
     for (int db = 0; db < 2; ++db) vf[st][db] = xk_vfrag<LK>(p, b, head, st, db, lane);
   bf16x8 qf[4], qn[4];
   xk_load_q(p, b, head, q_wave0, lane, qf);
-#pragma unroll
-  for (int blk = 0; blk < XK_QPW / 32; ++blk) {
+  for (int blk = 0; blk < nblocks; ++blk) {
     const int q0 = q_wave0 + blk * 32;
     if (q0 >= p.Lq) break;                     // wave-uniform
-    if (blk + 1 < XK_QPW / 32) xk_load_q(p, b, head, q0 + 32, lane, qn);
+    if (blk + 1 < nblocks) xk_load_q(p, b, head, q0 + 32, lane, qn);
     xk_block<PRE, false, LK>(p, b, head, q0, qf, [&](int kb, int ks) __attribute__((always_inline)) { return kf[kb][ks]; },
                          [&](int st, int db) __attribute__((always_inline)) { return vf[st][db]; }, patch, lane);
 #pragma unroll
