@@ -479,11 +479,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnGroup ga
     for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
   float m_run = -INFINITY;  // !PRE: running max of s*scale_log2 for query column r (identical in both halves)
   float l_run = 0.f;        // this half-wave's partial row sum
-  // PRE: the reference k-step.  A operand: K column of ones = element k == 0 of the step (held by the hh == 0 lanes);
-  // B operand: -m_ref (bf16-representable) in the same element of query column r.
-  const unsigned one_lo = hh == 0 ? 0x3F80u : 0u;
-  const bf16x8 kone = __builtin_bit_cast(bf16x8, u32x4{one_lo, 0u, 0u, 0u});
-  u32x4 qm = {0u, 0u, 0u, 0u};
+  // PRE: the scores leave their MFMA chain as s - m_ref: the chain STARTS from the accumulator negm = (-m_ref, ... 16 times) of the lane's query column
+  // (round 5; the guide's "row constants as the initial accumulator").  It was a fifth k-step (a K column of ones times -m_ref): two MFMAs per tile on the
+  // scores' dependency chain; the splat costs 16 registers and is rewritten only when the reference moves.
+  f32x16 negm = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float m_ref = 0.f;
 
   const int ntiles = (p.Lk + KT - 1) / KT;
@@ -529,12 +528,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnGroup ga
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
-    }
-    if constexpr (PRE) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm), s[kb], 0, 0, 0);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[ks], ks == 0 ? (PRE ? negm : zero16) : s[kb], 0, 0, 0);
     }
 #endif
     // V^T fragments (same registers): in flight while the softmax runs on the vector ALU
@@ -590,7 +584,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnGroup ga
           delta = nr - m_ref;
           m_ref = nr;
         }
-        qm[0] = hh == 0 ? (pack2(-m_ref, 0.f) & 0xffffu) : 0u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[e] = -m_ref;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -618,10 +613,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnGroup ga
           for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
-              s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm), s[kb], 0, 0, 0);
+              s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[ks], ks == 0 ? negm : s[kb], 0, 0, 0);
           move_reference(false);
           psum = exps();
 #pragma unroll
@@ -787,11 +779,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnGroup ga) 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 oacc[2][2] = {{zero16, zero16}, {zero16, zero16}};
   float l_run[2] = {0.f, 0.f};                 // this half-wave's partial row sums
-  // the reference k-step (see attn_fwd_kernel): A operand = a K column of ones, B operand = -m_ref of query column r
+  // the scores leave their MFMA chains as s - m_ref.  Block 0: the chain starts from negm0 = (-m_ref x 16) of the lane's query column (see attn_fwd_dma_kernel).
+  // Block 1: the reference k-step (A operand = a K column of ones, B operand = -m_ref of query column r, bf16-representable): a splat for both blocks does not
+  // fit the 256 registers of two waves per SIMD (measured with 11 spills: 332 -> 381 us at Lk 4096).
+  f32x16 negm0 = zero16;
   const unsigned one_lo = hh == 0 ? 0x3F80u : 0u;
   const bf16x8 kone = __builtin_bit_cast(bf16x8, u32x4{one_lo, 0u, 0u, 0u});
-  u32x4 qm[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  u32x4 qm1 = {0u, 0u, 0u, 0u};
   float m_ref[2] = {0.f, 0.f};
+  auto set_ref = [&](int blk) __attribute__((always_inline)) {
+    if (blk == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) negm0[e] = -m_ref[0];
+    } else {
+      qm1[0] = hh == 0 ? (pack2(-m_ref[1], 0.f) & 0xffffu) : 0u;
+    }
+  };
 
   const int ntiles = (p.Lk + KT - 1) / KT;     // >= 3 (launcher)
 
@@ -834,10 +837,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnGroup ga) 
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[blk][ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[kb * 4 + ks], qf[blk][ks], ks == 0 ? (blk == 0 ? negm0 : zero16) : s[kb], 0, 0, 0);
+    if (blk != 0) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-      s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm[blk]), s[kb], 0, 0, 0);
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, __builtin_bit_cast(bf16x8, qm1), s[kb], 0, 0, 0);
+    }
   };
   auto col_max = [&](const f32x16 (&s)[2]) __attribute__((always_inline)) {
     float mx_ = fmaxf(s[0][0], s[1][0]);
@@ -871,11 +876,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnGroup ga) 
     const float mx_ = col_max(s);
     float delta = 0.f;
     if (mx_ > 8.0f) {
-      const float nr = bf16lo_to_f32(pack2(m_ref[blk] + mx_, 0.f));          // new reference, bf16-representable
+      const float nr = bf16lo_to_f32(pack2(m_ref[blk] + mx_, 0.f));          // new reference (rounded to bf16, as the former k-step form needed it: same values)
       delta = nr - m_ref[blk];
       m_ref[blk] = nr;
     }
-    qm[blk][0] = hh == 0 ? (pack2(-m_ref[blk], 0.f) & 0xffffu) : 0u;
+    set_ref(blk);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnGroup ga) 
       f32x16 s[2];
       qk(s, fr, blk);
       m_ref[blk] = bf16lo_to_f32(pack2(col_max(s), 0.f));
-      qm[blk][0] = hh == 0 ? (pack2(-m_ref[blk], 0.f) & 0xffffu) : 0u;
+      set_ref(blk);
     }
   }
   int buf = 0;
