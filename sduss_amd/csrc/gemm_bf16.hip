@@ -190,6 +190,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs pk) {
 int launch_v2(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
 int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
 int launch_v4(hipStream_t s, const GemmArgs& a);
+bool small_m_serves(const mx_gemm_desc* d, bool conv);      // gemm_small_m.hip: M <= 16, the weight-stream form
+int launch_small_m(hipStream_t s, const GemmArgs& a);
 
 // Tile choice for the pipelined kernels.  Candidates (token rows x features): 256x256 (gemm_bf16_v3.hip), 256x160, 256x128,
 // 128x160, 128x128 (gemm_bf16_v2.hip).  Estimated cost = full-chip rounds of 256 workgroups (one per CU) x (rows + features):
@@ -560,7 +562,9 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   }
   const int mt128 = grouped ? a.mt_total : cdiv(d->M, BM);      // m-tiles of the generic kernel
   if (d->ln_final) MX_CHECK(v2bn == 256, "gemm: ln_final is the 256 x 256 kernel's form of the folded LayerNorm; this shape does not run there (use ln_stats)");
-  if (v2bn == 256) {
+  if (small_m_serves(d, conv)) {
+    launch_small_m(s, a);                      // M <= 16: a weight stream (gemm_small_m.hip)
+  } else if (v2bn == 256) {
     MX_CHECK(launch_v4(s, a) == 0, "gemm: no 256 x 256 instantiation serves ln_final with this epilogue (GEGLU, QKV or plain bias only)");   // 256 x 256 ping-pong (gemm_bf16_v4.hip)
   } else if (v2bn) {
     // 256-row tiles: ping-pong schedule (gemm_bf16_v5.hip).  128-row tiles (small M) stay on the lock-step loop of gemm_bf16_v2.hip: the

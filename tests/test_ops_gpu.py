@@ -53,6 +53,30 @@ def test_gemm_bias_residual(cuda_device, m, n, k):
     _close(got, F.silu(a @ w.t() + b), 1e-4, "gemm+silu f32")
 
 
+@pytest.mark.parametrize("m,n,k", [(8, 1280, 2816), (8, 1280, 320), (2, 1280, 1280), (16, 1536, 256), (1, 64, 64), (8, 13760, 1280), (5, 48, 192), (8, 1536, 2048)])
+def test_gemm_small_m_weight_stream(cuda_device, m, n, k):
+    """M <= 16 (gemm_small_m.hip: the time / condition embedding MLPs, the stacked time_emb_proj and AdaLN modulation): every epilogue the plans use on it"""
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(m * 131 + n + k)
+    a = _rt(torch.randn(m, k, generator=g)); w = _rt(torch.randn(n, k, generator=g) * k ** -0.5)
+    b = torch.randn(n, generator=g); r = _rt(torch.randn(m, n, generator=g))
+    ad, wd, bd, rd = _bf(a).cuda(), _bf(w).cuda(), b.cuda(), _bf(r).cuda()
+    lin = a @ w.t() + b
+    _close(ops.gemm(ad, wd, bd), lin, 2.0 ** -7, "small-M bias")
+    _close(ops.gemm(ad, wd, None), a @ w.t(), 2.0 ** -7, "small-M no bias")
+    _close(ops.gemm(ad, wd, bd, silu=True), F.silu(lin), 2.0 ** -7, "small-M silu")
+    _close(ops.gemm(ad, wd, bd, residual=rd, silu=True), F.silu(lin + r), 2.0 ** -7, "small-M residual + silu")
+    got = ops.gemm(ad, wd, bd, out_f32=True)
+    assert got.dtype == torch.float32
+    _close(got, lin, 1e-4, "small-M fp32 out")
+    # deterministic: the four K slices of a workgroup are added in wave order
+    assert torch.equal(ops.gemm(ad, wd, bd, out_f32=True), got)
+    # the row just past the form's reach takes the tile kernel and agrees
+    if m == 16:
+        a2 = _rt(torch.randn(17, k, generator=g))
+        _close(ops.gemm(_bf(a2).cuda(), wd, bd, out_f32=True), a2 @ w.t() + b, 1e-4, "M = 17 (tile kernel)")
+
+
 def test_gemm_rowbias(cuda_device):
     from sduss_amd import ops
     g = torch.Generator().manual_seed(3)
