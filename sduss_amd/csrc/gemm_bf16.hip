@@ -192,6 +192,8 @@ int launch_v5(hipStream_t s, const GemmArgs& a, bool conv, int bn, int rows);
 int launch_v4(hipStream_t s, const GemmArgs& a);
 bool small_m_serves(const mx_gemm_desc* d, bool conv);      // gemm_small_m.hip: M <= 16, the weight-stream form
 int launch_small_m(hipStream_t s, const GemmArgs& a);
+bool conv_small_n_serves(const mx_gemm_desc* d);                // conv_small_n.hip: 3x3 conv with N <= 16 output channels (conv_out)
+int launch_conv_small_n(hipStream_t s, const GemmArgs& a);
 
 // Tile choice for the pipelined kernels.  Candidates (token rows x features): 256x256 (gemm_bf16_v3.hip), 256x160, 256x128,
 // 128x160, 128x128 (gemm_bf16_v2.hip).  Estimated cost = full-chip rounds of 256 workgroups (one per CU) x (rows + features):
@@ -564,6 +566,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
   if (d->ln_final) MX_CHECK(v2bn == 256, "gemm: ln_final is the 256 x 256 kernel's form of the folded LayerNorm; this shape does not run there (use ln_stats)");
   if (small_m_serves(d, conv)) {
     launch_small_m(s, a);                      // M <= 16: a weight stream (gemm_small_m.hip)
+  } else if (conv && conv_small_n_serves(d)) {
+    launch_conv_small_n(s, a);                 // N <= 16: the input read once (conv_small_n.hip)
   } else if (v2bn == 256) {
     MX_CHECK(launch_v4(s, a) == 0, "gemm: no 256 x 256 instantiation serves ln_final with this epilogue (GEGLU, QKV or plain bias only)");   // 256 x 256 ping-pong (gemm_bf16_v4.hip)
   } else if (v2bn) {

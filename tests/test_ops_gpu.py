@@ -157,6 +157,21 @@ def test_conv3x3(cuda_device, stride, up, corner, hw, cin, cout):
     _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, f"conv3x3 s{stride} up{up} corner{corner}")
 
 
+@pytest.mark.parametrize("corner,h,w,cin,cout,b", [(0, 16, 16, 64, 4, 2), (0, 12, 20, 320, 4, 3), (4, 16, 16, 64, 4, 2), (8, 32, 32, 128, 8, 1), (0, 7, 9, 64, 16, 2), (0, 128, 128, 320, 4, 2)])
+def test_conv3x3_small_n(cuda_device, corner, h, w, cin, cout, b):
+    """a handful of output channels (conv_small_n.hip: the UNet's conv_out): ragged image edges, the sliced path's corner rule, several channel counts"""
+    from sduss_amd import ops
+    g = torch.Generator().manual_seed(corner * 7 + h + cin + cout)
+    x = _rt(torch.randn(b, cin, h, w, generator=g)); wt = _rt(torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g)
+    want = ref.conv3x3(x, wt, bias, 1, corner if corner else None)
+    got = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(wt)).cuda(), bias.cuda(), corner_patch=corner)
+    _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, f"conv3x3 small N corner{corner}")
+    if corner == 0:
+        got2 = ops.conv3x3(_bf(_nhwc(x)).cuda(), _bf(_conv_pack(wt)).cuda(), None)
+        _close(got2.permute(0, 3, 1, 2), F.conv2d(x, wt, None, padding=1), 2.0 ** -7, "conv3x3 small N, no bias")
+
+
 def test_conv3x3_rowbias_residual(cuda_device):
     from sduss_amd import ops
     g = torch.Generator().manual_seed(9)
