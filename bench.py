@@ -39,8 +39,8 @@ MODELS = {   # steps per image, algorithmic FLOP per sample-forward at 1024^2 (S
 STEPS_PER_IMAGE = 50
 MFMA_PEAK_BF16 = 2.5e15                    # dense, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
-KIND_NAMES = ["gemm_kernel<128,false>", "gemm_kernel<64,false>", "gemm_kernel<128,true> (conv3x3)",
-              "gemm_kernel<64,true> (conv3x3)", "attn_fwd_kernel", "groupnorm (3 kernels)", "gemm_v5/v2_kernel<160,false>",
+KIND_NAMES = ["gemm_kernel<128,false> / gemm_small_m_kernel (M <= 16)", "gemm_kernel<64,false> / gemm_small_m_kernel (M <= 16)", "gemm_kernel<128,true> (conv3x3)",
+              "gemm_kernel<64,true> / conv3x3_small_n_kernel (conv_in / conv_out)", "attn_fwd_kernel", "groupnorm (3 kernels)", "gemm_v5/v2_kernel<160,false>",
               "gemm_v5/v2_kernel<160,true> (conv3x3)", "gemm_v5/v2_kernel<128,false>", "gemm_v5/v2_kernel<128,true> (conv3x3)",
               "gemm_v4_kernel (256x256 ping-pong)", "attn_cross_kernel (Lk<=96)",
               "attn_tail_kernel (to_out + to_q + cross-attention + to_out, one chained launch)"]
