@@ -126,7 +126,7 @@ bool conv_small_n_serves(const mx_gemm_desc* d) {
   if (off || d->n_segs != 0 || d->N > 16 || d->N % 4 != 0 || d->Cin % 64 != 0) return false;
   if (d->stride != 1 || d->up != 0 || d->vhalo != 0 || d->flags != 0) return false;
   if (d->rowbias || d->residual || d->gate || d->out_scale != 0.f || d->gn_part_out || d->splitk > 1) return false;
-  if ((long)d->N * d->K * 2 > 64 * 1024 || d->ldc % 4 != 0) return false;
+  if ((((long)d->N * d->K * 2 + 255) & ~255L) + (long)kSnPix * kSnStride > 64 * 1024 || d->ldc % 4 != 0) return false;      // weights + one staged chunk within 64 KB of LDS
   if ((long)d->B * d->Hin * d->Win * d->Cin >= 2147483647L) return false;          // 32-bit source offsets
   return true;
 }
