@@ -223,6 +223,15 @@ int mx_gemm_ln_prefers_pass(const mx_gemm_desc* d);
 /* 1 when mx_gemm(d) with stats_out can also write ln_final_out (the launch takes a 256-row tile of the register-exchange kernels, ungrouped) */
 int mx_gemm_ln_final_supported(const mx_gemm_desc* d);
 int mx_gemm_gn_partials_supported(const mx_gemm_desc* d, int conv);   /* 1 when mx_gemm / mx_conv3x3 (d) can write gn_part_out */
+/* Which kernel family serves mx_gemm (conv = 0) / mx_conv3x3 (conv = 1) of d -- host only, the same chooser the launch uses:
+ *   MX_FORM_TILE_GENERIC   the 128-row register-prefetch tile kernel (small or odd shapes)
+ *   MX_FORM_TILE_256       a 256-row tile of the ping-pong kernels (256 x 160 / 128, one tile per CU)
+ *   MX_FORM_TILE_128       a 128-row tile of the lock-step LDS-DMA kernel (small M; possibly split along K)
+ *   MX_FORM_PERSISTENT_256 the persistent 256 x 256 kernel
+ *   MX_FORM_SMALL_M        round 5: M <= 16 rows as a weight stream (bias, per-row residual, SiLU, bf16 / fp32 out; N % 16 == 0, at most 64 MB of weights)
+ *   MX_FORM_CONV_SMALL_N   round 5: 3 x 3 conv with N <= 16 output channels (stride 1, bias only; weights + one staged chunk within 64 KB of LDS) */
+enum { MX_FORM_TILE_GENERIC = 0, MX_FORM_TILE_256 = 1, MX_FORM_TILE_128 = 2, MX_FORM_PERSISTENT_256 = 3, MX_FORM_SMALL_M = 4, MX_FORM_CONV_SMALL_N = 5 };
+int mx_gemm_form(const mx_gemm_desc* d, int conv);
 #define MX_STATS_PITCH(slabs) (((slabs) + 3) & ~3)     /* slabs per row of a statistics buffer: [M][pitch][2] floats */
 /* stats[m * 4 * 2 + {0, 1}] = (sum_c x[m][c], sum_c x[m][c]^2), x bf16 [M, C] with row stride ldx: the one-slab input of ln_stats
  * (buffer of M * MX_STATS_PITCH(1) * 2 floats) */

@@ -638,6 +638,13 @@ extern "C" int mx_gemm(void* stream, const mx_gemm_desc* d) {
 }
 /* launches mx_gemm(d) issues: 2 where the tail split applies (tests, planning) */
 extern "C" int mx_gemm_launches(const mx_gemm_desc* d) { mx_gemm_desc d1, d2; return d != nullptr && mx::tail_split(d, d1, d2) ? 2 : 1; }
+extern "C" int mx_gemm_form(const mx_gemm_desc* d, int conv) {
+  if (!d || mx::rows_of(d) <= 0 || d->N <= 0 || d->K <= 0) return MX_FORM_TILE_GENERIC;
+  if (mx::small_m_serves(d, conv != 0)) return MX_FORM_SMALL_M;
+  if (conv && mx::conv_small_n_serves(d)) return MX_FORM_CONV_SMALL_N;
+  const mx::TileChoice tc = mx::pick_tile(d, conv != 0);
+  return tc.bn == 256 ? MX_FORM_PERSISTENT_256 : tc.bn == 0 ? MX_FORM_TILE_GENERIC : tc.rows == 256 ? MX_FORM_TILE_256 : MX_FORM_TILE_128;
+}
 extern "C" int mx_gemm_stats_slabs(const mx_gemm_desc* d) {
   if (!d || mx::rows_of(d) <= 0 || d->N <= 0 || d->K <= 0) return 0;
   mx_gemm_desc q = *d;

@@ -203,6 +203,7 @@ SYMBOLS = {
     "mx_gemm_ln_final_supported": (_i, [C.POINTER(GemmDesc)]),
     "mx_gemm_launches": (_i, [C.POINTER(GemmDesc)]),
     "mx_gemm_gn_partials_supported": (_i, [C.POINTER(GemmDesc), _i]),
+    "mx_gemm_form": (_i, [C.POINTER(GemmDesc), _i]),
     "mx_groupnorm_nhwc_from_partials": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "mx_unet_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "mx_mmdit_patch_cache_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),

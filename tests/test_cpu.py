@@ -409,6 +409,23 @@ def test_layernorm_fold_algebra_and_tile_policy():
         return d
     assert l.mx_gemm_gn_partials_supported(C.byref(conv(8, 32, 1280, 1280)), 1) == 1 and l.mx_gemm_gn_partials_supported(C.byref(conv(8, 128, 320, 320)), 1) == 1
     assert l.mx_gemm_gn_partials_supported(C.byref(conv(8, 32, 1280, 1280, residual=True)), 1) == 0 and l.mx_gemm_gn_partials_supported(C.byref(conv(1, 32, 1280, 1280)), 1) == 0
+    # round 5: which kernel family serves a launch (mx_gemm_form): the M <= 16 weight stream, conv_out's small-N kernel, and the tile families
+    GENERIC, T256, T128, P256, SMALL_M, SMALL_N = range(6)
+    form = lambda d, c=0: l.mx_gemm_form(C.byref(d), c)
+    assert form(desc(8, 1280, 2816, lib.EPI_SILU)) == SMALL_M and form(desc(16, 13760, 1280, lib.EPI_OUT_F32)) == SMALL_M and form(desc(1, 64, 64)) == SMALL_M
+    assert form(desc(17, 1280, 2816)) == GENERIC                      # one row past the form's reach
+    assert form(desc(8, 442368, 1536, lib.EPI_OUT_F32)) == GENERIC    # the MMDiT's stacked AdaLN modulation (1.4 GB of weights): the tile kernel streams it faster
+    assert form(desc(8, 1280, 1280, lib.EPI_GEGLU)) == GENERIC and form(desc(8, 1288, 1280)) == GENERIC      # gated epilogue / N % 16 != 0
+    assert form(desc(8192, 1280, 1280)) == T256 and form(desc(2048, 1280, 1280)) == T128 and form(desc(8192, 10240, 1280, lib.EPI_GEGLU)) == P256
+    def conv_out(b, hw, cin, cout, **kw):
+        d = conv(b, hw, cin, cout)
+        d.rowbias, d.ldrb, d.rows_per_batch = None, 0, 0
+        for k, v in kw.items(): setattr(d, k, v)
+        return d
+    assert form(conv_out(8, 128, 320, 4), 1) == SMALL_N and form(conv_out(2, 128, 320, 4, corner_patch=32), 1) == SMALL_N
+    assert form(conv_out(8, 128, 320, 16), 1) != SMALL_N               # 16 x 2880 weights + the staged chunk exceed 64 KB of LDS
+    assert form(conv_out(8, 128, 320, 4, stride=2, Hout=64, Wout=64, M=8 * 64 * 64), 1) != SMALL_N and form(conv(8, 128, 320, 4), 1) != SMALL_N      # stride 2; a row bias
+    assert form(conv_out(8, 128, 320, 320), 1) == T256
 
 
 def test_clip_plan_resolves_packed_weights_on_host():
