@@ -207,6 +207,9 @@ typedef struct mx_gemm_desc {
    * (the reference's resnet: conv1 + time embedding -> norm2, resnet.py:414-429).  mx_gemm_gn_partials_supported(d,
    * conv) tells whether the launch can. */
   float* gn_part_out;
+  /* mx_conv3x3 (round 5): > 0 = only the first cin_valid (<= 8) channels of every input pixel are non-zero -- the UNet's conv_in reads the 4 latent channels
+   * zero-padded to Cin = 64.  The launch may then contract over 9 x 8 instead of 9 x Cin (conv_small_n.hip); 0 = every channel counts.  Never changes the result. */
+  int cin_valid;
 } mx_gemm_desc;
 
 int mx_gemm(void* stream, const mx_gemm_desc* d);      /* C = A * W^T (+epilogue) */
@@ -229,8 +232,9 @@ int mx_gemm_gn_partials_supported(const mx_gemm_desc* d, int conv);   /* 1 when 
  *   MX_FORM_TILE_128       a 128-row tile of the lock-step LDS-DMA kernel (small M; possibly split along K)
  *   MX_FORM_PERSISTENT_256 the persistent 256 x 256 kernel
  *   MX_FORM_SMALL_M        round 5: M <= 16 rows as a weight stream (bias, per-row residual, SiLU, bf16 / fp32 out; N % 16 == 0, at most 64 MB of weights)
- *   MX_FORM_CONV_SMALL_N   round 5: 3 x 3 conv with N <= 16 output channels (stride 1, bias only; weights + one staged chunk within 64 KB of LDS) */
-enum { MX_FORM_TILE_GENERIC = 0, MX_FORM_TILE_256 = 1, MX_FORM_TILE_128 = 2, MX_FORM_PERSISTENT_256 = 3, MX_FORM_SMALL_M = 4, MX_FORM_CONV_SMALL_N = 5 };
+ *   MX_FORM_CONV_SMALL_N   round 5: 3 x 3 conv with N <= 16 output channels (stride 1, bias only; weights + one staged chunk within 64 KB of LDS)
+ *   MX_FORM_CONV_SMALL_CIN round 5: 3 x 3 conv whose descriptor names cin_valid <= 8 input channels (stride 1, bias only, N % 80 == 0) */
+enum { MX_FORM_TILE_GENERIC = 0, MX_FORM_TILE_256 = 1, MX_FORM_TILE_128 = 2, MX_FORM_PERSISTENT_256 = 3, MX_FORM_SMALL_M = 4, MX_FORM_CONV_SMALL_N = 5, MX_FORM_CONV_SMALL_CIN = 6 };
 int mx_gemm_form(const mx_gemm_desc* d, int conv);
 #define MX_STATS_PITCH(slabs) (((slabs) + 3) & ~3)     /* slabs per row of a statistics buffer: [M][pitch][2] floats */
 /* stats[m * 4 * 2 + {0, 1}] = (sum_c x[m][c], sum_c x[m][c]^2), x bf16 [M, C] with row stride ldx: the one-slab input of ln_stats

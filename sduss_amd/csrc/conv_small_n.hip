@@ -121,6 +121,90 @@ __global__ __launch_bounds__(256) void conv3x3_small_n_kernel(const GemmArgs p) 
   }
 }
 
+// ---- the mirror case: a handful of INPUT channels (the UNet's conv_in: 4 latent channels -> 320, stored zero-padded to 64 channels per pixel so that the
+// tile kernels can read it; unet.py:344).  As an implicit GEMM over the padded input it is K = 9 x 64 with 4 useful channels per tap: 95 us at the headline batch
+// for 84 MB of output.  Here K is 9 taps x 8 channels = 72: a lane's MFMA fragment is the first 16 bytes of ONE tap's pixel (three k-steps of four taps; taps 9..11
+// are zeros), the repacked weights [N][72] sit in LDS, a wave owns 16 pixels and walks the output channels 80 at a time -- 15 MFMAs, then the 16 x 80 results go
+// through a wave-private LDS patch so that they leave as 160 contiguous bytes per pixel.  Bound by the output write.
+constexpr int kScWRow = 72;                    // repacked weight row: 9 taps x 8 channels (144 bytes: 16 rows x 4 pieces read conflict-free)
+constexpr int kScStage = 176;                  // bytes per staged pixel: 80 channels + 16 of padding
+
+__global__ __launch_bounds__(256) void conv3x3_small_cin_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // weights [N][72] bf16, then 4 waves x 16 pixels x 176 bytes of output staging
+  bf16_t* sw = reinterpret_cast<bf16_t*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int H = p.Hin, W = p.Win, Cin = p.Cin, N = p.N;
+  char* stage = smem + (((size_t)N * kScWRow * 2 + 255) & ~(size_t)255) + wave * (16 * kScStage);
+  for (int c = tid; c < N * 9; c += 256) {             // (feature, tap): the first 8 channels of the tap
+    const int n = c / 9, tap = c - n * 9;
+    *reinterpret_cast<u32x4*>(sw + (long)n * kScWRow + tap * 8) = *reinterpret_cast<const u32x4*>(p.w + ((long)n * 9 + tap) * Cin);
+  }
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + 3) >> 2;
+  const int tiles = p.B * tiles_x * tiles_y;
+  const int P = p.corner_patch;
+  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int t = tile - b * tiles_x * tiles_y;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int y = ty * 4 + wave, x = tx * 16 + j;
+    if (y >= H) continue;                               // (wave-uniform; the loop holds no workgroup barrier)
+    // B operand: k-step s holds taps 4 s + kq of pixel j
+    bf16x8 xf[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int tap = 4 * s + kq;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      int iy = y + dy;
+      const int ix = x + dx;
+      if (P > 0 && dy != 0 && dx != 0) {                // halo-corner rule of the reference's sliced path (norm_silu_concat.cu:210-221, 228-239)
+        const bool cross_r = ((iy + P) / P) != ((y + P) / P);
+        const bool cross_c = ((ix + P) / P) != ((x + P) / P);
+        if (cross_r && cross_c) iy = y;
+      }
+      const bool ok = tap < 9 && x < W && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      xf[s] = ok ? *reinterpret_cast<const bf16x8*>(p.a + ((long)(b * H + iy) * W + ix) * Cin) : zero8;
+    }
+    for (int n0 = 0; n0 < N; n0 += 80) {                // (N % 80 == 0: the launcher)
+      f32x4 acc[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tap = 4 * s + kq;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {                   // A operand: lane (j, kq) holds weight row n0 + 16 i + j, tap 4 s + kq
+          const bf16x8 wf = tap < 9 ? *reinterpret_cast<const bf16x8*>(sw + (long)(n0 + 16 * i + j) * kScWRow + tap * 8) : zero8;
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s], acc[i], 0, 0, 0);
+        }
+      }
+      // lane (j, kq) holds outputs n0 + 16 i + 4 kq + {0..3} of pixel x: through the wave's patch, out as 160 contiguous bytes per pixel
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        f32x4 v = acc[i];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * i + 4 * kq);
+        *reinterpret_cast<u32x2*>(stage + j * kScStage + (16 * i + 4 * kq) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations complete in order)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int piece = lane + 64 * r;                // 16 pixels x 10 pieces of 16 bytes
+        if (piece < 160) {
+          const int pj = piece / 10, c16 = piece - pj * 10;
+          const u32x4 o = *reinterpret_cast<const u32x4*>(stage + pj * kScStage + c16 * 16);
+          const int px = tx * 16 + pj;
+          if (px < W) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.c) + ((long)(b * H + y) * W + px) * p.ldc + n0 + c16 * 8) = o;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the patch is read before the next 80 channels overwrite it
+    }
+  }
+}
+
 bool conv_small_n_serves(const mx_gemm_desc* d) {
   static const bool off = [] { const char* e = getenv("MX_CONV_SMALL_N"); return e && e[0] == '0'; }();      // A/B: the generic tile kernel
   if (off || d->n_segs != 0 || d->N > 16 || d->N % 4 != 0 || d->Cin % 64 != 0) return false;
@@ -129,6 +213,23 @@ bool conv_small_n_serves(const mx_gemm_desc* d) {
   if ((((long)d->N * d->K * 2 + 255) & ~255L) + (long)kSnPix * kSnStride > 64 * 1024 || d->ldc % 4 != 0) return false;      // weights + one staged chunk within 64 KB of LDS
   if ((long)d->B * d->Hin * d->Win * d->Cin >= 2147483647L) return false;          // 32-bit source offsets
   return true;
+}
+
+bool conv_small_cin_serves(const mx_gemm_desc* d) {
+  static const bool off = [] { const char* e = getenv("MX_CONV_SMALL_CIN"); return e && e[0] == '0'; }();     // A/B: the tile kernels over the padded input
+  if (off || d->n_segs != 0 || d->cin_valid <= 0 || d->cin_valid > 8 || d->Cin % 8 != 0 || d->N % 80 != 0) return false;
+  if (d->stride != 1 || d->up != 0 || d->vhalo != 0 || d->flags != 0) return false;
+  if (d->rowbias || d->residual || d->gate || d->out_scale != 0.f || d->gn_part_out || d->splitk > 1 || d->ldc % 8 != 0) return false;
+  if ((((long)d->N * kScWRow * 2 + 255) & ~255L) + 4L * 16 * kScStage > 64 * 1024) return false;      // repacked weights + output staging within 64 KB of LDS
+  return true;
+}
+
+int launch_conv_small_cin(hipStream_t s, const GemmArgs& a) {
+  const int tiles = a.B * ((a.Hin + 3) / 4) * ((a.Win + 15) / 16);
+  const size_t lds = (((size_t)a.N * kScWRow * 2 + 255) & ~(size_t)255) + 4 * 16 * kScStage;
+  const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 256))));
+  hipLaunchKernelGGL(conv3x3_small_cin_kernel, dim3(std::min(tiles, per_cu * cu_count())), dim3(256), lds, s, a);
+  return 0;
 }
 
 int launch_conv_small_n(hipStream_t s, const GemmArgs& a) {

@@ -194,6 +194,8 @@ bool small_m_serves(const mx_gemm_desc* d, bool conv);      // gemm_small_m.hip:
 int launch_small_m(hipStream_t s, const GemmArgs& a);
 bool conv_small_n_serves(const mx_gemm_desc* d);                // conv_small_n.hip: 3x3 conv with N <= 16 output channels (conv_out)
 int launch_conv_small_n(hipStream_t s, const GemmArgs& a);
+bool conv_small_cin_serves(const mx_gemm_desc* d);              // conv_small_n.hip: 3x3 conv over <= 8 non-zero input channels (conv_in)
+int launch_conv_small_cin(hipStream_t s, const GemmArgs& a);
 
 // Tile choice for the pipelined kernels.  Candidates (token rows x features): 256x256 (gemm_bf16_v3.hip), 256x160, 256x128,
 // 128x160, 128x128 (gemm_bf16_v2.hip).  Estimated cost = full-chip rounds of 256 workgroups (one per CU) x (rows + features):
@@ -568,6 +570,8 @@ static int launch(void* stream, const mx_gemm_desc* d, bool conv) {
     launch_small_m(s, a);                      // M <= 16: a weight stream (gemm_small_m.hip)
   } else if (conv && conv_small_n_serves(d)) {
     launch_conv_small_n(s, a);                 // N <= 16: the input read once (conv_small_n.hip)
+  } else if (conv && conv_small_cin_serves(d)) {
+    launch_conv_small_cin(s, a);               // <= 8 non-zero input channels: K = 72 (conv_small_n.hip)
   } else if (v2bn == 256) {
     MX_CHECK(launch_v4(s, a) == 0, "gemm: no 256 x 256 instantiation serves ln_final with this epilogue (GEGLU, QKV or plain bias only)");   // 256 x 256 ping-pong (gemm_bf16_v4.hip)
   } else if (v2bn) {
@@ -642,6 +646,7 @@ extern "C" int mx_gemm_form(const mx_gemm_desc* d, int conv) {
   if (!d || mx::rows_of(d) <= 0 || d->N <= 0 || d->K <= 0) return MX_FORM_TILE_GENERIC;
   if (mx::small_m_serves(d, conv != 0)) return MX_FORM_SMALL_M;
   if (conv && mx::conv_small_n_serves(d)) return MX_FORM_CONV_SMALL_N;
+  if (conv && mx::conv_small_cin_serves(d)) return MX_FORM_CONV_SMALL_CIN;
   const mx::TileChoice tc = mx::pick_tile(d, conv != 0);
   return tc.bn == 256 ? MX_FORM_PERSISTENT_256 : tc.bn == 0 ? MX_FORM_TILE_GENERIC : tc.rows == 256 ? MX_FORM_TILE_256 : MX_FORM_TILE_128;
 }

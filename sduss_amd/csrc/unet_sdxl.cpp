@@ -441,6 +441,7 @@ struct Plan {
   // 3x3 conv over the images of every group at the current level (Hin, Win: the first group's size; the others come from ch / cw).  A mixed
   // batch is ONE grouped launch: problem g = group g's images, its output grid, its samples' rows of the time-embedding row bias.
   // gn_part / gn_done: ask the launch to leave the GroupNorm partial sums of its output (mx_gemm_desc.gn_part_out); *gn_done tells whether it could
+  int conv_cin_valid = 0;   // set around conv_in's launch
   bool conv(const bf16_t* x, int Hin, int Win, int Cin, const std::string& prefix, bf16_t* out, int Cout, int stride, int up,
             int corner_patch, const float* rowbias = nullptr, int ldrb = 0, const void* residual = nullptr, int vhalo = 0, float* gn_part = nullptr,
             bool* gn_done = nullptr) {
@@ -471,6 +472,7 @@ struct Plan {
       d.segs = sg; d.n_segs = ng;
     }
     if (gn_part && gn_done && ng == 1 && mx_gemm_gn_partials_supported(&d, 1)) { d.gn_part_out = gn_part; *gn_done = true; }
+    d.cin_valid = conv_cin_valid;             // (conv_in only: the latent's channels inside its zero-padded rows)
     return gemm(d, true);
   }
   bool groupnorm(const bf16_t* x, bf16_t* y, const std::string& prefix, int h, int wd, int C, float eps, bool silu, int patch,
@@ -1007,7 +1009,7 @@ struct Plan {
       halo_exchange(x0p, h, wd, kConvInPad);
       conv(x0p, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0, nullptr, 0, nullptr, 1);
     } else
-    conv(x0, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0);  // patches are cut from the true latent: no corner rule (unet.py:123-158)
+    { conv_cin_valid = c.in_channels <= 8 ? 8 : 0; conv(x0, h, wd, kConvInPad, "conv_in", x, C0, 1, 0, 0); conv_cin_valid = 0; }  // patches are cut from the true latent: no corner rule (unet.py:123-158)
     dump("conv_in", x, (size_t)rows() * C0);
 
     struct Skip { bf16_t* t; int C; int h, wd; int level; };

@@ -48,7 +48,7 @@ class GemmDesc(C.Structure):
         ("gate", C.c_void_p), ("ldg", C.c_int), ("out_scale", C.c_float), ("rms_wq", C.c_void_p), ("rms_wk", C.c_void_p), ("rms_eps", C.c_float), ("vhalo", C.c_int), ("a2", C.c_void_p), ("lda2", C.c_int), ("k_split", C.c_int),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_slabs", C.c_int), ("ln_eps", C.c_float), ("stats_out", C.c_void_p),
         ("segs", C.POINTER(GemmSeg)), ("n_segs", C.c_int), ("splitk", C.c_int),
-        ("ln_final", C.c_void_p), ("ln_final_out", C.c_void_p), ("ln_final_cnt", C.c_void_p), ("gn_part_out", C.c_void_p),
+        ("ln_final", C.c_void_p), ("ln_final_out", C.c_void_p), ("ln_final_cnt", C.c_void_p), ("gn_part_out", C.c_void_p), ("cin_valid", C.c_int),
     ]
 
 

@@ -149,8 +149,10 @@ def gemm_qkv(a: torch.Tensor, w: torch.Tensor, seg: int, period: int, rows_per_b
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, up: int = 0,
-            corner_patch: int = 0, rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, splitk: int = 0, want_gn_partials: bool = False):
-    """x NHWC bf16 [B,H,W,Cin]; w bf16 [Cout, 9*Cin] tap-major; returns NHWC bf16 [B,Ho,Wo,Cout].  ``want_gn_partials``: also return the per-64-row,
+            corner_patch: int = 0, rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, splitk: int = 0, want_gn_partials: bool = False,
+            cin_valid: int = 0):
+    """x NHWC bf16 [B,H,W,Cin]; w bf16 [Cout, 9*Cin] tap-major; returns NHWC bf16 [B,Ho,Wo,Cout].  ``cin_valid`` > 0: the caller's promise that only the first
+    cin_valid (<= 8) channels of x are non-zero (mx_gemm_desc.cin_valid: conv_in's zero-padded latent).  ``want_gn_partials``: also return the per-64-row,
     per-channel (sum, sum of squares) of its ACCUMULATORS (the output minus bias and row bias) [M / 64, Cout, 2] (mx_gemm_desc.gn_part_out), or None where it cannot."""
     l = _lib.load()
     _bf16(x); _bf16(w)
@@ -166,6 +168,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stri
     d.rows_per_batch = ho * wo
     d.B, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.up, d.corner_patch = b, h, wd, cin, ho, wo, stride, up, corner_patch
     d.splitk = splitk
+    d.cin_valid = cin_valid
     part = None
     if want_gn_partials and l.mx_gemm_gn_partials_supported(C.byref(d), 1):
         part = torch.full((b * ho * wo // 64, cout, 2), float("nan"), dtype=torch.float32, device=x.device)

@@ -426,6 +426,8 @@ def test_layernorm_fold_algebra_and_tile_policy():
     assert form(conv_out(8, 128, 320, 16), 1) != SMALL_N               # 16 x 2880 weights + the staged chunk exceed 64 KB of LDS
     assert form(conv_out(8, 128, 320, 4, stride=2, Hout=64, Wout=64, M=8 * 64 * 64), 1) != SMALL_N and form(conv(8, 128, 320, 4), 1) != SMALL_N      # stride 2; a row bias
     assert form(conv_out(8, 128, 320, 320), 1) == T256
+    assert form(conv_out(8, 128, 64, 320, cin_valid=8), 1) == 6 and form(conv_out(8, 128, 64, 320), 1) == T256      # conv_in: only when the caller names the valid channels
+    assert form(conv_out(8, 128, 64, 128, cin_valid=8), 1) != 6 and form(conv_out(8, 128, 64, 320, cin_valid=16), 1) != 6                  # N % 80; more than 8 channels
 
 
 def test_clip_plan_resolves_packed_weights_on_host():

@@ -172,6 +172,24 @@ def test_conv3x3_small_n(cuda_device, corner, h, w, cin, cout, b):
         _close(got2.permute(0, 3, 1, 2), F.conv2d(x, wt, None, padding=1), 2.0 ** -7, "conv3x3 small N, no bias")
 
 
+@pytest.mark.parametrize("corner,h,w,cout,b,cv", [(0, 16, 16, 80, 2, 4), (0, 12, 20, 320, 3, 4), (4, 16, 16, 160, 2, 8), (0, 7, 9, 80, 2, 3), (0, 128, 128, 320, 2, 4)])
+def test_conv3x3_small_cin(cuda_device, corner, h, w, cout, b, cv):
+    """a handful of non-zero input channels inside rows padded to 64 (conv_small_n.hip, conv3x3_small_cin_kernel: the UNet's conv_in): same result as the tile
+    kernel over the padded input, which the oracle checks"""
+    from sduss_amd import lib, ops
+    g = torch.Generator().manual_seed(corner * 7 + h + cout + cv)
+    x = torch.zeros(b, 64, h, w)
+    x[:, :cv] = _rt(torch.randn(b, cv, h, w, generator=g))
+    wt = _rt(torch.randn(cout, 64, 3, 3, generator=g) * (9 * cv) ** -0.5)     # (weights of the padded channels: anything -- they meet zeros)
+    bias = torch.randn(cout, generator=g)
+    want = ref.conv3x3(x, wt, bias, 1, corner if corner else None)
+    xd, wd = _bf(_nhwc(x)).cuda(), _bf(_conv_pack(wt)).cuda()
+    got = ops.conv3x3(xd, wd, bias.cuda(), corner_patch=corner, cin_valid=8)
+    _close(got.permute(0, 3, 1, 2), want, 2.0 ** -7, f"conv3x3 small Cin corner{corner}")
+    plain = ops.conv3x3(xd, wd, bias.cuda(), corner_patch=corner)                  # the tile kernel over all 64 channels
+    _close(got.permute(0, 3, 1, 2), plain.float().cpu().permute(0, 3, 1, 2), 2.0 ** -7, "small Cin vs the tile kernel")
+
+
 def test_conv3x3_rowbias_residual(cuda_device):
     from sduss_amd import ops
     g = torch.Generator().manual_seed(9)
