@@ -80,14 +80,70 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_small_m_kernel(const GemmArgs
   }
 }
 
+// The LONG stream (N K > 32 M weights: the MMDiT's stacked AdaLN modulation, 1.4 GB): no K split, no barrier in the loop.  The <= 16 activation rows are staged once per
+// workgroup in LDS (row stride K + 8 elements: the 16 rows' pieces fall on distinct banks); every WAVE then owns 16 output features at a time over the whole K, eight
+// 16-byte weight loads in flight per lane, each row read front to back as whole lines, and walks on to its next group.  (The K-split form above reached 3.5-3.9 TB/s
+// on this size -- two barriers per group drain its loads -- the tile kernel 4.45.)
+template <bool F32OUT>
+__global__ __launch_bounds__(256) void gemm_small_m_stream_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char xs_raw[];      // X [16][K + 8] bf16, rows >= M zero
+  bf16_t* xs = reinterpret_cast<bf16_t*>(xs_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int K = p.K, ldx = K + 8;
+  for (int c = tid; c < 16 * (K >> 3); c += 256) {
+    const int row = c / (K >> 3), piece = c - row * (K >> 3);
+    *reinterpret_cast<u32x4*>(xs + (long)row * ldx + piece * 8) = row < p.M ? *reinterpret_cast<const u32x4*>(p.a + (long)row * p.lda + piece * 8) : u32x4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  const bf16_t* xl = xs + (long)r * ldx + kq * 8;
+  const int steps = K >> 5;
+  const int ngroups = p.N >> 4;
+  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+    const int n0 = grp * 16;
+    const bf16_t* wp = p.w + (long)(n0 + r) * K + kq * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= steps; s += 8) {
+      bf16x8 wf[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (long)(s + u) * 32));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], *reinterpret_cast<const bf16x8*>(xl + (s + u) * 32), acc, 0, 0, 0);
+    }
+    for (; s < steps; ++s)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (long)s * 32)), *reinterpret_cast<const bf16x8*>(xl + s * 32), acc, 0, 0, 0);
+    // lane (r, kq) holds row m = r, features n0 + 4 kq + {0..3}
+    const int m = r, n = n0 + 4 * kq;
+    if (m < p.M) {
+      f32x4 v = acc;
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.residual) {
+        const u32x2 rr = *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
+        v[0] += bf16lo_to_f32(rr[0]); v[1] += bf16hi_to_f32(rr[0]); v[2] += bf16lo_to_f32(rr[1]); v[3] += bf16hi_to_f32(rr[1]);
+      }
+      if (p.flags & MX_EPI_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+      }
+      if constexpr (F32OUT) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c) + (long)m * p.ldc + n) = v;
+      else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.c) + (long)m * p.ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+  }
+}
+
+constexpr long kSmallMLong = 32L << 20;        // weights (elements) from which the launch is a LONG stream
+static bool small_m_long_fits(long K) { return 16L * (K + 8) * 2 <= 64 * 1024; }      // the staged activations within 64 KB of LDS
+
 // does this form serve d?  (plain linear layers only: bias, per-row residual, SiLU, bf16 or fp32 out)
 bool small_m_serves(const mx_gemm_desc* d, bool conv) {
   static const bool off = [] { const char* e = getenv("MX_SMALL_M"); return e && e[0] == '0'; }();      // A/B: the generic tile kernel
   if (off || conv || d->n_segs != 0 || d->M <= 0 || d->M > kSmallMRows) return false;
   if (d->N % 16 != 0 || d->K % 64 != 0) return false;
-  // beyond ~64 MB of weights the tile kernel's LDS-staged stream is the faster one (the MMDiT's stacked AdaLN modulation, 1.36 GB: 305 vs 390 us; at 340 MB a tie:
-  // profiles/r05_q_small_m.txt)
-  if ((long)d->N * d->K > (32L << 20)) return false;
+  // a long stream (> 64 MB of weights) runs the no-split form, which stages the activations in LDS: K <= 2040; beyond that the tile kernel
+  if ((long)d->N * d->K > kSmallMLong && !small_m_long_fits(d->K)) return false;
   if (d->flags & ~(MX_EPI_SILU | MX_EPI_OUT_F32)) return false;
   if (d->rowbias || d->gate || d->vt || d->a2 || d->ln_stats || d->ln_final || d->stats_out || d->ln_final_out || d->gn_part_out) return false;
   if (d->out_scale != 0.f || d->a_batch_rows > 0 || d->c_batch_rows > 0 || d->splitk > 1) return false;
@@ -100,10 +156,18 @@ int launch_small_m(hipStream_t s, const GemmArgs& a) {
   const int ncu = cu_count();
   // few groups (N 1280: 80): sixteen waves split K, so that a wave's share is one or two rounds of loads; many (the stacked projections): four waves per
   // workgroup and as many consecutive groups per workgroup as keep ~8 workgroups per CU busy for the launch's life
+  const bool f32 = (a.flags & MX_EPI_OUT_F32) != 0;
+  if ((long)a.N * a.K > kSmallMLong) {          // the long stream: persistent waves, one 16-feature group at a time over the whole K
+    const size_t lds = 16 * (size_t)(a.K + 8) * 2;
+    const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 256))));
+    const dim3 grid((unsigned)std::min(cdiv(ngroups, 4), per_cu * ncu));
+    if (f32) hipLaunchKernelGGL((gemm_small_m_stream_kernel<true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((gemm_small_m_stream_kernel<false>), grid, dim3(256), lds, s, a);
+    return 0;
+  }
   const bool wide = ngroups < 2 * ncu && a.K >= 1024;
   const int groups = wide ? 1 : std::max(1, std::min(16, ngroups / (8 * ncu)));
   const dim3 grid((unsigned)cdiv(ngroups, groups));
-  const bool f32 = (a.flags & MX_EPI_OUT_F32) != 0;
   if (wide) {
     if (f32) hipLaunchKernelGGL((gemm_small_m_kernel<true, 16>), grid, dim3(1024), 0, s, a, groups);
     else hipLaunchKernelGGL((gemm_small_m_kernel<false, 16>), grid, dim3(1024), 0, s, a, groups);

@@ -53,7 +53,8 @@ def test_gemm_bias_residual(cuda_device, m, n, k):
     _close(got, F.silu(a @ w.t() + b), 1e-4, "gemm+silu f32")
 
 
-@pytest.mark.parametrize("m,n,k", [(8, 1280, 2816), (8, 1280, 320), (2, 1280, 1280), (16, 1536, 256), (1, 64, 64), (8, 13760, 1280), (5, 48, 192), (8, 1536, 2048)])
+@pytest.mark.parametrize("m,n,k", [(8, 1280, 2816), (8, 1280, 320), (2, 1280, 1280), (16, 1536, 256), (1, 64, 64), (8, 13760, 1280), (5, 48, 192), (8, 1536, 2048),
+                                   (8, 36864, 1536), (3, 22016, 1600)])      # the last two: > 32 M weights, the long-stream form (K % 256 == 0 and a remainder)
 def test_gemm_small_m_weight_stream(cuda_device, m, n, k):
     """M <= 16 (gemm_small_m.hip: the time / condition embedding MLPs, the stacked time_emb_proj and AdaLN modulation): every epilogue the plans use on it"""
     from sduss_amd import ops
