@@ -231,7 +231,7 @@ int mx_gemm_gn_partials_supported(const mx_gemm_desc* d, int conv);   /* 1 when 
  *   MX_FORM_TILE_256       a 256-row tile of the ping-pong kernels (256 x 160 / 128, one tile per CU)
  *   MX_FORM_TILE_128       a 128-row tile of the lock-step LDS-DMA kernel (small M; possibly split along K)
  *   MX_FORM_PERSISTENT_256 the persistent 256 x 256 kernel
- *   MX_FORM_SMALL_M        round 5: M <= 16 rows as a weight stream (bias, per-row residual, SiLU, bf16 / fp32 out; N % 16 == 0; above 64 MB of weights K <= 2040)
+ *   MX_FORM_SMALL_M        round 5: M <= 16 rows as a weight stream (bias, per-row residual, SiLU, bf16 / fp32 out; N % 16 == 0; above 64 MB of weights M (K + 8) <= 32 K elements)
  *   MX_FORM_CONV_SMALL_N   round 5: 3 x 3 conv with N <= 16 output channels (stride 1, bias only; weights + one staged chunk within 64 KB of LDS)
  *   MX_FORM_CONV_SMALL_CIN round 5: 3 x 3 conv whose descriptor names cin_valid <= 8 input channels (stride 1, bias only, N % 80 == 0) */
 enum { MX_FORM_TILE_GENERIC = 0, MX_FORM_TILE_256 = 1, MX_FORM_TILE_128 = 2, MX_FORM_PERSISTENT_256 = 3, MX_FORM_SMALL_M = 4, MX_FORM_CONV_SMALL_N = 5, MX_FORM_CONV_SMALL_CIN = 6 };

@@ -86,19 +86,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_small_m_kernel(const GemmArgs
 // on this size -- two barriers per group drain its loads -- the tile kernel 4.45.)
 template <bool F32OUT>
 __global__ __launch_bounds__(256) void gemm_small_m_stream_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char xs_raw[];      // X [16][K + 8] bf16, rows >= M zero
+  extern __shared__ __attribute__((aligned(16))) char xs_raw[];      // X [M][K + 8] bf16 (lanes of rows >= M read row M - 1: their results are never stored)
   bf16_t* xs = reinterpret_cast<bf16_t*>(xs_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
   const int K = p.K, ldx = K + 8;
-  for (int c = tid; c < 16 * (K >> 3); c += 256) {
+  for (int c = tid; c < p.M * (K >> 3); c += 256) {
     const int row = c / (K >> 3), piece = c - row * (K >> 3);
-    *reinterpret_cast<u32x4*>(xs + (long)row * ldx + piece * 8) = row < p.M ? *reinterpret_cast<const u32x4*>(p.a + (long)row * p.lda + piece * 8) : u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(xs + (long)row * ldx + piece * 8) = *reinterpret_cast<const u32x4*>(p.a + (long)row * p.lda + piece * 8);
   }
   __syncthreads();
-  const bf16_t* xl = xs + (long)r * ldx + kq * 8;
+  const bf16_t* xl = xs + (long)(r < p.M ? r : p.M - 1) * ldx + kq * 8;
   const int steps = K >> 5;
   const int ngroups = p.N >> 4;
   for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
@@ -135,15 +135,15 @@ __global__ __launch_bounds__(256) void gemm_small_m_stream_kernel(const GemmArgs
 }
 
 constexpr long kSmallMLong = 32L << 20;        // weights (elements) from which the launch is a LONG stream
-static bool small_m_long_fits(long K) { return 16L * (K + 8) * 2 <= 64 * 1024; }      // the staged activations within 64 KB of LDS
+static bool small_m_long_fits(long M, long K) { return M * (K + 8) * 2 <= 64 * 1024; }      // the staged activations within 64 KB of LDS
 
 // does this form serve d?  (plain linear layers only: bias, per-row residual, SiLU, bf16 or fp32 out)
 bool small_m_serves(const mx_gemm_desc* d, bool conv) {
   static const bool off = [] { const char* e = getenv("MX_SMALL_M"); return e && e[0] == '0'; }();      // A/B: the generic tile kernel
   if (off || conv || d->n_segs != 0 || d->M <= 0 || d->M > kSmallMRows) return false;
   if (d->N % 16 != 0 || d->K % 64 != 0) return false;
-  // a long stream (> 64 MB of weights) runs the no-split form, which stages the activations in LDS: K <= 2040; beyond that the tile kernel
-  if ((long)d->N * d->K > kSmallMLong && !small_m_long_fits(d->K)) return false;
+  // a long stream (> 64 MB of weights) runs the no-split form, which stages the M x K activations in LDS (64 KB); beyond that the tile kernel
+  if ((long)d->N * d->K > kSmallMLong && !small_m_long_fits(d->M, d->K)) return false;
   if (d->flags & ~(MX_EPI_SILU | MX_EPI_OUT_F32)) return false;
   if (d->rowbias || d->gate || d->vt || d->a2 || d->ln_stats || d->ln_final || d->stats_out || d->ln_final_out || d->gn_part_out) return false;
   if (d->out_scale != 0.f || d->a_batch_rows > 0 || d->c_batch_rows > 0 || d->splitk > 1) return false;
@@ -158,8 +158,8 @@ int launch_small_m(hipStream_t s, const GemmArgs& a) {
   // workgroup and as many consecutive groups per workgroup as keep ~8 workgroups per CU busy for the launch's life
   const bool f32 = (a.flags & MX_EPI_OUT_F32) != 0;
   if ((long)a.N * a.K > kSmallMLong) {          // the long stream: persistent waves, one 16-feature group at a time over the whole K
-    const size_t lds = 16 * (size_t)(a.K + 8) * 2;
-    const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (lds + 256))));
+    const size_t lds = (size_t)a.M * (a.K + 8) * 2;
+    const int per_cu = std::max(1, std::min(6, (int)((160 * 1024) / (lds + 256))));
     const dim3 grid((unsigned)std::min(cdiv(ngroups, 4), per_cu * ncu));
     if (f32) hipLaunchKernelGGL((gemm_small_m_stream_kernel<true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((gemm_small_m_stream_kernel<false>), grid, dim3(256), lds, s, a);

@@ -415,7 +415,7 @@ def test_layernorm_fold_algebra_and_tile_policy():
     assert form(desc(8, 1280, 2816, lib.EPI_SILU)) == SMALL_M and form(desc(16, 13760, 1280, lib.EPI_OUT_F32)) == SMALL_M and form(desc(1, 64, 64)) == SMALL_M
     assert form(desc(17, 1280, 2816)) == GENERIC                      # one row past the form's reach
     assert form(desc(8, 442368, 1536, lib.EPI_OUT_F32)) == SMALL_M    # the MMDiT's stacked AdaLN modulation (1.4 GB of weights): the long-stream form (activations staged in LDS)
-    assert form(desc(8, 65536, 4096, lib.EPI_OUT_F32)) == GENERIC     # a long stream whose 16 x K activations exceed 64 KB of LDS: the tile kernel
+    assert form(desc(16, 65536, 4096, lib.EPI_OUT_F32)) == GENERIC    # a long stream whose M x K activations exceed 64 KB of LDS: the tile kernel
     assert form(desc(8, 1280, 1280, lib.EPI_GEGLU)) == GENERIC and form(desc(8, 1288, 1280)) == GENERIC      # gated epilogue / N % 16 != 0
     assert form(desc(8192, 1280, 1280)) == T256 and form(desc(2048, 1280, 1280)) == T128 and form(desc(8192, 10240, 1280, lib.EPI_GEGLU)) == P256
     def conv_out(b, hw, cin, cout, **kw):
