@@ -106,6 +106,13 @@ __global__ __launch_bounds__(256) void gemm_small_m_stream_kernel(const GemmArgs
     const bf16_t* wp = p.w + (long)(n0 + r) * K + kq * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int s = 0;
+    for (; s + 16 <= steps; s += 16) {                  // sixteen 16-byte loads in flight per lane (1 KB of every one of the wave's 16 rows)
+      bf16x8 wf[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (long)(s + u) * 32));
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], *reinterpret_cast<const bf16x8*>(xl + (s + u) * 32), acc, 0, 0, 0);
+    }
     for (; s + 8 <= steps; s += 8) {
       bf16x8 wf[8];
 #pragma unroll
