@@ -167,8 +167,7 @@ __device__ __forceinline__ void gemm_ln_row(const GemmArgs& p, const int m, cons
     const f32x2 v = *reinterpret_cast<const f32x2*>(p.ln_stats + ((long)mc * pitch + s) * 2);
     s1 += v[0]; s2 += v[1];
   }
-  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+  s1 = sum_over_fq(s1); s2 = sum_over_fq(s2);
   const float inv = 1.0f / (float)p.K;
   const float mean = s1 * inv;
   const float var = fmaxf(fmaf(-mean, mean, s2 * inv), 0.f);
@@ -363,8 +362,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const float t = acc[i][j][q] + (p.bias ? p.bias[n + q] : 0.f); ss += t * t; }
       }
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
+      ss = sum_over_fq(ss);
       rms_mul = rsqrtf(ss * (1.0f / 64.0f) + p.rms_eps) * ((seg_pos == 0 && p.out_scale != 0.f) ? p.out_scale : 1.0f);
     }
     if (m >= p.M) continue;
@@ -767,8 +765,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const float t = acc[i][j][q] + bias_r[i][q]; ss = fmaf(t, t, ss); }
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
+      ss = sum_over_fq(ss);
       rms_mul = rsqrtf(fmaf(ss, 1.0f / 64.0f, p.rms_eps)) * ((seg_pos == 0 && p.out_scale != 0.f) ? p.out_scale : 1.0f);
     }
 #pragma unroll
@@ -895,8 +892,7 @@ __device__ __forceinline__ void gemm_epilogue_regs(const GemmArgs& p, f32x4 (&ac
       if (m < p.M) store_c8(row_own(j), col0 + NP * 32 + fq * 4, u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])});
     }
     if (stats) {                               // the token's four lanes hold disjoint columns of the wave's panel: slab = panel index
-      st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
-      st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
+      st1 = sum_over_fq(st1); st2 = sum_over_fq(st2);      // (round 5: permlane swaps instead of four trips through the LDS crossbar per token block; same sums, same order)
       if (fq == 0 && m < p.M) {
         const int slab = wave_n0 / (16 * NI), pitch = (p.N / (16 * NI) + 3) & ~3;
         float* dst = p.stats_out + ((long)m * pitch + slab) * 2;
